@@ -1,0 +1,123 @@
+"""Pins the CPU oracle (oracle/) against every known answer the reference's tests hold for the
+hot path and against the golden vectors generated from the reference (tests/golden/)."""
+import random
+
+import numpy as np
+import pytest
+
+from conftest import load_json, load_carsonella
+
+
+def test_one_hot_matches_reference(oracle):
+    kat = load_json("knn_kat.json")["one_hot"]
+    assert oracle.one_hot_encode(kat["in"]) == kat["out"]
+
+
+def test_three_row_kat(oracle):
+    # reference tests/test_core.py:116-126
+    kat = load_json("knn_kat.json")["three_row"]
+    tp = oracle.OracleTargetProcessor(kat["targets"], "hamming", kat["editdist"], kat["knum"])
+    tp.create_index()
+    tp.get_neighbors()
+    e = kat["expect"]
+    assert tp.neighbors[e["key"]]["neighbors"]["dist"][e["dist_index"]] == e["dist_value"]
+    assert tp.db == ["AAATGGTACGTTATGTGTTA", "AACAGTAAAATGGTTTAATG"]
+
+
+def test_levin_kat(oracle):
+    # reference tests/test_core.py:319-347
+    kat = load_json("knn_kat.json")["levin"]
+    for dtype, expect in (("levin", kat["expect_leven_dist"]), ("hamming", kat["expect_hamming_dist"])):
+        tp = oracle.OracleTargetProcessor(kat["targets"], dtype, kat["editdist"], kat["knum"])
+        tp.create_index()
+        tp.get_neighbors()
+        assert tp.neighbors[kat["expect_key"]]["neighbors"]["dist"] == expect
+
+
+def test_knum_larger_than_index(oracle):
+    # reference tests/test_core.py:129-139: knum=10 on a 2-point index must not crash
+    kat = load_json("knn_kat.json")["three_row"]
+    tp = oracle.OracleTargetProcessor(kat["targets"], "hamming", 2, 10)
+    tp.create_index()
+    tp.get_neighbors()
+    assert tp.neighbors["AAATGGTACGTTATGTGTTA"]["neighbors"]["dist"] == [0, 12]
+
+
+def test_cfd_golden(oracle, cfd_table):
+    cases = load_json("cfd_kat.json")["cases"]
+    assert len(cases) > 1000
+    # reference tests/test_core.py:265-267
+    assert abs(oracle.calc_cfd(cases[0]["guide"], cases[0]["off"], cfd_table) - 0.176470588) < 1e-4
+    for c in cases:
+        want = float.fromhex(c["cfd_hex"])
+        assert oracle.calc_cfd(c["guide"], c["off"], cfd_table) == want          # bit-exact
+    by_len = {}
+    for c in cases:
+        by_len.setdefault(len(c["guide"]), []).append(c)
+    for L, cs in by_len.items():
+        got = oracle.cfd_batch([c["guide"] for c in cs], [c["off"] for c in cs], L, cfd_table)
+        want = np.array([float.fromhex(c["cfd_hex"]) for c in cs])
+        assert (got == want).all()
+
+
+def test_cfd_unequal_length_asserts(oracle, cfd_table):
+    with pytest.raises(AssertionError):
+        oracle.calc_cfd("ACGT", "ACG", cfd_table)
+
+
+def test_c_distances_match_pure_python(oracle):
+    rng = random.Random(3)
+    for L in (10, 20, 23, 27):
+        seqs = ["".join(rng.choice("ACGT") for _ in range(L)) for _ in range(12)]
+        # plant near neighbours incl. an indel
+        seqs.append(seqs[0][1:] + "A")
+        seqs.append(seqs[1][:5] + "T" + seqs[1][5:-1])
+        oh = oracle.one_hot_encode(seqs)
+        mh = oracle.dist_matrix(seqs, seqs, L, "hamming")
+        ml = oracle.dist_matrix(seqs, seqs, L, "leven")
+        arr = np.frombuffer("".join(seqs).encode(), np.uint8).reshape(len(seqs), L)
+        assert (mh == 2 * oracle.np_hamming_matrix(arr, arr)).all()
+        for i in range(len(seqs)):
+            for j in range(len(seqs)):
+                assert mh[i, j] == oracle.py_bit_hamming(oh[i], oh[j])
+                assert ml[i, j] == oracle.py_leven(seqs[i], seqs[j])
+
+
+def test_knn_is_sorted_and_canonical(oracle):
+    rng = random.Random(5)
+    L, n = 20, 300
+    db = ["".join(rng.choice("ACGT") for _ in range(L)) for _ in range(n)]
+    for metric in ("hamming", "leven"):
+        ids, dists, counts = oracle.knn(db, db[:50], L, metric, 7)
+        full = oracle.dist_matrix(db, db[:50], L, metric)
+        for i in range(50):
+            order = sorted(range(n), key=lambda j: (full[i, j], j))[:7]
+            assert ids[i].tolist() == order
+            assert dists[i].tolist() == [int(full[i, j]) for j in order]
+            assert counts[i] == 7
+
+
+def test_carsonella_summary(oracle):
+    summ = load_json("carsonella_summary.json")["summary"]
+    # values in SURVEY.md section 8(c), re-derived here by the oracle
+    expect = {"NGG5p": dict(n_db=3814, n_q=3810, retained=3808,
+                            hist=[0, 2, 25, 197, 571, 1104, 1069, 569, 225, 48],
+                            first=[0, 6, 6, 7, 7, 7, 7, 7, 7, 7]),
+              "NGG3p": dict(n_db=3813, n_q=3812, retained=3810,
+                            hist=[0, 2, 32, 162, 564, 1055, 1124, 618, 206, 49],
+                            first=[0, 6, 6, 6, 6, 6, 6, 7, 7, 7])}
+    for tag, e in expect.items():
+        cols = load_carsonella(tag)
+        assert len(cols["target"]) == summ[tag]["n_targets"]
+        tp = oracle.OracleTargetProcessor(cols["target"], "hamming", 2, 10,
+                                          cols["isseedduplicated"], cols["hasrestrictionsite"])
+        tp.create_index()
+        assert len(tp.db) == e["n_db"] == summ[tag]["n_unique"]
+        q = tp.query_list()
+        assert len(q) == e["n_q"] == summ[tag]["n_query"]
+        tp.get_neighbors()
+        assert len(tp.neighbors) == e["retained"]
+        _, dists, _ = tp.knn_raw(q, 10)
+        hist = np.bincount(dists[:, 1] // 2, minlength=10)[:10].tolist()
+        assert hist == e["hist"]
+        assert (dists[0] // 2).tolist() == e["first"]
