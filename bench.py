@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- guide-pair distance comparisons/s of the MI355X neighbour search.
+
+  python bench.py --gpus N --steps K --warmup W          (N=1 default)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch: the k-NN scan of every candidate guide of the
+workload against the whole target pool (TargetProcessor.get_neighbors' knnQueryBatch), inputs
+already resident in HBM, outputs left in HBM.  Workload at N=1 = BASELINE.json configs[1] (E. coli
+NGG L=20 hamming k=10) as the synthetic stand-in S1 (no real genome exists offline).  For N>1 every
+rank holds the full pool (replicated db) and scans its own, equally large shard of candidates (weak
+scaling: rank r>0 gets the candidates of a further S1-like genome), followed by ONE RCCL
+all-gather of the per-shard neighbour lists (ids, dists, counts).
+
+Prints one JSON line (rank 0) with the contract fields plus `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+B_ALG = {"hamming": 16, "leven": 16}     # algorithmic bytes per guide pair: two 8-byte packed operands
+VALU_LANE_OPS_PER_S = 256 * 128 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz
+OPS_ALG = {"hamming": 3.5}               # xor, bitop3, bcnt(+offset), 1/2 min3 per pair
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="s1", choices=["s1", "s2", "s3", "s4", "tiny"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(pool, seconds):
+    """The oracle's exact scan (restatement of nmslib brute_force + bit_hamming/leven), all host
+    threads, on a bounded sample: the first q_s candidates against the FULL pool."""
+    from oracle import oracle as orc
+    from guidemaker_amd import _lib
+    orc.build()
+    L, metric, k = pool["guidelen"], pool["metric"], pool["k"]
+    db = np.frombuffer("".join(_lib.unpack(pool["packed_db"], L)).encode(), np.uint8).reshape(-1, L)
+    threads = orc.lib().orc_max_threads()
+    q_s = min(db.shape[0], 256 if metric == "hamming" else 16)
+    for _ in range(4):      # grow the sample until it costs about `seconds` of CPU time
+        t0 = time.perf_counter()
+        orc.knn(db, db[:q_s], L, metric, k, threads)
+        dt = max(time.perf_counter() - t0, 1e-4)
+        if dt >= 0.6 * seconds or q_s == db.shape[0]:
+            break
+        q_s = int(min(db.shape[0], max(q_s + 1, q_s * seconds / dt)))
+    return {"value": q_s * db.shape[0] / dt, "unit": "guide-pair comparisons/s", "cores": threads,
+            "kind": "port",
+            "sample": "%d candidates x %d targets (full pool), %s, k=%d, %.1f s, OpenMP exact scan "
+                      "(oracle/gm_oracle.c: nmslib brute_force restated)" % (q_s, db.shape[0], metric, k, dt)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d"
+                             % (args.gpus, args.gpus))
+    import torch.distributed as dist
+    from guidemaker_amd import _lib, workloads
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libgmhip has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    pool = workloads.make_pool(args.workload)
+    L, k = pool["guidelen"], pool["k"]
+    metric_code = _lib.METRIC_HAMMING if pool["metric"] == "hamming" else _lib.METRIC_LEVEN
+    db_np = pool["packed_db"]
+    n_db = db_np.shape[0]
+    if args.scaling == "weak":
+        n_q = pool["packed_all"].shape[0]
+        if rank == 0:
+            q_np = pool["packed_all"]
+        else:   # a further genome of the same kind supplies this rank's candidates
+            other = workloads.make_pool(args.workload, seed_offset=1000 * rank)["packed_all"]
+            reps = -(-n_q // other.shape[0])
+            q_np = np.tile(other, reps)[:n_q]
+    else:
+        shard = -(-pool["packed_all"].shape[0] // world)
+        n_q = shard
+        q_np = pool["packed_all"][rank * shard:(rank + 1) * shard]
+        if q_np.shape[0] < shard:       # pad the last shard so the all-gather is regular
+            q_np = np.concatenate([q_np, np.tile(q_np[-1:], shard - q_np.shape[0])])
+
+    d_db = torch.from_numpy(db_np.view(np.int64)).to(dev)
+    d_q = torch.from_numpy(np.ascontiguousarray(q_np).view(np.int64)).to(dev)
+    ids = torch.empty((n_q, k), dtype=torch.int32, device=dev)
+    dists = torch.empty((n_q, k), dtype=torch.int32, device=dev)
+    counts = torch.empty((n_q,), dtype=torch.int32, device=dev)
+    if world > 1:
+        g_ids = torch.empty((world * n_q, k), dtype=torch.int32, device=dev)
+        g_dists = torch.empty((world * n_q, k), dtype=torch.int32, device=dev)
+        g_counts = torch.empty((world * n_q,), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    idx = _lib.Index.from_device(d_db.data_ptr(), n_db, L, metric_code, local_rank, stream)
+
+    def step():
+        idx.knn_dev(d_q.data_ptr(), n_q, k, ids.data_ptr(), dists.data_ptr(), counts.data_ptr(), stream)
+        if world > 1:   # the one exchange of the path: per-shard neighbour lists over RCCL/xGMI
+            dist.all_gather_into_tensor(g_ids, ids)
+            dist.all_gather_into_tensor(g_dists, dists)
+            dist.all_gather_into_tensor(g_counts, counts)
+
+    for _ in range(args.warmup):
+        step()
+    idx.timing_reserve(max(1, args.steps))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = idx.timing_read()
+    kname = idx.last_kernel()[0]
+
+    # sanity: every candidate of rank 0 is in the pool, so its nearest hit is itself at distance 0
+    if rank == 0:
+        c = counts.cpu().numpy()
+        d0 = dists[:, 0].cpu().numpy()
+        i0 = ids[:, 0].cpu().numpy()
+        assert (c == min(k, n_db)).all() and (d0 == 0).all(), "bench sanity check failed"
+        uniq_first = np.unique(q_np, return_index=True)[1]
+        assert (db_np[i0[uniq_first]] == q_np[uniq_first]).all(), "bench sanity check failed (ids)"
+
+    if rank == 0:
+        pairs_per_step = float(world) * n_q * n_db
+        value = pairs_per_step * args.steps / elapsed
+        kern_s = float(np.mean(kernel_ms)) * 1e-3
+        launch_pairs = float(n_q) * n_db
+        achieved = launch_pairs * B_ALG[pool["metric"]] / kern_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as fh:
+                traffic = json.load(fh).get(args.workload, {}).get("bytes_per_launch")
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,
+                "kernel_ms_avg": kern_s * 1e3, "launches_timed": int(len(kernel_ms)),
+                "algorithmic_bytes_per_pair": B_ALG[pool["metric"]], "pairs_per_launch": launch_pairs,
+                "note": "algorithmic (no-reuse) operand bytes / HIP-event kernel time; the scan is "
+                        "VALU-bound, not HBM-bound, so frac > 1 means LDS/register reuse beats the "
+                        "streaming model (SURVEY.md 8d)"}
+        if pool["metric"] in OPS_ALG:
+            ops = launch_pairs * OPS_ALG[pool["metric"]] / kern_s
+            roof["valu"] = {"achieved": ops / 1e12, "peak": VALU_LANE_OPS_PER_S / 1e12,
+                            "unit": "T lane-ops/s", "frac": ops / VALU_LANE_OPS_PER_S,
+                            "ops_per_pair": OPS_ALG[pool["metric"]]}
+        out = {
+            "metric": "guide-pair distance comparisons/sec (whole node)",
+            "value": value, "unit": "guide-pair comparisons/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {"workload": pool["label"], "n_candidates_per_gpu": int(n_q), "n_targets": int(n_db),
+                       "guidelen": L, "k": k, "distance": pool["metric"],
+                       "parallelism": "candidate shards x%d, replicated pool, 1 RCCL all-gather" % world},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pool, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    idx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

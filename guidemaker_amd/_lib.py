@@ -1,0 +1,234 @@
+"""ctypes binding of libgmhip.so (include/gmhip.h).  There is no CPU fallback: if the HIP
+library is missing, or no MI355X is visible, every compute call raises."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgmhip.so")
+
+METRIC_HAMMING = 0
+METRIC_LEVEN = 1
+MAX_GUIDELEN = 27
+MAX_K = 64
+
+_lib = None
+
+
+class GmHipError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile guidemaker_amd/libgmhip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    args = ["make", "-s", "-C", os.path.join(_HERE, "csrc")]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args)
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "guidemaker_amd: %s not found. Build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C guidemaker_amd/csrc). "
+            "There is no CPU fallback." % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    c = ctypes
+    vp, i64, i32 = c.c_void_p, c.c_int64, c.c_int
+    L.gm_version.restype = c.c_char_p
+    L.gm_last_error.restype = c.c_char_p
+    L.gm_device_count.restype = i32
+    L.gm_pack.argtypes = [c.c_char_p, i64, i32, vp]
+    L.gm_unpack.argtypes = [vp, i64, i32, vp]
+    L.gm_index_create.argtypes = [vp, i64, i32, i32, i32, c.POINTER(vp)]
+    L.gm_index_create_dev.argtypes = [vp, i64, i32, i32, i32, vp, c.POINTER(vp)]
+    L.gm_index_free.argtypes = [vp]
+    L.gm_index_free.restype = None
+    L.gm_index_size.argtypes = [vp]
+    L.gm_index_size.restype = i64
+    L.gm_index_guidelen.argtypes = [vp]
+    L.gm_index_metric.argtypes = [vp]
+    L.gm_knn_query.argtypes = [vp, vp, i64, i32, vp, vp, vp]
+    L.gm_knn_query_dev.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp]
+    L.gm_nearest_dist.argtypes = [vp, vp, i64, vp]
+    L.gm_nearest_dist_dev.argtypes = [vp, vp, i64, vp, vp]
+    L.gm_cfd_batch.argtypes = [vp, vp, i64, i32, vp, vp, i32]
+    L.gm_cfd_batch_dev.argtypes = [vp, vp, i64, i32, vp, vp, vp]
+    L.gm_last_kernel_ms.argtypes = [vp]
+    L.gm_last_kernel_ms.restype = c.c_double
+    L.gm_last_kernel_name.argtypes = [vp]
+    L.gm_last_kernel_name.restype = c.c_char_p
+    L.gm_last_kernel_pairs.argtypes = [vp]
+    L.gm_last_kernel_pairs.restype = i64
+    L.gm_set_variant.argtypes = [vp, i32]
+    L.gm_timing_reserve.argtypes = [vp, i32]
+    L.gm_timing_reserve.restype = i32
+    L.gm_timing_read.argtypes = [vp, vp, i32]
+    L.gm_timing_read.restype = i32
+    for name in ("gm_pack", "gm_unpack", "gm_index_create", "gm_index_create_dev", "gm_index_guidelen",
+                 "gm_index_metric", "gm_knn_query", "gm_knn_query_dev", "gm_nearest_dist",
+                 "gm_nearest_dist_dev", "gm_cfd_batch", "gm_cfd_batch_dev", "gm_set_variant"):
+        getattr(L, name).restype = i32
+    _lib = L
+    return L
+
+
+# every symbol include/gmhip.h declares (tests check the built library exports them all)
+EXPORTS = [
+    "gm_version", "gm_last_error", "gm_device_count", "gm_pack", "gm_unpack", "gm_index_create",
+    "gm_index_create_dev", "gm_index_free", "gm_index_size", "gm_index_guidelen", "gm_index_metric",
+    "gm_knn_query", "gm_knn_query_dev", "gm_nearest_dist", "gm_nearest_dist_dev", "gm_cfd_batch",
+    "gm_cfd_batch_dev", "gm_last_kernel_ms", "gm_last_kernel_name", "gm_last_kernel_pairs",
+    "gm_set_variant", "gm_timing_reserve", "gm_timing_read",
+]
+
+
+def _check(rc):
+    if rc != 0:
+        msg = lib().gm_last_error().decode(errors="replace")
+        if rc == -4:
+            raise ValueError(msg)
+        raise GmHipError("libgmhip error %d: %s" % (rc, msg))
+
+
+def _ptr(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+def pack(seqs, guidelen):
+    """list[str] (all of length guidelen, ACGT only) -> uint64 array, 2 bits per base."""
+    seqs = list(seqs)
+    n = len(seqs)
+    out = np.empty((n,), np.uint64)
+    if n == 0:
+        return out
+    joined = "".join(seqs)
+    if len(joined) != n * guidelen or any(len(s) != guidelen for s in seqs[:1] + seqs[-1:]):
+        raise ValueError("all sequences must have length %d" % guidelen)
+    _check(lib().gm_pack(joined.encode("ascii"), n, guidelen, _ptr(out)))
+    return out
+
+
+def pack_bytes(buf, n, guidelen):
+    """(n*guidelen) ASCII bytes / uint8 array -> uint64 array."""
+    arr = np.ascontiguousarray(np.frombuffer(buf, dtype=np.uint8) if not isinstance(buf, np.ndarray) else buf)
+    assert arr.size == n * guidelen
+    out = np.empty((n,), np.uint64)
+    if n:
+        _check(lib().gm_pack(arr.ctypes.data_as(ctypes.c_char_p), n, guidelen, _ptr(out)))
+    return out
+
+
+def unpack(packed, guidelen):
+    packed = np.ascontiguousarray(packed, dtype=np.uint64)
+    n = packed.shape[0]
+    buf = np.empty((n, guidelen), np.uint8)
+    if n:
+        _check(lib().gm_unpack(_ptr(packed), n, guidelen, _ptr(buf)))
+    return [row.tobytes().decode("ascii") for row in buf]
+
+
+class Index:
+    """Exact neighbour-search index resident in one GPU's HBM (replaces the nmslib index object)."""
+
+    def __init__(self, packed, guidelen, metric, device=0, _dev_ptr=None, _n=None, _stream=None):
+        self._h = ctypes.c_void_p()
+        self.guidelen = guidelen
+        self.metric = metric
+        self.device = device
+        if _dev_ptr is not None:
+            _check(lib().gm_index_create_dev(ctypes.c_void_p(_dev_ptr), _n, guidelen, metric, device,
+                                             ctypes.c_void_p(_stream or 0), ctypes.byref(self._h)))
+            self.n = _n
+        else:
+            packed = np.ascontiguousarray(packed, dtype=np.uint64)
+            self.n = int(packed.shape[0])
+            _check(lib().gm_index_create(_ptr(packed), self.n, guidelen, metric, device, ctypes.byref(self._h)))
+
+    @classmethod
+    def from_device(cls, dev_ptr, n, guidelen, metric, device=0, stream=None):
+        return cls(None, guidelen, metric, device, _dev_ptr=dev_ptr, _n=n, _stream=stream)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().gm_index_free(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return self.n
+
+    def knn(self, q_packed, k):
+        """-> (ids [nq,k] int32, dists [nq,k] int32 true units, counts [nq] int32); -1 padded."""
+        q = np.ascontiguousarray(q_packed, dtype=np.uint64)
+        nq = int(q.shape[0])
+        ids = np.full((nq, k), -1, np.int32)
+        dists = np.full((nq, k), -1, np.int32)
+        counts = np.zeros((nq,), np.int32)
+        if nq:
+            _check(lib().gm_knn_query(self._h, _ptr(q), nq, k, _ptr(ids), _ptr(dists), _ptr(counts)))
+        return ids, dists, counts
+
+    def knn_dev(self, q_ptr, nq, k, ids_ptr, dists_ptr, counts_ptr, stream=None):
+        _check(lib().gm_knn_query_dev(self._h, ctypes.c_void_p(q_ptr), nq, k, ctypes.c_void_p(ids_ptr),
+                                      ctypes.c_void_p(dists_ptr), ctypes.c_void_p(counts_ptr),
+                                      ctypes.c_void_p(stream or 0)))
+
+    def nearest(self, q_packed):
+        q = np.ascontiguousarray(q_packed, dtype=np.uint64)
+        nq = int(q.shape[0])
+        d1 = np.full((nq,), -1, np.int32)
+        if nq:
+            _check(lib().gm_nearest_dist(self._h, _ptr(q), nq, _ptr(d1)))
+        return d1
+
+    def nearest_dev(self, q_ptr, nq, d1_ptr, stream=None):
+        _check(lib().gm_nearest_dist_dev(self._h, ctypes.c_void_p(q_ptr), nq, ctypes.c_void_p(d1_ptr),
+                                         ctypes.c_void_p(stream or 0)))
+
+    def set_variant(self, v):
+        _check(lib().gm_set_variant(self._h, v))
+
+    def timing_reserve(self, n):
+        _check(lib().gm_timing_reserve(self._h, n))
+
+    def timing_read(self, max_n=4096):
+        """Durations (ms) of the scan-kernel launches recorded since timing_reserve (HIP events)."""
+        buf = np.zeros((max_n,), np.float64)
+        n = lib().gm_timing_read(self._h, _ptr(buf), max_n)
+        if n < 0:
+            _check(n)
+        return buf[:n].copy()
+
+    def last_kernel(self):
+        """(name, ms, pairs) of the dominant scan kernel of the last query (HIP events)."""
+        L = lib()
+        return (L.gm_last_kernel_name(self._h).decode(), L.gm_last_kernel_ms(self._h),
+                L.gm_last_kernel_pairs(self._h))
+
+
+def cfd_batch(guides_packed, offs_packed, guidelen, mm, device=0):
+    g = np.ascontiguousarray(guides_packed, dtype=np.uint64)
+    o = np.ascontiguousarray(offs_packed, dtype=np.uint64)
+    assert g.shape == o.shape
+    table = np.ascontiguousarray(np.asarray(mm, dtype=np.float64).reshape(-1))
+    assert table.size == 320
+    out = np.empty(g.shape, np.float64)
+    if g.size:
+        _check(lib().gm_cfd_batch(_ptr(g), _ptr(o), g.size, guidelen, _ptr(table), _ptr(out), device))
+    return out
+
+
+def device_count():
+    return lib().gm_device_count()

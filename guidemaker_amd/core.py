@@ -1,0 +1,430 @@
+"""Host-side mirror of GuideMaker's operator interface for the neighbour-search path.
+
+Same class / method names, arguments and error behaviour as the reference's
+``guidemaker/core.py`` (v0.4.2), so code and tests written against ``guidemaker.core`` run
+against this module; the work happens in libgmhip.so on an MI355X.  Mirrored symbols:
+
+  PamTarget(pam, pam_orientation, dtype).find_targets   reference core.py:39-292  (host, numpy)
+  TargetProcessor.__init__/__len__/__str__               reference core.py:304-352
+  TargetProcessor.check_restriction_enzymes              reference core.py:354-377 (host, pandas)
+  TargetProcessor.find_unique_near_pam                   reference core.py:388-416 (host, pandas)
+  TargetProcessor.create_index                           reference core.py:418-467 -> gm_index_create
+  TargetProcessor.get_neighbors                          reference core.py:471-523 -> gm_knn_query
+  TargetProcessor.export_bed                             reference core.py:525-543
+  TargetProcessor.get_control_seqs                       reference core.py:545-633 -> gm_nearest_dist
+  cfd_score(df)                                          reference core.py:1129-1148 -> gm_cfd_batch
+
+Deliberate, documented differences (DESIGN.md "Parity contract"):
+  * the search is exact, not HNSW: the NMSLIB block of the config is read and ignored;
+  * the index order is first occurrence in the targets frame, not ``list(set(...))`` hash order,
+    and ties are ordered (distance, index);
+  * ``neighbors[...]["seqs"]`` holds the TRUE neighbour sequences (the reference looks nmslib ids
+    up in the wrong table, core.py:513);
+  * there is no CPU fallback: without the HIP library / a GPU every search call raises.
+"""
+import hashlib
+import json
+import os
+import statistics
+from copy import deepcopy
+from itertools import product
+from typing import List
+
+import numpy as np
+import pandas as pd
+import yaml
+
+from . import _lib
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+CONFIG_PATH = os.path.join(_DATA, "config_default.yaml")
+
+_IUPAC = {
+    "A": "A", "C": "C", "G": "G", "T": "T", "M": "AC", "R": "AG", "W": "AT", "S": "CG", "Y": "CT",
+    "K": "GT", "V": "ACG", "H": "ACT", "D": "AGT", "B": "CGT", "X": "GATC", "N": "GATC",
+}
+_COMP = str.maketrans("ACGTMRWSYKVHDBXN", "TGCAKYWSRMBDHVXN")
+_CODE = np.full(256, 4, np.uint8)
+for _i, _c in enumerate("ACGT"):
+    _CODE[ord(_c)] = _i
+
+
+def reverse_complement(seq: str) -> str:
+    return seq.translate(_COMP)[::-1]
+
+
+def extend_ambiguous_dna(seq: str) -> List[str]:
+    """All concrete sequences of an IUPAC string (reference core.py:1093-1124, same order)."""
+    return ["".join(p) for p in product(*[_IUPAC[b] for b in seq])]
+
+
+# ------------------------------------------------------------------------------------------------
+# PAM scan (producer of the hot path's input; host side, vectorised numpy)
+# ------------------------------------------------------------------------------------------------
+def _match_positions(codes: np.ndarray, pam: str) -> np.ndarray:
+    """Start offsets of all (overlapping) occurrences of the IUPAC pattern; non-ACGT never matches."""
+    n, plen = codes.shape[0], len(pam)
+    if n < plen:
+        return np.empty((0,), np.int64)
+    ok = np.ones(n - plen + 1, dtype=bool)
+    for p, sym in enumerate(pam):
+        allowed = np.zeros(5, dtype=bool)
+        for b in _IUPAC[sym]:
+            allowed["ACGT".index(b)] = True
+        ok &= allowed[codes[p:n - plen + 1 + p]]
+    return np.flatnonzero(ok).astype(np.int64)
+
+
+def _windows(codes: np.ndarray, starts: np.ndarray, width: int) -> np.ndarray:
+    return codes[starts[:, None] + np.arange(width)[None, :]]
+
+
+def scan_targets(seq: str, pam: str, pam_orientation: str, target_len: int):
+    """Array-level PAM scan of one record.
+
+    Returns dict with 'codes' (n, L) uint8 base codes of the targets as reported (i.e. reverse
+    complemented for the minus strand), 'start', 'stop' (int64), 'strand' (bool), 'mstart', 'mend'
+    (match coordinates on the forward sequence).  Row order = forward matches ascending, then reverse
+    matches ascending, as the reference emits them (core.py:252-284).
+    """
+    codes = _CODE[np.frombuffer(seq.encode("ascii", "replace"), dtype=np.uint8)]
+    n, plen, L = codes.shape[0], len(pam), target_len
+    out = {k: [] for k in ("codes", "start", "stop", "strand", "mstart", "mend")}
+    for forward in (True, False):
+        pat = pam if forward else reverse_complement(pam)
+        ms = _match_positions(codes, pat)
+        me = ms + plen
+        # target lies after the match (5prime forward / 3prime reverse) or before it
+        after = (pam_orientation == "5prime") == forward
+        tstart = me if after else ms - L
+        keep = (tstart >= 0) & (tstart + L <= n)
+        ms, me, tstart = ms[keep], me[keep], tstart[keep]
+        win = _windows(codes, tstart, L) if tstart.size else np.empty((0, L), np.uint8)
+        good = (win < 4).all(axis=1)
+        ms, me, tstart, win = ms[good], me[good], tstart[good], win[good]
+        if not forward:
+            win = (3 - win)[:, ::-1]
+        out["codes"].append(win)
+        out["start"].append(tstart)
+        out["stop"].append(tstart + L)
+        out["strand"].append(np.full(tstart.shape, forward, dtype=bool))
+        out["mstart"].append(ms)
+        out["mend"].append(me)
+    return {k: np.concatenate(v) for k, v in out.items()}
+
+
+def codes_to_strings(codes: np.ndarray) -> List[str]:
+    if codes.shape[0] == 0:
+        return []
+    asc = np.frombuffer(b"ACGT", np.uint8)[codes]
+    L = codes.shape[1]
+    return np.ascontiguousarray(asc).view("S%d" % L).ravel().astype(str).tolist()
+
+
+def pack_codes(codes: np.ndarray) -> np.ndarray:
+    """(n, L) base codes -> uint64, base p in bits [2p, 2p+1] (the layout of include/gmhip.h)."""
+    L = codes.shape[1]
+    shifts = (2 * np.arange(L, dtype=np.uint64))[None, :]
+    return (codes.astype(np.uint64) << shifts).sum(axis=1, dtype=np.uint64)
+
+
+class PamTarget:
+    """A PAM plus the targets it defines (mirror of reference core.py:39-292)."""
+
+    def __init__(self, pam: str, pam_orientation: str, dtype: str) -> None:
+        for letter in pam.upper():
+            assert letter in _IUPAC
+        assert pam_orientation in ["3prime", "5prime"]
+        self.pam: str = pam.upper()
+        self.pam_orientation: str = pam_orientation
+        self.dtype: str = dtype
+
+    def __str__(self) -> str:
+        return "A PAM object: {self.pam}".format(self=self)
+
+    def find_targets(self, seq_record_iter: object, target_len: int) -> pd.DataFrame:
+        """All targets next to the PAM on both strands, as the reference's dataframe."""
+        five = self.pam_orientation == "5prime"
+        frames = []
+        for record in seq_record_iter:
+            seq = str(record.seq)
+            res = scan_targets(seq, self.pam, self.pam_orientation, target_len)
+            if res["start"].size == 0:
+                continue
+            strand = res["strand"]
+            ms, me = res["mstart"], res["mend"]
+            # 30-mer context: python slice semantics (a negative start wraps, core.py:156,184,211,237)
+            lo = np.where(strand == five, ms - 3, me - 27)
+            seq30 = []
+            for a, fw in zip(lo.tolist(), strand.tolist()):
+                s30 = seq[a:a + 30]
+                seq30.append(s30 if fw else reverse_complement(s30))
+            pams = []
+            for a, b, fw in zip(ms.tolist(), me.tolist(), strand.tolist()):
+                pams.append(seq[a:b] if fw else reverse_complement(seq[a:b]))
+            df = pd.DataFrame({
+                "target": codes_to_strings(res["codes"]),
+                "exact_pam": pams,
+                "start": res["start"], "stop": res["stop"], "strand": strand,
+                "pam_orientation": np.full(strand.shape, five, dtype=bool),
+                "target_seq30": seq30,
+            })
+            df["seqid"] = record.id
+            # per strand block the reference casts separately; the concatenation below matches it
+            frames.append(df)
+        if not frames:
+            raise ValueError("No objects to concatenate")   # what pd.concat([]) raises in the reference
+        df_targets = pd.concat(frames, ignore_index=True)
+        df_targets = df_targets.astype({"target": "str", "exact_pam": "category", "start": "uint32",
+                                        "stop": "uint32", "strand": "bool", "pam_orientation": "bool",
+                                        "seqid": "category"})
+        df_targets = df_targets.assign(seedseq=np.nan, hasrestrictionsite=np.nan, isseedduplicated=np.nan)
+        df_targets = df_targets.astype({"seedseq": "str", "isseedduplicated": "bool"})
+        df_targets = df_targets.assign(dtype=self.dtype)
+        df_targets = df_targets.astype({"dtype": "category"})
+        return df_targets
+
+
+# ------------------------------------------------------------------------------------------------
+# TargetProcessor
+# ------------------------------------------------------------------------------------------------
+def _load_cfd_table():
+    with open(os.path.join(_DATA, "cfd_mm_table.json")) as fh:
+        return np.asarray(json.load(fh)["mm"], dtype=np.float64)
+
+
+class TargetProcessor:
+    """A set of guide RNA targets and its MI355X-resident neighbour index."""
+
+    def __init__(self, targets: pd.DataFrame, lsr: int, editdist: int = 2, knum: int = 2,
+                 device: int = 0) -> None:
+        self.targets = targets
+        self.lsr: int = lsr
+        self.editdist: int = editdist
+        self.knum: int = knum
+        self.nmslib_index: object = None      # name kept; holds a guidemaker_amd._lib.Index
+        self.neighbors: dict = {}
+        self.closest_neighbor_df: pd.DataFrame = None
+        self.ncontrolsearched: int = None
+        self.gc_percent: float = None
+        self.genomesize: float = None
+        self.pam_orientation: bool = targets['pam_orientation'].iat[0]
+        self.device = device
+        self._db_targets = None               # index id -> sequence
+        self._guidelen = None
+        self.last_knn = None                  # (ids, dists, counts) of the last get_neighbors
+
+    def __str__(self) -> str:
+        return "TargetList: contains a set of {} potential PAM targets".format(len(self.targets))
+
+    def __len__(self) -> int:
+        return len(self.targets)
+
+    def _is_hamming(self) -> bool:
+        # anything but "hamming" selects Levenshtein (reference core.py:448,496,509)
+        return self.targets['dtype'].iat[0] == "hamming"
+
+    def check_restriction_enzymes(self, restriction_enzyme_list: list = []) -> None:
+        """Flag targets containing a restriction site or its reverse complement."""
+        sites = []
+        for record in set(restriction_enzyme_list):
+            for letter in record.upper():
+                assert letter in _IUPAC
+            sites += extend_ambiguous_dna(record.upper())
+            sites += extend_ambiguous_dna(reverse_complement(record.upper()))
+        if len(sites) > 0:
+            self.targets['hasrestrictionsite'] = self.targets['target'].str.contains('|'.join(sites))
+        else:
+            self.targets['hasrestrictionsite'] = False
+
+    def _one_hot_encode(self, seq_list: List[object]) -> np.ndarray:
+        """Encoding step of the reference (core.py:379-386); here: 2-bit packing for the GPU."""
+        return _lib.pack(seq_list, self._target_len(seq_list))
+
+    def _target_len(self, seq_list=None) -> int:
+        if self._guidelen is not None:
+            return self._guidelen
+        if seq_list is not None and len(seq_list):
+            return len(seq_list[0])
+        return len(self.targets['target'].iat[0])
+
+    def find_unique_near_pam(self) -> None:
+        """Flag targets whose PAM-proximal seed (length lsr) already occurred earlier in the frame."""
+        self.targets = deepcopy(self.targets)
+        t = self.targets['target']
+        if self.lsr == 0:
+            seed = t
+        elif self.pam_orientation == True:   # 5prime: PAM sits in front of the target
+            seed = t.str[0:self.lsr]
+        else:
+            seed = t.apply(lambda s: s[(len(s) - self.lsr):])
+        self.targets['seedseq'] = seed
+        self.targets['isseedduplicated'] = self.targets['seedseq'].duplicated()
+
+    def create_index(self, configpath: str, num_threads=2):
+        """Upload the de-duplicated targets to HBM (replaces the nmslib HNSW build)."""
+        with open(configpath) as cf:
+            config = yaml.safe_load(cf)
+        # read for interface compatibility; an exact scan has no M / efC / post
+        _ = config['NMSLIB']['M'], config['NMSLIB']['efc'], config['NMSLIB']['post']
+        notduplicated = pd.unique(self.targets['target'])       # first-occurrence order
+        self._db_targets = np.asarray(notduplicated, dtype=object)
+        self._guidelen = len(self._db_targets[0])
+        if self._guidelen > _lib.MAX_GUIDELEN:
+            raise ValueError("guide length %d exceeds %d" % (self._guidelen, _lib.MAX_GUIDELEN))
+        metric = _lib.METRIC_HAMMING if self._is_hamming() else _lib.METRIC_LEVEN
+        packed = _lib.pack(self._db_targets.tolist(), self._guidelen)
+        if self.nmslib_index is not None:
+            self.nmslib_index.close()
+        self.nmslib_index = _lib.Index(packed, self._guidelen, metric, self.device)
+
+    def _query_targets(self) -> list:
+        # the OR is the reference's (core.py:495)
+        t = self.targets
+        return t.loc[(t['isseedduplicated'] == False) | (t['hasrestrictionsite'] == False)]['target'].tolist()
+
+    def get_neighbors(self, configpath, num_threads=2) -> None:
+        """k nearest targets of every candidate guide; keep guides whose 2nd hit is >= editdist away.
+
+        Writes self.neighbors[seq] = {"target": seq, "neighbors": {"seqs": [...], "dist": [...]}}.
+        """
+        with open(configpath) as cf:
+            config = yaml.safe_load(cf)
+        _ = config['NMSLIB']['ef']
+        unique_targets = self._query_targets()
+        qpacked = _lib.pack(unique_targets, self._guidelen)
+        ids, dists, counts = self.nmslib_index.knn(qpacked, self.knum)
+        self.last_knn = (ids, dists, counts)
+        if len(unique_targets) and (self.knum < 2 or int(counts.min()) < 2):
+            raise IndexError("list index out of range")      # editdist[1] in the reference (core.py:512)
+        # reference: hamming compares the one-hot distance (2 x mismatches) with 2 * editdist and
+        # reports int(x / 2); in true units both reduce to the same test / value
+        keep = np.flatnonzero(dists[:, 1] >= self.editdist) if len(unique_targets) else np.empty(0, np.int64)
+        db = self._db_targets
+        neighbor_dict = {}
+        for i in keep.tolist():
+            c = int(counts[i])
+            queryseq = unique_targets[i]
+            neighbor_dict[queryseq] = {"target": queryseq,
+                                       "neighbors": {"seqs": db[ids[i, :c]].tolist(),
+                                                     "dist": dists[i, :c].tolist()}}
+        self.neighbors = neighbor_dict
+
+    def export_bed(self) -> object:
+        """Targets that are not seed-duplicated, as a BED-like frame."""
+        df = deepcopy(self.targets.loc[self.targets['isseedduplicated'] == False])
+        df = df[["seqid", "start", "stop", "target", "strand"]]
+        df['strand'] = df['strand'].apply(lambda x: '+' if x == True else '-')
+        df.columns = ["chrom", "chromstart", "chromend", "name", "strand"]
+        df.sort_values(by=['chrom', 'chromstart'], inplace=True)
+        return df
+
+    @staticmethod
+    def _draw_control_seqs(count: int, length: int, gc: float) -> List[str]:
+        """`count` random sequences, consuming numpy's global RNG exactly like the reference's
+        per-sequence np.random.choice(["G","C","A","T"], size=length, p=...) calls (core.py:590-592):
+        choice() draws one uniform per base and maps it through the cumulative distribution."""
+        p = np.array([gc / 2, gc / 2, (1 - gc) / 2, (1 - gc) / 2], dtype=np.float64)
+        cdf = p.cumsum()
+        cdf /= cdf[-1]
+        u = np.random.random_sample((count, length))
+        idx = cdf.searchsorted(u, side='right')
+        asc = np.frombuffer(b"GCAT", np.uint8)[idx]
+        return np.ascontiguousarray(asc).view("S%d" % length).ravel().astype(str).tolist()
+
+    def get_control_seqs(self, seq_record_iter: object, configpath, length: int = 20, n: int = 10,
+                         num_threads: int = 2) -> pd.DataFrame:
+        """Random sequences with the genome's GC content that are farthest from every target."""
+        with open(configpath) as cf:
+            config = yaml.safe_load(cf)
+        MINIMUM_HMDIST = config['CONTROL']['MINIMUM_HMDIST']
+        MAX_CONTROL_SEARCH_MULTIPLE = max(config['CONTROL']['CONTROL_SEARCH_MULTIPLE'])
+        CONTROL_SEARCH_MULTIPLE = config['CONTROL']['CONTROL_SEARCH_MULTIPLE']
+
+        totlen = 0
+        gccnt = 0
+        for record in seq_record_iter:
+            s = str(record.seq)
+            # Bio.SeqUtils.gc_fraction(seq) default: (G+C+S) / (G+C+S+A+T+W+U), other letters ignored
+            gc_total = sum(s.count(c) for c in "CGScgs")
+            counted = gc_total + sum(s.count(c) for c in "ATWUatwu")
+            gccnt += (gc_total / counted if counted else 0) * len(s)
+            totlen += len(s)
+        gc = gccnt / (totlen)
+        self.gc_percent = gc * 100
+        self.genomesize = totlen / (1024 * 1024)
+
+        minimum_hmdist = 0
+        sm_count = 0
+        search_mult = 0
+        hamming = self._is_hamming()
+        try:
+            # loop condition (and its walk off the end of the list) as in the reference, core.py:586
+            while minimum_hmdist < MINIMUM_HMDIST or search_mult == MAX_CONTROL_SEARCH_MULTIPLE:
+                search_mult = CONTROL_SEARCH_MULTIPLE[sm_count]
+                seqs = self._draw_control_seqs(n * search_mult, length, gc)
+                d1 = self.nmslib_index.nearest(_lib.pack(seqs, length))
+                # sorted(..., reverse=True, key=dist) is stable: ties stay in draw order
+                order = np.argsort(-d1.astype(np.int64), kind="stable")[0:n]
+                sort_seq = [seqs[i] for i in order.tolist()]
+                if hamming:
+                    sort_dist = [float(d1[i]) for i in order.tolist()]   # reference: raw / 2 -> float
+                else:
+                    sort_dist = [int(d1[i]) for i in order.tolist()]
+                minimum_hmdist = int(min(sort_dist))
+                sm_count += 1
+        except IndexError as e:
+            raise e
+
+        total_ncontrolsearched = search_mult * n
+        self.ncontrolsearched = total_ncontrolsearched
+        randomdf = pd.DataFrame(data={"Sequences": sort_seq, "Hamming distance": sort_dist})
+
+        def create_name(seq):
+            return "Cont-" + hashlib.md5(seq.encode()).hexdigest()
+        randomdf['name'] = randomdf["Sequences"].apply(create_name)
+        randomdf = randomdf[["name", "Sequences", "Hamming distance"]]
+        return (min(sort_dist), statistics.median(sort_dist), randomdf)
+
+
+# ------------------------------------------------------------------------------------------------
+# CFD
+# ------------------------------------------------------------------------------------------------
+def calc_cfd_pairs(guides: List[str], offs: List[str], device: int = 0) -> np.ndarray:
+    """CFD score of equal-length (guide, off-target) pairs on the GPU (calc_cfd, batched)."""
+    for g, o in zip(guides, offs):
+        assert len(g) == len(o), "The lengths wt and off differ: wt = {}, off = {}".format(
+            str(len(g)), str(len(o)))
+    out = np.empty((len(guides),), np.float64)
+    if not len(guides):
+        return out
+    mm = _load_cfd_table()
+    lens = np.fromiter((len(g) for g in guides), dtype=np.int64, count=len(guides))
+    for L in np.unique(lens).tolist():
+        sel = np.flatnonzero(lens == L)
+        gp = _lib.pack([guides[i].upper().replace('U', 'T') for i in sel.tolist()], L)
+        op = _lib.pack([offs[i].upper().replace('U', 'T') for i in sel.tolist()], L)
+        out[sel] = _lib.cfd_batch(gp, op, L, mm, device)
+    return out
+
+
+def calc_cfd(wt: str, off: str, mm_scores=None) -> float:
+    """Single-pair form of the reference's cfd_score_calculator.calc_cfd (runs on the GPU)."""
+    return float(calc_cfd_pairs([wt], [off])[0])
+
+
+def cfd_score(df, device: int = 0):
+    """Adds 'CFD Similar Guides' (list of str(float)) and 'Max CFD' (reference core.py:1129-1148)."""
+    guides, offs, owner = [], [], []
+    for row, (g, sim) in enumerate(zip(df['Guide sequence'].tolist(), df['Similar guides'].tolist())):
+        for item in sim.split(';'):
+            guides.append(g)
+            offs.append(item)
+            owner.append(row)
+    scores = calc_cfd_pairs(guides, offs, device)
+    per_row = [[] for _ in range(len(df))]
+    for r, v in zip(owner, scores.tolist()):
+        per_row[r].append(str(v))
+    df['CFD Similar Guides'] = pd.Series(per_row, index=df.index, dtype=object)
+    df['Max CFD'] = df['CFD Similar Guides'].apply(lambda lst: sorted(float(x) for x in lst)[-1])
+    return df

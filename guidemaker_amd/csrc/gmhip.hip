@@ -1,0 +1,491 @@
+// gmhip.hip -- C ABI (include/gmhip.h) over the gfx950 kernels in gm_kernels.hip.h.
+// Host side of libgmhip.so: handle management, HBM workspaces, launches, HIP-event timing.
+#include "gm_kernels.hip.h"
+
+#include <string>
+#include <vector>
+#include <cstdio>
+#include <cstring>
+
+#include "gmhip.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(GM_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+}  // namespace
+
+struct gm_index {
+    int device = 0;
+    int L = 0;
+    int metric = 0;
+    int64_t n_db = 0;
+    int64_t n_db_pad = 0;
+    uint2* d_db = nullptr;        // bit planes, padded to a multiple of gm::TILE
+    // workspaces (grow-only), so repeated queries do not allocate
+    uint2* d_q = nullptr;
+    int64_t q_cap = 0;
+    void* d_stage = nullptr;      // host-pointer API: packed queries in / results out
+    int64_t stage_cap = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    std::vector<hipEvent_t> hist0, hist1;   // optional per-launch history (gm_timing_reserve)
+    int64_t hist_count = 0;
+    const char* last_kernel = "";
+    int64_t last_pairs = 0;
+    int variant = 0;
+};
+
+namespace {
+
+int ensure_q(gm_index* idx, int64_t n_q) {
+    if (n_q <= idx->q_cap) return GM_OK;
+    if (idx->d_q) (void)hipFree(idx->d_q);
+    idx->d_q = nullptr;
+    idx->q_cap = 0;
+    int64_t cap = round_up(n_q, 4096);
+    if (hipMalloc(&idx->d_q, sizeof(uint2) * cap) != hipSuccess)
+        return fail(GM_ERR_ALLOC, "hipMalloc(query planes) failed");
+    idx->q_cap = cap;
+    return GM_OK;
+}
+
+int ensure_stage(gm_index* idx, int64_t bytes) {
+    if (bytes <= idx->stage_cap) return GM_OK;
+    if (idx->d_stage) (void)hipFree(idx->d_stage);
+    idx->d_stage = nullptr;
+    idx->stage_cap = 0;
+    int64_t cap = round_up(bytes, 1 << 20);
+    if (hipMalloc(&idx->d_stage, cap) != hipSuccess) return fail(GM_ERR_ALLOC, "hipMalloc(staging) failed");
+    idx->stage_cap = cap;
+    return GM_OK;
+}
+
+int planes_launch(const uint64_t* d_in, uint2* d_out, int64_t n, int64_t n_pad, hipStream_t st) {
+    if (n_pad <= 0) return GM_OK;
+    int64_t blocks = (n_pad + 255) / 256;
+    hipLaunchKernelGGL(gm::k_to_planes, dim3((unsigned)blocks), dim3(256), 0, st, d_in, d_out, n, n_pad);
+    HIP_TRY(hipGetLastError());
+    return GM_OK;
+}
+
+// queries per lane by list size: keeps the per-wave list (k * R * 256 B) near 10 KiB
+int pick_r(int k) { return k <= 10 ? 4 : (k <= 20 ? 2 : 1); }
+
+template <int R>
+int launch_hamming_knn(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* dists, int32_t* counts,
+                       hipStream_t st) {
+    int64_t blocks = (n_q + R * gm::WAVE - 1) / (R * gm::WAVE);
+    size_t lds = sizeof(uint2) * 2 * gm::TILE + sizeof(uint32_t) * (size_t)k * R * gm::WAVE;
+    int n_tiles = (int)(idx->n_db_pad / gm::TILE);
+    auto kern = gm::k_hamming_knn<R, 8>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(gm::WAVE), lds, st, idx->d_db, (int)idx->n_db,
+                       n_tiles, idx->d_q, n_q, k, ids, dists, counts);
+    HIP_TRY(hipGetLastError());
+    return GM_OK;
+}
+
+template <int R>
+int launch_leven_knn(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* dists, int32_t* counts,
+                     hipStream_t st) {
+    int64_t blocks = (n_q + R * gm::WAVE - 1) / (R * gm::WAVE);
+    size_t lds = sizeof(uint2) * 2 * gm::TILE + sizeof(uint32_t) * (size_t)k * R * gm::WAVE;
+    int n_tiles = (int)(idx->n_db_pad / gm::TILE);
+    auto kern = gm::k_leven_knn<R>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(gm::WAVE), lds, st, idx->d_db, (int)idx->n_db,
+                       n_tiles, idx->d_q, n_q, k, idx->L, ids, dists, counts);
+    HIP_TRY(hipGetLastError());
+    return GM_OK;
+}
+
+int timing_begin(gm_index* idx, hipStream_t st) {
+    HIP_TRY(hipEventRecord(idx->ev0, st));
+    if (!idx->hist0.empty()) HIP_TRY(hipEventRecord(idx->hist0[idx->hist_count % idx->hist0.size()], st));
+    return GM_OK;
+}
+
+int timing_end(gm_index* idx, hipStream_t st, int64_t pairs) {
+    HIP_TRY(hipEventRecord(idx->ev1, st));
+    if (!idx->hist1.empty()) {
+        HIP_TRY(hipEventRecord(idx->hist1[idx->hist_count % idx->hist1.size()], st));
+        idx->hist_count++;
+    }
+    idx->timed = true;
+    idx->last_pairs = pairs;
+    return GM_OK;
+}
+
+void timing_clear(gm_index* idx) {
+    for (auto e : idx->hist0) (void)hipEventDestroy(e);
+    for (auto e : idx->hist1) (void)hipEventDestroy(e);
+    idx->hist0.clear();
+    idx->hist1.clear();
+    idx->hist_count = 0;
+}
+
+int check_index(const gm_index* idx) {
+    if (!idx) return fail(GM_ERR_ARG, "null index handle");
+    return GM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* gm_version(void) { return "gmhip 0.1.0 (gfx950)"; }
+
+const char* gm_last_error(void) { return g_err.c_str(); }
+
+int gm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int gm_pack(const char* seqs, int64_t n, int guidelen, uint64_t* out) {
+    if (!seqs || !out || n < 0 || guidelen < 1 || guidelen > GM_MAX_GUIDELEN)
+        return fail(GM_ERR_ARG, "gm_pack: bad argument");
+    for (int64_t i = 0; i < n; ++i) {
+        uint64_t v = 0;
+        const char* s = seqs + i * guidelen;
+        for (int p = 0; p < guidelen; ++p) {
+            uint64_t c;
+            switch (s[p]) {
+                case 'A': c = 0; break;
+                case 'C': c = 1; break;
+                case 'G': c = 2; break;
+                case 'T': c = 3; break;
+                default:
+                    return fail(GM_ERR_SEQ, "gm_pack: non-ACGT base in sequence " + std::to_string(i));
+            }
+            v |= c << (2 * p);
+        }
+        out[i] = v;
+    }
+    return GM_OK;
+}
+
+int gm_unpack(const uint64_t* packed, int64_t n, int guidelen, char* out) {
+    if (!packed || !out || n < 0 || guidelen < 1 || guidelen > GM_MAX_GUIDELEN)
+        return fail(GM_ERR_ARG, "gm_unpack: bad argument");
+    static const char B[4] = {'A', 'C', 'G', 'T'};
+    for (int64_t i = 0; i < n; ++i)
+        for (int p = 0; p < guidelen; ++p) out[i * guidelen + p] = B[(packed[i] >> (2 * p)) & 3u];
+    return GM_OK;
+}
+
+int gm_index_create_dev(const void* d_packed, int64_t n_db, int guidelen, int metric, int device,
+                        void* stream, gm_index** out) {
+    if (!out) return fail(GM_ERR_ARG, "gm_index_create: null out");
+    *out = nullptr;
+    if (n_db < 0 || n_db > GM_MAX_DB) return fail(GM_ERR_ARG, "gm_index_create: n_db out of range");
+    if (n_db > 0 && !d_packed) return fail(GM_ERR_ARG, "gm_index_create: null data");
+    if (guidelen < 1 || guidelen > GM_MAX_GUIDELEN) return fail(GM_ERR_ARG, "gm_index_create: guidelen must be 1..27");
+    if (metric != GM_METRIC_HAMMING && metric != GM_METRIC_LEVEN)
+        return fail(GM_ERR_ARG, "gm_index_create: unknown metric");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(GM_ERR_DEVICE, "no HIP device available (libgmhip has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(GM_ERR_ARG, "gm_index_create: bad device ordinal");
+    HIP_TRY(hipSetDevice(device));
+    gm_index* idx = new gm_index();
+    idx->device = device;
+    idx->L = guidelen;
+    idx->metric = metric;
+    idx->n_db = n_db;
+    idx->n_db_pad = n_db > 0 ? round_up(n_db, gm::TILE) : 0;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (n_db > 0) {
+        if (hipMalloc(&idx->d_db, sizeof(uint2) * idx->n_db_pad) != hipSuccess) {
+            delete idx;
+            return fail(GM_ERR_ALLOC, "hipMalloc(db planes) failed");
+        }
+        int rc = planes_launch(static_cast<const uint64_t*>(d_packed), idx->d_db, n_db, idx->n_db_pad, st);
+        if (rc != GM_OK) {
+            gm_index_free(idx);
+            return rc;
+        }
+    }
+    if (hipEventCreate(&idx->ev0) != hipSuccess || hipEventCreate(&idx->ev1) != hipSuccess) {
+        gm_index_free(idx);
+        return fail(GM_ERR_DEVICE, "hipEventCreate failed");
+    }
+    *out = idx;
+    return GM_OK;
+}
+
+int gm_index_create(const uint64_t* packed, int64_t n_db, int guidelen, int metric, int device,
+                    gm_index** out) {
+    if (!out) return fail(GM_ERR_ARG, "gm_index_create: null out");
+    *out = nullptr;
+    if (n_db < 0 || n_db > GM_MAX_DB) return fail(GM_ERR_ARG, "gm_index_create: n_db out of range");
+    if (n_db > 0 && !packed) return fail(GM_ERR_ARG, "gm_index_create: null data");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(GM_ERR_DEVICE, "no HIP device available (libgmhip has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(GM_ERR_ARG, "gm_index_create: bad device ordinal");
+    HIP_TRY(hipSetDevice(device));
+    uint64_t* d_tmp = nullptr;
+    if (n_db > 0) {
+        if (hipMalloc(&d_tmp, sizeof(uint64_t) * n_db) != hipSuccess)
+            return fail(GM_ERR_ALLOC, "hipMalloc(packed db) failed");
+        hipError_t e = hipMemcpy(d_tmp, packed, sizeof(uint64_t) * n_db, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(d_tmp);
+            return fail(GM_ERR_DEVICE, std::string("hipMemcpy(db): ") + hipGetErrorString(e));
+        }
+    }
+    int rc = gm_index_create_dev(d_tmp, n_db, guidelen, metric, device, nullptr, out);
+    if (rc == GM_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(GM_ERR_DEVICE, "db upload failed");
+    if (d_tmp) (void)hipFree(d_tmp);
+    if (rc != GM_OK && *out) {
+        gm_index_free(*out);
+        *out = nullptr;
+    }
+    return rc;
+}
+
+void gm_index_free(gm_index* idx) {
+    if (!idx) return;
+    (void)hipSetDevice(idx->device);
+    if (idx->d_db) (void)hipFree(idx->d_db);
+    if (idx->d_q) (void)hipFree(idx->d_q);
+    if (idx->d_stage) (void)hipFree(idx->d_stage);
+    timing_clear(idx);
+    if (idx->ev0) (void)hipEventDestroy(idx->ev0);
+    if (idx->ev1) (void)hipEventDestroy(idx->ev1);
+    delete idx;
+}
+
+int64_t gm_index_size(const gm_index* idx) { return idx ? idx->n_db : -1; }
+int gm_index_guidelen(const gm_index* idx) { return idx ? idx->L : -1; }
+int gm_index_metric(const gm_index* idx) { return idx ? idx->metric : -1; }
+
+int gm_set_variant(gm_index* idx, int variant) {
+    if (check_index(idx)) return GM_ERR_ARG;
+    idx->variant = variant;
+    return GM_OK;
+}
+
+int gm_knn_query_dev(gm_index* idx, const void* d_q, int64_t n_q, int k, void* d_ids, void* d_dists,
+                     void* d_counts, void* stream) {
+    if (check_index(idx)) return GM_ERR_ARG;
+    if (n_q < 0 || k < 1 || k > GM_MAX_K) return fail(GM_ERR_ARG, "gm_knn_query: need n_q >= 0, 1 <= k <= 64");
+    if (n_q == 0) return GM_OK;
+    if (!d_q || !d_ids || !d_dists || !d_counts) return fail(GM_ERR_ARG, "gm_knn_query: null buffer");
+    HIP_TRY(hipSetDevice(idx->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int32_t* ids = static_cast<int32_t*>(d_ids);
+    int32_t* dists = static_cast<int32_t*>(d_dists);
+    int32_t* counts = static_cast<int32_t*>(d_counts);
+    if (idx->n_db == 0) {   // empty index: no hits
+        HIP_TRY(hipMemsetAsync(ids, 0xff, sizeof(int32_t) * n_q * k, st));
+        HIP_TRY(hipMemsetAsync(dists, 0xff, sizeof(int32_t) * n_q * k, st));
+        HIP_TRY(hipMemsetAsync(counts, 0, sizeof(int32_t) * n_q, st));
+        return GM_OK;
+    }
+    int rc = ensure_q(idx, n_q);
+    if (rc) return rc;
+    rc = planes_launch(static_cast<const uint64_t*>(d_q), idx->d_q, n_q, n_q, st);
+    if (rc) return rc;
+    rc = timing_begin(idx, st);
+    if (rc) return rc;
+    const int R = pick_r(k);
+    if (idx->metric == GM_METRIC_HAMMING) {
+        idx->last_kernel = "k_hamming_knn";
+        rc = R == 4 ? launch_hamming_knn<4>(idx, n_q, k, ids, dists, counts, st)
+           : R == 2 ? launch_hamming_knn<2>(idx, n_q, k, ids, dists, counts, st)
+                    : launch_hamming_knn<1>(idx, n_q, k, ids, dists, counts, st);
+    } else {
+        idx->last_kernel = "k_leven_knn";
+        rc = R == 4 ? launch_leven_knn<4>(idx, n_q, k, ids, dists, counts, st)
+           : R == 2 ? launch_leven_knn<2>(idx, n_q, k, ids, dists, counts, st)
+                    : launch_leven_knn<1>(idx, n_q, k, ids, dists, counts, st);
+    }
+    if (rc) return rc;
+    return timing_end(idx, st, n_q * idx->n_db);
+}
+
+int gm_knn_query(gm_index* idx, const uint64_t* q, int64_t n_q, int k, int32_t* ids, int32_t* dists,
+                 int32_t* counts) {
+    if (check_index(idx)) return GM_ERR_ARG;
+    if (n_q < 0 || k < 1 || k > GM_MAX_K) return fail(GM_ERR_ARG, "gm_knn_query: need n_q >= 0, 1 <= k <= 64");
+    if (n_q == 0) return GM_OK;
+    if (!q || !ids || !dists || !counts) return fail(GM_ERR_ARG, "gm_knn_query: null buffer");
+    HIP_TRY(hipSetDevice(idx->device));
+    const int64_t bq = round_up(sizeof(uint64_t) * n_q, 256);
+    const int64_t bl = round_up(sizeof(int32_t) * n_q * k, 256);
+    const int64_t bc = round_up(sizeof(int32_t) * n_q, 256);
+    int rc = ensure_stage(idx, bq + 2 * bl + bc);
+    if (rc) return rc;
+    char* base = static_cast<char*>(idx->d_stage);
+    HIP_TRY(hipMemcpy(base, q, sizeof(uint64_t) * n_q, hipMemcpyHostToDevice));
+    rc = gm_knn_query_dev(idx, base, n_q, k, base + bq, base + bq + bl, base + bq + 2 * bl, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(ids, base + bq, sizeof(int32_t) * n_q * k, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dists, base + bq + bl, sizeof(int32_t) * n_q * k, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(counts, base + bq + 2 * bl, sizeof(int32_t) * n_q, hipMemcpyDeviceToHost));
+    return GM_OK;
+}
+
+int gm_nearest_dist_dev(gm_index* idx, const void* d_q, int64_t n_q, void* d_d1, void* stream) {
+    if (check_index(idx)) return GM_ERR_ARG;
+    if (n_q < 0) return fail(GM_ERR_ARG, "gm_nearest_dist: n_q < 0");
+    if (n_q == 0) return GM_OK;
+    if (!d_q || !d_d1) return fail(GM_ERR_ARG, "gm_nearest_dist: null buffer");
+    HIP_TRY(hipSetDevice(idx->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int32_t* d1 = static_cast<int32_t*>(d_d1);
+    if (idx->n_db == 0) {
+        HIP_TRY(hipMemsetAsync(d1, 0xff, sizeof(int32_t) * n_q, st));
+        return GM_OK;
+    }
+    int rc = ensure_q(idx, n_q);
+    if (rc) return rc;
+    rc = planes_launch(static_cast<const uint64_t*>(d_q), idx->d_q, n_q, n_q, st);
+    if (rc) return rc;
+    int n_tiles = (int)(idx->n_db_pad / gm::TILE);
+    rc = timing_begin(idx, st);
+    if (rc) return rc;
+    if (idx->metric == GM_METRIC_HAMMING) {
+        constexpr int R = 4;
+        int64_t blocks = (n_q + R * gm::WAVE - 1) / (R * gm::WAVE);
+        idx->last_kernel = "k_hamming_nearest";
+        hipLaunchKernelGGL((gm::k_hamming_nearest<R, 8>), dim3((unsigned)blocks), dim3(gm::WAVE), 0, st,
+                           idx->d_db, n_tiles, idx->d_q, n_q, d1);
+    } else {
+        constexpr int R = 2;
+        int64_t blocks = (n_q + R * gm::WAVE - 1) / (R * gm::WAVE);
+        idx->last_kernel = "k_leven_nearest";
+        hipLaunchKernelGGL((gm::k_leven_nearest<R>), dim3((unsigned)blocks), dim3(gm::WAVE), 0, st,
+                           idx->d_db, (int)idx->n_db, n_tiles, idx->d_q, n_q, idx->L, d1);
+    }
+    HIP_TRY(hipGetLastError());
+    return timing_end(idx, st, n_q * idx->n_db);
+}
+
+int gm_nearest_dist(gm_index* idx, const uint64_t* q, int64_t n_q, int32_t* d1) {
+    if (check_index(idx)) return GM_ERR_ARG;
+    if (n_q < 0) return fail(GM_ERR_ARG, "gm_nearest_dist: n_q < 0");
+    if (n_q == 0) return GM_OK;
+    if (!q || !d1) return fail(GM_ERR_ARG, "gm_nearest_dist: null buffer");
+    HIP_TRY(hipSetDevice(idx->device));
+    const int64_t bq = round_up(sizeof(uint64_t) * n_q, 256);
+    int rc = ensure_stage(idx, bq + sizeof(int32_t) * n_q);
+    if (rc) return rc;
+    char* base = static_cast<char*>(idx->d_stage);
+    HIP_TRY(hipMemcpy(base, q, sizeof(uint64_t) * n_q, hipMemcpyHostToDevice));
+    rc = gm_nearest_dist_dev(idx, base, n_q, base + bq, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(d1, base + bq, sizeof(int32_t) * n_q, hipMemcpyDeviceToHost));
+    return GM_OK;
+}
+
+int gm_cfd_batch_dev(const void* d_guides, const void* d_offs, int64_t n_pairs, int guidelen,
+                     const void* d_mm, void* d_out, void* stream) {
+    if (n_pairs < 0 || guidelen < 1 || guidelen > GM_MAX_GUIDELEN)
+        return fail(GM_ERR_ARG, "gm_cfd_batch: bad argument");
+    if (n_pairs == 0) return GM_OK;
+    if (!d_guides || !d_offs || !d_mm || !d_out) return fail(GM_ERR_ARG, "gm_cfd_batch: null buffer");
+    int64_t blocks = (n_pairs + 255) / 256;
+    hipLaunchKernelGGL(gm::k_cfd, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       static_cast<const uint64_t*>(d_guides), static_cast<const uint64_t*>(d_offs), n_pairs,
+                       guidelen, static_cast<const double*>(d_mm), static_cast<double*>(d_out));
+    HIP_TRY(hipGetLastError());
+    return GM_OK;
+}
+
+int gm_cfd_batch(const uint64_t* guides, const uint64_t* offs, int64_t n_pairs, int guidelen,
+                 const double* mm, double* out, int device) {
+    if (n_pairs < 0 || guidelen < 1 || guidelen > GM_MAX_GUIDELEN)
+        return fail(GM_ERR_ARG, "gm_cfd_batch: bad argument");
+    if (n_pairs == 0) return GM_OK;
+    if (!guides || !offs || !mm || !out) return fail(GM_ERR_ARG, "gm_cfd_batch: null buffer");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(GM_ERR_DEVICE, "no HIP device available (libgmhip has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(GM_ERR_ARG, "gm_cfd_batch: bad device ordinal");
+    HIP_TRY(hipSetDevice(device));
+    const int64_t bs = round_up(sizeof(uint64_t) * n_pairs, 256);
+    const int64_t bm = 320 * sizeof(double);
+    char* base = nullptr;
+    if (hipMalloc(&base, 3 * bs + bm) != hipSuccess) return fail(GM_ERR_ALLOC, "hipMalloc(cfd) failed");
+    int rc = GM_OK;
+    hipError_t e = hipMemcpy(base, guides, sizeof(uint64_t) * n_pairs, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(base + bs, offs, sizeof(uint64_t) * n_pairs, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(base + 3 * bs, mm, bm, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        rc = gm_cfd_batch_dev(base, base + bs, n_pairs, guidelen, base + 3 * bs, base + 2 * bs, nullptr);
+        if (rc == GM_OK) e = hipMemcpy(out, base + 2 * bs, sizeof(double) * n_pairs, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(base);
+    if (rc != GM_OK) return rc;
+    if (e != hipSuccess) return fail(GM_ERR_DEVICE, std::string("gm_cfd_batch: ") + hipGetErrorString(e));
+    return GM_OK;
+}
+
+double gm_last_kernel_ms(gm_index* idx) {
+    if (!idx || !idx->timed) return -1.0;
+    if (hipSetDevice(idx->device) != hipSuccess) return -1.0;
+    if (hipEventSynchronize(idx->ev1) != hipSuccess) return -1.0;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, idx->ev0, idx->ev1) != hipSuccess) return -1.0;
+    return (double)ms;
+}
+
+int gm_timing_reserve(gm_index* idx, int n) {
+    if (check_index(idx)) return GM_ERR_ARG;
+    if (n < 0 || n > 4096) return fail(GM_ERR_ARG, "gm_timing_reserve: 0 <= n <= 4096");
+    HIP_TRY(hipSetDevice(idx->device));
+    timing_clear(idx);
+    for (int i = 0; i < n; ++i) {
+        hipEvent_t a = nullptr, b = nullptr;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess)
+            return fail(GM_ERR_DEVICE, "hipEventCreate failed");
+        idx->hist0.push_back(a);
+        idx->hist1.push_back(b);
+    }
+    return GM_OK;
+}
+
+int gm_timing_read(gm_index* idx, double* ms_out, int max_n) {
+    if (check_index(idx)) return GM_ERR_ARG;
+    if (!ms_out || max_n < 0) return fail(GM_ERR_ARG, "gm_timing_read: bad argument");
+    if (idx->hist0.empty()) return 0;
+    if (hipSetDevice(idx->device) != hipSuccess) return fail(GM_ERR_DEVICE, "hipSetDevice failed");
+    const int64_t cap = (int64_t)idx->hist0.size();
+    const int64_t have = idx->hist_count < cap ? idx->hist_count : cap;
+    const int64_t first = idx->hist_count - have;
+    int n = 0;
+    for (int64_t i = first; i < idx->hist_count && n < max_n; ++i, ++n) {
+        float ms = 0.f;
+        if (hipEventSynchronize(idx->hist1[i % cap]) != hipSuccess ||
+            hipEventElapsedTime(&ms, idx->hist0[i % cap], idx->hist1[i % cap]) != hipSuccess)
+            return fail(GM_ERR_DEVICE, "gm_timing_read: event query failed");
+        ms_out[n] = (double)ms;
+    }
+    return n;
+}
+
+const char* gm_last_kernel_name(gm_index* idx) { return idx ? idx->last_kernel : ""; }
+int64_t gm_last_kernel_pairs(gm_index* idx) { return idx ? idx->last_pairs : 0; }
+
+}  // extern "C"

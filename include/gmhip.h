@@ -1,0 +1,115 @@
+/*
+ * gmhip.h -- C ABI of libgmhip.so: MI355X (gfx950) guide-RNA neighbour search + CFD scoring.
+ *
+ * This is the drop-in boundary for GuideMaker's one data-parallel hot path.  Each entry point
+ * replaces one interface of the reference (citations into USDA-ARS-GBRU/GuideMaker v0.4.2):
+ *
+ *   gm_pack                 guidemaker/core.py:379-386  TargetProcessor._one_hot_encode (and its
+ *                           inline copy core.py:594-601): sequence -> the encoding the index eats
+ *   gm_index_create         guidemaker/core.py:451-456 / 461-466  nmslib.init(space='bit_hamming' |
+ *                           'leven', DistType.INT, OBJECT_AS_STRING, 'hnsw') + addDataPointBatch +
+ *                           createIndex
+ *   gm_knn_query            guidemaker/core.py:501-503  index.setQueryTimeParams + knnQueryBatch(k)
+ *   gm_nearest_dist         guidemaker/core.py:603-606  knnQueryBatch(binseq, k=2) then i[1][0]
+ *   gm_cfd_batch            guidemaker/cfd_score_calculator.py:60-85  calc_cfd, batched
+ *   gm_index_free           (index object lifetime, core.py:321 self.nmslib_index)
+ *
+ * Conventions
+ *   - plain C types only; the caller owns every buffer; nothing is retained except inside a handle
+ *   - every function returns 0 on success, <0 on error; gm_last_error() returns the thread-local
+ *     message of the last failure
+ *   - sequences cross the boundary 2-bit packed: uint64 per target, base p in bits [2p, 2p+1],
+ *     A=0 C=1 G=2 T=3, all higher bits zero, 1 <= guidelen <= 27 (reference CLI range 10..27,
+ *     cli.py:43-44)
+ *   - distances are in TRUE units (mismatching bases / edit operations).  The reference sees
+ *     2 x mismatches for Hamming because of the one-hot encoding (core.py:510-514); the host side
+ *     applies that factor where it mirrors the reference's comparison.
+ *   - neighbour lists are exact and ordered by (distance ascending, db index ascending); rows with
+ *     fewer than k db points are padded with -1 and counts[] holds the valid length
+ *   - *_dev variants take DEVICE pointers (HBM-resident inputs/outputs) and a hipStream_t passed as
+ *     void*; they enqueue asynchronously on that stream
+ *   - one host thread per handle; handles are independent; one handle = one GPU (multi-GPU is one
+ *     process per GPU)
+ *   - there is NO CPU fallback: without a gfx950 device every compute entry point fails with
+ *     GM_ERR_DEVICE
+ */
+#ifndef GMHIP_H
+#define GMHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GM_METRIC_HAMMING 0
+#define GM_METRIC_LEVEN 1
+
+#define GM_OK 0
+#define GM_ERR_ARG (-1)      /* bad argument */
+#define GM_ERR_DEVICE (-2)   /* no usable GPU / HIP runtime error */
+#define GM_ERR_ALLOC (-3)    /* out of memory */
+#define GM_ERR_SEQ (-4)      /* non-ACGT base in input */
+
+#define GM_MAX_GUIDELEN 27
+#define GM_MAX_K 64
+#define GM_MAX_DB (1 << 27)  /* neighbour keys are (dist << 27 | id) */
+
+typedef struct gm_index gm_index;
+
+const char* gm_version(void);
+const char* gm_last_error(void);
+int gm_device_count(void);
+
+/* ASCII -> packed.  seqs: n rows of guidelen chars, no terminators.  GM_ERR_SEQ on a non-ACGT base. */
+int gm_pack(const char* seqs, int64_t n, int guidelen, uint64_t* out);
+int gm_unpack(const uint64_t* packed, int64_t n, int guidelen, char* out);
+
+/* Build the (exact, brute-force) index on GPU `device`: copies the packed db to HBM as bit planes. */
+int gm_index_create(const uint64_t* packed, int64_t n_db, int guidelen, int metric, int device,
+                    gm_index** out);
+int gm_index_create_dev(const void* d_packed, int64_t n_db, int guidelen, int metric, int device,
+                        void* stream, gm_index** out);
+void gm_index_free(gm_index* idx);
+int64_t gm_index_size(const gm_index* idx);
+int gm_index_guidelen(const gm_index* idx);
+int gm_index_metric(const gm_index* idx);
+
+/* k nearest db points of every query.  ids/dists: [n_q * k] int32, counts: [n_q] int32. */
+int gm_knn_query(gm_index* idx, const uint64_t* q, int64_t n_q, int k,
+                 int32_t* ids, int32_t* dists, int32_t* counts);
+int gm_knn_query_dev(gm_index* idx, const void* d_q, int64_t n_q, int k,
+                     void* d_ids, void* d_dists, void* d_counts, void* stream);
+
+/* distance to the nearest db point of every query.  d1: [n_q] int32 (-1 if the index is empty). */
+int gm_nearest_dist(gm_index* idx, const uint64_t* q, int64_t n_q, int32_t* d1);
+int gm_nearest_dist_dev(gm_index* idx, const void* d_q, int64_t n_q, void* d_d1, void* stream);
+
+/* CFD score of n_pairs (guide, off-target) pairs.  mm: [20*4*4] doubles,
+ * mm[(pos-1)*16 + r*4 + d], r = guide base (ACGU), d = complement of the off-target base (ACGT),
+ * 1.0 on the Watson-Crick entries.  out: [n_pairs] doubles. */
+int gm_cfd_batch(const uint64_t* guides, const uint64_t* offs, int64_t n_pairs, int guidelen,
+                 const double* mm, double* out, int device);
+int gm_cfd_batch_dev(const void* d_guides, const void* d_offs, int64_t n_pairs, int guidelen,
+                     const void* d_mm, void* d_out, void* stream);
+
+/* Measurement hooks: HIP-event duration (ms) of the dominant scan kernel of the last query on this
+ * handle (blocks until that kernel has finished), its name, and the pairs it evaluated. */
+double gm_last_kernel_ms(gm_index* idx);
+const char* gm_last_kernel_name(gm_index* idx);
+int64_t gm_last_kernel_pairs(gm_index* idx);
+
+/* Per-launch timing history: gm_timing_reserve(idx, n) arms n HIP-event pairs (and resets the
+ * history); every later scan-kernel launch on this handle records into the next pair (wrapping);
+ * gm_timing_read waits for the recorded launches and writes up to max_n durations (ms, oldest
+ * first) into ms_out, returning how many were written. */
+int gm_timing_reserve(gm_index* idx, int n);
+int gm_timing_read(gm_index* idx, double* ms_out, int max_n);
+
+/* Tuning knob for experiments (bench/tests): select a kernel variant; 0 = default. */
+int gm_set_variant(gm_index* idx, int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GMHIP_H */

@@ -1,0 +1,280 @@
+"""GPU parity tests: the HIP path (through the C-ABI in libgmhip.so) against the CPU oracle, the
+reference's known answers and the golden fixtures.  Bar: bit-exact for distances / ids / counts,
+|delta| <= 1e-6 for CFD (observed: bit-exact)."""
+import random
+
+import numpy as np
+import pytest
+
+from conftest import load_json, load_carsonella
+from helpers import Rec, carsonella, random_pool, targets_frame
+
+import guidemaker_amd
+from guidemaker_amd import _lib, core
+
+pytestmark = pytest.mark.gpu
+CONFIG = guidemaker_amd.CONFIG_PATH
+
+
+def _oracle_true_units(orc, db, q, L, metric, k):
+    ids, dists, counts = orc.knn(db, q, L, metric, k)
+    if metric == "hamming":
+        dists = np.where(dists >= 0, dists // 2, -1)     # oracle reports nmslib's one-hot units
+    return ids, dists, counts
+
+
+def _gpu_knn(db, q, L, metric, k):
+    idx = _lib.Index(_lib.pack(db, L), L, _lib.METRIC_HAMMING if metric == "hamming" else _lib.METRIC_LEVEN)
+    try:
+        return idx.knn(_lib.pack(q, L), k)
+    finally:
+        idx.close()
+
+
+# ------------------------------------------------------------------ reference known answers
+def test_get_neighbors_three_row():
+    # reference tests/test_core.py:116-126
+    kat = load_json("knn_kat.json")["three_row"]
+    tl = core.TargetProcessor(targets=targets_frame(kat["targets"]), lsr=10, editdist=2, knum=2)
+    tl.check_restriction_enzymes(["NRAGCA"])
+    tl.find_unique_near_pam()
+    tl.create_index(configpath=CONFIG)
+    tl.get_neighbors(configpath=CONFIG)
+    assert tl.neighbors["AAATGGTACGTTATGTGTTA"]["neighbors"]["dist"][1] == 12
+    assert tl.neighbors["AAATGGTACGTTATGTGTTA"]["neighbors"]["seqs"] == [
+        "AAATGGTACGTTATGTGTTA", "AACAGTAAAATGGTTTAATG"]
+
+
+def test_export_bed_knum_larger_than_index():
+    # reference tests/test_core.py:129-139: knum=10 on a 2-point index
+    kat = load_json("knn_kat.json")["three_row"]
+    tl = core.TargetProcessor(targets=targets_frame(kat["targets"]), lsr=10, editdist=2, knum=10)
+    tl.check_restriction_enzymes(["NRAGCA"])
+    tl.find_unique_near_pam()
+    tl.create_index(configpath=CONFIG)
+    tl.get_neighbors(configpath=CONFIG)
+    assert tl.neighbors["AAATGGTACGTTATGTGTTA"]["neighbors"]["dist"] == [0, 12]
+    assert tl.export_bed().shape == (2, 5)
+
+
+def test_levin_dist():
+    # reference tests/test_core.py:319-347
+    kat = load_json("knn_kat.json")["levin"]
+    distseq = [Rec(kat["seq"], "distseq")]
+    pd_levin = core.PamTarget("NGG", "3prime", "levin").find_targets(distseq, 20)
+    pd_hamming = core.PamTarget("NGG", "3prime", "hamming").find_targets(distseq, 20)
+    tp_levin = core.TargetProcessor(targets=pd_levin, lsr=0, editdist=1, knum=3)
+    tp_hamming = core.TargetProcessor(targets=pd_hamming, lsr=0, editdist=1, knum=3)
+    for tp in (tp_levin, tp_hamming):
+        tp.find_unique_near_pam()
+        tp.check_restriction_enzymes()
+        tp.create_index(configpath=CONFIG)
+        tp.get_neighbors(configpath=CONFIG)
+    assert tp_levin.neighbors['CTAGTCACTAGCTGACAGCA']['neighbors']['dist'] == [0, 1, 2]
+    assert tp_hamming.neighbors['CTAGTCACTAGCTGACAGCA']['neighbors']['dist'] == [0, 1, 16]
+
+
+def test_single_point_index_raises_like_reference():
+    # reference core.py:512 editdist[1] -> IndexError when nmslib returns < 2 hits
+    tl = core.TargetProcessor(targets=targets_frame(["ACGTACGTACGTACGTACGT"]), lsr=0, editdist=1, knum=2)
+    tl.find_unique_near_pam()
+    tl.check_restriction_enzymes()
+    tl.create_index(configpath=CONFIG)
+    with pytest.raises(IndexError):
+        tl.get_neighbors(configpath=CONFIG)
+
+
+# ------------------------------------------------------------------ oracle parity, real data
+@pytest.mark.parametrize("tag,orient", [("NGG5p", "5prime"), ("NGG3p", "3prime")])
+@pytest.mark.parametrize("dtype", ["hamming", "leven"])
+def test_carsonella_neighbors_match_oracle(oracle, tag, orient, dtype):
+    cols = load_carsonella(tag)
+    df = core.PamTarget("NGG", orient, dtype).find_targets(carsonella(), 20)
+    tl = core.TargetProcessor(targets=df, lsr=10, editdist=2, knum=10)
+    tl.check_restriction_enzymes(["NRAGCA"])
+    tl.find_unique_near_pam()
+    tl.create_index(configpath=CONFIG)
+    tl.get_neighbors(configpath=CONFIG)
+
+    otp = oracle.OracleTargetProcessor(cols["target"], dtype, 2, 10, cols["isseedduplicated"],
+                                       cols["hasrestrictionsite"])
+    otp.create_index()
+    otp.get_neighbors()
+    assert tl._db_targets.tolist() == otp.db
+    assert set(tl.neighbors.keys()) == set(otp.neighbors.keys())           # P2 retained set
+    for key, val in otp.neighbors.items():
+        assert tl.neighbors[key]["neighbors"]["dist"] == val["neighbors"]["dist"]   # P1
+        assert tl.neighbors[key]["neighbors"]["seqs"] == val["neighbors"]["seqs"]   # P3
+    if dtype == "hamming":
+        expect = {"NGG5p": 3808, "NGG3p": 3810}[tag]
+        assert len(tl.neighbors) == expect
+        ids, dists, _ = tl.last_knn
+        want_first = {"NGG5p": [0, 6, 6, 7, 7, 7, 7, 7, 7, 7], "NGG3p": [0, 6, 6, 6, 6, 6, 6, 7, 7, 7]}[tag]
+        assert dists[0].tolist() == want_first
+
+
+# ------------------------------------------------------------------ oracle parity, synthetic pools
+@pytest.mark.parametrize("L", [10, 17, 20, 23, 27])
+@pytest.mark.parametrize("k", [2, 10, 20])
+def test_hamming_knn_matches_oracle(oracle, L, k):
+    db = list(dict.fromkeys(random_pool(3000 + 37 * L, L, seed=L * 100 + k)))
+    q = db[::3] + random_pool(200, L, seed=5)
+    ids, dists, counts = _gpu_knn(db, q, L, "hamming", k)
+    oi, od, oc = _oracle_true_units(oracle, db, q, L, "hamming", k)
+    assert (counts == oc).all()
+    assert (dists == od).all()
+    assert (ids == oi).all()
+
+
+@pytest.mark.parametrize("L", [10, 20, 23, 27])
+@pytest.mark.parametrize("k", [2, 5, 20])
+def test_leven_knn_matches_oracle(oracle, L, k):
+    db = list(dict.fromkeys(random_pool(1500 + 11 * L, L, seed=L * 7 + k, indel=True)))
+    q = db[::4] + random_pool(100, L, seed=6, indel=True)
+    ids, dists, counts = _gpu_knn(db, q, L, "leven", k)
+    oi, od, oc = _oracle_true_units(oracle, db, q, L, "leven", k)
+    assert (counts == oc).all()
+    assert (dists == od).all()
+    assert (ids == oi).all()
+
+
+def test_ragged_and_edge_sizes(oracle):
+    L = 20
+    pool = list(dict.fromkeys(random_pool(1300, L, seed=11)))
+    for n_db in (1, 2, 3, 63, 64, 65, 511, 512, 513, 1025):
+        for n_q in (1, 63, 257):
+            for metric in ("hamming", "leven"):
+                db, q = pool[:n_db], pool[-n_q:]
+                k = 5
+                ids, dists, counts = _gpu_knn(db, q, L, metric, k)
+                oi, od, oc = _oracle_true_units(oracle, db, q, L, metric, k)
+                assert (counts == oc).all() and (dists == od).all() and (ids == oi).all(), (n_db, n_q, metric)
+    # empty query set and empty index
+    idx = _lib.Index(_lib.pack(pool[:10], L), L, _lib.METRIC_HAMMING)
+    ids, dists, counts = idx.knn(np.empty((0,), np.uint64), 3)
+    assert ids.shape == (0, 3) and counts.shape == (0,)
+    idx.close()
+    idx = _lib.Index(np.empty((0,), np.uint64), L, _lib.METRIC_HAMMING)
+    ids, dists, counts = idx.knn(_lib.pack(pool[:5], L), 3)
+    assert (ids == -1).all() and (dists == -1).all() and (counts == 0).all()
+    assert (idx.nearest(_lib.pack(pool[:5], L)) == -1).all()
+    idx.close()
+
+
+def test_duplicate_db_entries_and_ties(oracle):
+    # collisions: many identical / equidistant db points -> canonical (distance, id) order
+    L = 20
+    base = "ACGTACGTACGTACGTACGT"
+    db = [base] * 40 + [base[:-1] + "A"] * 40 + random_pool(500, L, seed=2)
+    q = [base, base[:-1] + "C", base[:-2] + "AA"]
+    for metric in ("hamming", "leven"):
+        ids, dists, counts = _gpu_knn(db, q, L, metric, 20)
+        oi, od, oc = _oracle_true_units(oracle, db, q, L, metric, 20)
+        assert (ids == oi).all() and (dists == od).all() and (counts == oc).all()
+    assert ids[0].tolist() == list(range(20))
+
+
+@pytest.mark.parametrize("metric", ["hamming", "leven"])
+def test_nearest_dist_matches_oracle(oracle, metric):
+    L = 20
+    db = list(dict.fromkeys(random_pool(2500, L, seed=21, indel=True)))
+    q = random_pool(700, L, seed=22) + db[:50]
+    idx = _lib.Index(_lib.pack(db, L), L, _lib.METRIC_HAMMING if metric == "hamming" else _lib.METRIC_LEVEN)
+    d1 = idx.nearest(_lib.pack(q, L))
+    idx.close()
+    _, od, _ = _oracle_true_units(oracle, db, q, L, metric, 2)
+    assert (d1 == od[:, 0]).all()
+
+
+# ------------------------------------------------------------------ size-independent properties
+def test_full_size_properties():
+    """E. coli-sized pool (BASELINE config 2 shape): properties that need no oracle."""
+    L, k, n = 20, 10, 560_000
+    rng = np.random.default_rng(1)
+    codes = rng.integers(0, 4, size=(n, L), dtype=np.uint8)
+    packed = np.unique(core.pack_codes(codes))
+    rng.shuffle(packed)
+    n = packed.shape[0]
+    idx = _lib.Index(packed, L, _lib.METRIC_HAMMING)
+    qsel = rng.choice(n, size=70_000, replace=False)
+    ids, dists, counts = idx.knn(packed[qsel], k)
+    assert (counts == k).all()
+    assert (dists[:, 0] == 0).all() and (ids[:, 0] == qsel).all()          # self is the nearest
+    assert (np.diff(dists, axis=1) >= 0).all()                              # sorted
+    same = np.diff(dists, axis=1) == 0
+    assert (np.diff(ids, axis=1)[same] > 0).all()                           # ties by id
+    # reported distances are the true distances of the reported ids
+    x = packed[qsel][:, None] ^ packed[ids]
+    mism = ((x | (x >> np.uint64(1))) & np.uint64(0x5555555555555555))
+    pop = np.zeros(mism.shape, np.int32)
+    for b in range(0, 64, 2):
+        pop += ((mism >> np.uint64(b)) & np.uint64(1)).astype(np.int32)
+    assert (pop == dists).all()
+    # nearest-distance kernel agrees with the k-NN kernel: query != db point -> compare on a probe set
+    probe = core.pack_codes(rng.integers(0, 4, size=(5000, L), dtype=np.uint8))
+    d1 = idx.nearest(probe)
+    pid, pd_, _ = idx.knn(probe, 2)
+    assert (d1 == pd_[:, 0]).all()
+    # idempotence: same call, same answer
+    ids2, dists2, _ = idx.knn(packed[qsel], k)
+    assert (ids2 == ids).all() and (dists2 == dists).all()
+    # shard invariance (the multi-GPU decomposition): query shards give the same rows
+    for nshard in (2, 8):
+        parts = [idx.knn(part, k) for part in np.array_split(packed[qsel], nshard)]
+        assert (np.concatenate([p[0] for p in parts]) == ids).all()
+        assert (np.concatenate([p[1] for p in parts]) == dists).all()
+    idx.close()
+
+
+# ------------------------------------------------------------------ controls
+def test_get_control_seqs(oracle):
+    # reference tests/test_core.py:144-155 (shape), plus exact agreement with the oracle on the draw
+    df = core.PamTarget("NGG", "5prime", "hamming").find_targets(carsonella(), 20)
+    tl = core.TargetProcessor(targets=df, lsr=10, editdist=2, knum=10)
+    tl.check_restriction_enzymes(['NRAGCA'])
+    tl.find_unique_near_pam()
+    tl.create_index(configpath=CONFIG)
+    np.random.seed(42)
+    data = tl.get_control_seqs(carsonella(), length=20, n=100, num_threads=2, configpath=CONFIG)
+    assert data[2].shape == (100, 3)
+    assert list(data[2].columns) == ["name", "Sequences", "Hamming distance"]
+    assert data[0] >= 7 and tl.ncontrolsearched in (1000, 10000, 100000)
+    assert abs(tl.gc_percent - 16.56) < 0.01
+    # replay the same RNG stream through the oracle's restatement of core.py:586-617
+    otp = oracle.OracleTargetProcessor(df["target"].tolist(), "hamming", 2, 10)
+    otp.create_index()
+    np.random.seed(42)
+    gc = tl.gc_percent / 100
+    minimum, sm = 0, 0
+    while minimum < 7:
+        mult = [10, 100, 1000, 10000][sm]
+        seqs = core.TargetProcessor._draw_control_seqs(100 * mult, 20, gc)
+        sort_seq, sort_dist, minimum = otp.control_select(seqs, 100)
+        sm += 1
+    assert data[2]["Sequences"].tolist() == sort_seq
+    assert data[2]["Hamming distance"].tolist() == sort_dist
+    assert (data[0], data[1]) == otp.control_stats(sort_dist)
+
+
+# ------------------------------------------------------------------ CFD
+def test_cfd_golden(cfd_table):
+    cases = load_json("cfd_kat.json")["cases"]
+    got = core.calc_cfd_pairs([c["guide"] for c in cases], [c["off"] for c in cases])
+    want = np.array([float.fromhex(c["cfd_hex"]) for c in cases])
+    assert np.abs(got - want).max() <= 1e-6          # north-star tolerance
+    assert (got == want).all()                       # and in fact bit-exact
+    # reference tests/test_core.py:265-267
+    assert abs(core.calc_cfd("GCATGCACAGCTAGCATGCATGCAGCT", "GCATGCACAGCTAGCATGCATGCAGCG") - 0.176470588) < 1e-4
+
+
+def test_cfd_score_frame(oracle, cfd_table):
+    import pandas as pd
+    rng = random.Random(9)
+    guides = random_pool(300, 20, seed=31)
+    sims = [";".join(random_pool(10, 20, seed=100 + i)[:rng.randint(1, 10)]) for i in range(300)]
+    df = pd.DataFrame({"Guide sequence": guides, "Similar guides": sims})
+    out = core.cfd_score(df)
+    want_lists, want_max = oracle.cfd_score_rows(guides, sims, cfd_table)
+    assert out["CFD Similar Guides"].tolist() == want_lists
+    assert out["Max CFD"].tolist() == want_max
+    assert out["Max CFD"][0] > 0                      # reference tests/test_core.py:315

@@ -1,0 +1,144 @@
+"""CPU tests of the host side: PAM scan, filters, RNG stream, packing, and the C-ABI library's
+exported symbols.  No compute entry point is called here (there is no GPU in this container)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import load_json, load_carsonella, ROOT
+from helpers import Rec, carsonella
+
+import guidemaker_amd
+from guidemaker_amd import _lib, core
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "gmhip.h")).read()
+    declared = set(re.findall(r"\b(gm_[a-z0-9_]+)\s*\(", header))
+    declared.discard("gm_index")
+    assert declared == set(_lib.EXPORTS)
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert b"gfx950" in _lib.lib().gm_version()
+
+
+def test_no_cpu_fallback_without_gpu():
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(_lib.GmHipError, match="no HIP device"):
+        _lib.Index(_lib.pack(["ACGTACGTAC"], 10), 10, _lib.METRIC_HAMMING)
+    with pytest.raises(_lib.GmHipError, match="no HIP device"):
+        core.calc_cfd("ACGTACGTAC", "ACGTACGTAA")
+
+
+def test_product_does_not_import_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "guidemaker_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.lower() or f == "core.py" and "oracle" not in text, f
+
+
+def test_pack_roundtrip_and_layout():
+    seqs = ["ACGTACGTAC", "TTTTTTTTTT", "AAAAAAAAAA", "GATTACAGAT"]
+    p = _lib.pack(seqs, 10)
+    assert p[0] == sum(c << (2 * i) for i, c in enumerate([0, 1, 2, 3, 0, 1, 2, 3, 0, 1]))
+    assert p[1] == (1 << 20) - 1 and p[2] == 0
+    assert _lib.unpack(p, 10) == seqs
+    codes = np.array([["ACGT".index(c) for c in s] for s in seqs], dtype=np.uint8)
+    assert (core.pack_codes(codes) == p).all()
+    for L in range(1, 28):
+        s = ("ACGT" * 7)[:L]
+        assert _lib.unpack(_lib.pack([s], L), L) == [s]
+    with pytest.raises(ValueError):
+        _lib.pack(["ACGTNCGTAC"], 10)
+    with pytest.raises(ValueError):
+        _lib.pack(["ACGT", "ACG"], 4)
+    with pytest.raises(_lib.GmHipError):
+        _lib.pack(["A" * 28], 28)
+
+
+def test_find_targets_known_answers():
+    kat = load_json("find_targets_kat.json")
+    for name, case in kat["cases"].items():
+        pt = core.PamTarget(case["pam"], case["orientation"], "hamming")
+        df = pt.find_targets([Rec(case["seq"], name)], case["target_len"])
+        got = [[r.target, str(r.exact_pam), int(r.start), int(r.stop), bool(r.strand),
+                bool(r.pam_orientation), r.target_seq30] for r in df.itertuples()]
+        assert got == case["rows"], name
+    # the two assertions of the reference's tests/test_core.py:41-57
+    c5 = kat["cases"]["testseq1_NGG_5p_L6"]["rows"]
+    assert c5[0][0] == "ATGCAC" and c5[1][0] == "TAACAA"
+    c3 = kat["cases"]["testseq1_NGG_3p_L6"]["rows"]
+    assert c3[0][0] == "ATGATC" and c3[1][0] == "ATTAGA"
+
+
+@pytest.mark.parametrize("tag,orient", [("NGG5p", "5prime"), ("NGG3p", "3prime")])
+def test_carsonella_targets_and_filters(tag, orient):
+    cols = load_carsonella(tag)
+    pt = core.PamTarget("NGG", orient, "hamming")
+    df = pt.find_targets(carsonella(), 20)
+    assert df["target"].tolist() == cols["target"]
+    assert df["start"].tolist() == cols["start"]
+    assert df["stop"].tolist() == cols["stop"]
+    assert df["strand"].tolist() == cols["strand"]
+    assert list(df.columns) == ["target", "exact_pam", "start", "stop", "strand", "pam_orientation",
+                                "target_seq30", "seqid", "seedseq", "hasrestrictionsite",
+                                "isseedduplicated", "dtype"]
+    tp = core.TargetProcessor(df, lsr=10, editdist=2, knum=10)
+    tp.check_restriction_enzymes(["NRAGCA"])
+    tp.find_unique_near_pam()
+    assert tp.targets["isseedduplicated"].tolist() == cols["isseedduplicated"]
+    assert tp.targets["hasrestrictionsite"].tolist() == cols["hasrestrictionsite"]
+    summ = load_json("carsonella_summary.json")["summary"][tag]
+    assert len(tp._query_targets()) == summ["n_query"]
+    assert tp.export_bed().shape == (summ["n_bed"], 5)
+    assert len(tp) == summ["n_targets"] and "potential PAM targets" in str(tp)
+
+
+def test_three_row_filters():
+    # reference tests/test_core.py:86-102
+    from helpers import targets_frame
+    kat = load_json("knn_kat.json")["three_row"]
+    tl = core.TargetProcessor(targets_frame(kat["targets"]), lsr=10, editdist=2, knum=2)
+    tl.check_restriction_enzymes(["NGGTAB"])
+    assert tl.targets["hasrestrictionsite"][0] == True
+    tl.find_unique_near_pam()
+    assert tl.targets[tl.targets["isseedduplicated"] == False].shape == (2, 12)
+
+
+def test_extend_ambiguous_dna():
+    kat = load_json("knn_kat.json")["extend_ambiguous_dna"]
+    for k, v in kat.items():
+        assert core.extend_ambiguous_dna(k) == v
+
+
+def test_pam_asserts():
+    with pytest.raises(AssertionError):
+        core.PamTarget("NGZ", "5prime", "hamming")
+    with pytest.raises(AssertionError):
+        core.PamTarget("NGG", "sideways", "hamming")
+    assert core.PamTarget("ngg", "5prime", "hamming").pam == "NGG"
+    assert str(core.PamTarget("NGG", "5prime", "hamming")) == "A PAM object: NGG"
+
+
+def test_control_draw_consumes_rng_like_np_random_choice():
+    # reference core.py:590-592 draws each control with np.random.choice(..., p=...)
+    gc, length, count = 0.37, 20, 50
+    p = [gc / 2, gc / 2, (1 - gc) / 2, (1 - gc) / 2]
+    np.random.seed(123)
+    want = ["".join(np.random.choice(a=["G", "C", "A", "T"], size=length, replace=True, p=p))
+            for _ in range(count)]
+    after_want = np.random.random_sample()
+    np.random.seed(123)
+    got = core.TargetProcessor._draw_control_seqs(count, length, gc)
+    after_got = np.random.random_sample()
+    assert got == want and after_got == after_want
+
+
+def test_cfd_length_assert():
+    with pytest.raises(AssertionError, match="lengths wt and off differ"):
+        core.calc_cfd("ACGT", "ACG")
