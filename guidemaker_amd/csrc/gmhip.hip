@@ -1,6 +1,7 @@
 // gmhip.hip -- C ABI (include/gmhip.h) over the gfx950 kernels in gm_kernels.hip.h.
 // Host side of libgmhip.so: handle management, HBM workspaces, launches, HIP-event timing.
 #include "gm_kernels.hip.h"
+#include "gm_bitslice.hip.h"
 
 #include <string>
 #include <vector>
@@ -36,6 +37,8 @@ struct gm_index {
     int64_t n_db = 0;
     int64_t n_db_pad = 0;
     uint2* d_db = nullptr;        // bit planes, padded to a multiple of gm::TILE
+    uint32_t* d_vert = nullptr;   // bit-sliced groups of 32 entries (Hamming, 10 <= L <= 27)
+    int64_t n_groups = 0;
     // workspaces (grow-only), so repeated queries do not allocate
     uint2* d_q = nullptr;
     int64_t q_cap = 0;
@@ -114,6 +117,34 @@ int launch_leven_knn(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* d
                        n_tiles, idx->d_q, n_q, k, idx->L, ids, dists, counts);
     HIP_TRY(hipGetLastError());
     return GM_OK;
+}
+
+template <int L, bool NEAREST>
+int launch_bs(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* dists, int32_t* counts,
+              hipStream_t st) {
+    int64_t blocks = (n_q + gm::WAVE - 1) / gm::WAVE;
+    size_t lds = sizeof(uint32_t) * (size_t)k * gm::WAVE;
+    hipLaunchKernelGGL((gm::k_hamming_knn_bs<L, NEAREST>), dim3((unsigned)blocks), dim3(gm::WAVE), lds, st,
+                       idx->d_vert, (int)idx->n_db, (int)idx->n_groups, idx->d_q, n_q, k, ids, dists, counts);
+    HIP_TRY(hipGetLastError());
+    return GM_OK;
+}
+
+template <bool NEAREST>
+int launch_bs_by_len(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* dists, int32_t* counts,
+                     hipStream_t st) {
+    switch (idx->L) {
+#define GM_CASE(LEN) case LEN: return launch_bs<LEN, NEAREST>(idx, n_q, k, ids, dists, counts, st);
+        GM_CASE(10) GM_CASE(11) GM_CASE(12) GM_CASE(13) GM_CASE(14) GM_CASE(15) GM_CASE(16) GM_CASE(17)
+        GM_CASE(18) GM_CASE(19) GM_CASE(20) GM_CASE(21) GM_CASE(22) GM_CASE(23) GM_CASE(24) GM_CASE(25)
+        GM_CASE(26) GM_CASE(27)
+#undef GM_CASE
+        default: return fail(GM_ERR_ARG, "bit-sliced kernel: guidelen out of range");
+    }
+}
+
+bool use_bitslice(const gm_index* idx) {
+    return idx->metric == GM_METRIC_HAMMING && idx->d_vert != nullptr && idx->variant == 0;
 }
 
 int timing_begin(gm_index* idx, hipStream_t st) {
@@ -223,6 +254,21 @@ int gm_index_create_dev(const void* d_packed, int64_t n_db, int guidelen, int me
             gm_index_free(idx);
             return rc;
         }
+        if (metric == GM_METRIC_HAMMING && guidelen >= 10 && guidelen <= 27) {
+            const int W = gm::vert_stride(guidelen);
+            idx->n_groups = (n_db + gm::GROUP - 1) / gm::GROUP;
+            if (hipMalloc(&idx->d_vert, sizeof(uint32_t) * idx->n_groups * W) != hipSuccess) {
+                gm_index_free(idx);
+                return fail(GM_ERR_ALLOC, "hipMalloc(db bit-sliced groups) failed");
+            }
+            int64_t words = idx->n_groups * W;
+            hipLaunchKernelGGL(gm::k_to_vertical, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st,
+                               idx->d_db, n_db, idx->d_vert, idx->n_groups, guidelen, W);
+            if (hipGetLastError() != hipSuccess) {
+                gm_index_free(idx);
+                return fail(GM_ERR_DEVICE, "k_to_vertical launch failed");
+            }
+        }
     }
     if (hipEventCreate(&idx->ev0) != hipSuccess || hipEventCreate(&idx->ev1) != hipSuccess) {
         gm_index_free(idx);
@@ -267,6 +313,7 @@ void gm_index_free(gm_index* idx) {
     if (!idx) return;
     (void)hipSetDevice(idx->device);
     if (idx->d_db) (void)hipFree(idx->d_db);
+    if (idx->d_vert) (void)hipFree(idx->d_vert);
     if (idx->d_q) (void)hipFree(idx->d_q);
     if (idx->d_stage) (void)hipFree(idx->d_stage);
     timing_clear(idx);
@@ -309,7 +356,10 @@ int gm_knn_query_dev(gm_index* idx, const void* d_q, int64_t n_q, int k, void* d
     rc = timing_begin(idx, st);
     if (rc) return rc;
     const int R = pick_r(k);
-    if (idx->metric == GM_METRIC_HAMMING) {
+    if (use_bitslice(idx)) {
+        idx->last_kernel = "k_hamming_knn_bs";
+        rc = launch_bs_by_len<false>(idx, n_q, k, ids, dists, counts, st);
+    } else if (idx->metric == GM_METRIC_HAMMING) {
         idx->last_kernel = "k_hamming_knn";
         rc = R == 4 ? launch_hamming_knn<4>(idx, n_q, k, ids, dists, counts, st)
            : R == 2 ? launch_hamming_knn<2>(idx, n_q, k, ids, dists, counts, st)
@@ -365,7 +415,11 @@ int gm_nearest_dist_dev(gm_index* idx, const void* d_q, int64_t n_q, void* d_d1,
     int n_tiles = (int)(idx->n_db_pad / gm::TILE);
     rc = timing_begin(idx, st);
     if (rc) return rc;
-    if (idx->metric == GM_METRIC_HAMMING) {
+    if (use_bitslice(idx)) {
+        idx->last_kernel = "k_hamming_knn_bs(nearest)";
+        rc = launch_bs_by_len<true>(idx, n_q, 1, nullptr, d1, nullptr, st);
+        if (rc) return rc;
+    } else if (idx->metric == GM_METRIC_HAMMING) {
         constexpr int R = 4;
         int64_t blocks = (n_q + R * gm::WAVE - 1) / (R * gm::WAVE);
         idx->last_kernel = "k_hamming_nearest";

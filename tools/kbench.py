@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmark: random pools, variants A/B-interleaved in ONE process (HIP-event times).
+
+  python tools/kbench.py --n 600000 --k 10 --variants 0,1,2 --rounds 5 [--metric leven] [--nearest]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from guidemaker_amd import _lib, core  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=600000)
+    ap.add_argument("--nq", type=int, default=0)
+    ap.add_argument("--L", type=int, default=20)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--metric", default="hamming")
+    ap.add_argument("--variants", default="0")
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--nearest", action="store_true")
+    ap.add_argument("--check", action="store_true", help="compare every variant's output with variant 0")
+    a = ap.parse_args()
+    rng = np.random.default_rng(5)
+    db = np.unique(core.pack_codes(rng.integers(0, 4, size=(a.n, a.L), dtype=np.uint8)))
+    rng.shuffle(db)
+    q = db if a.nq == 0 else db[:a.nq]
+    idx = _lib.Index(db, a.L, _lib.METRIC_HAMMING if a.metric == "hamming" else _lib.METRIC_LEVEN)
+    variants = [int(v) for v in a.variants.split(",")]
+    times = {v: [] for v in variants}
+    ref = None
+    for r in range(a.rounds + 1):
+        for v in variants:
+            idx.set_variant(v)
+            if a.nearest:
+                out = (idx.nearest(q),)
+            else:
+                out = idx.knn(q, a.k)
+            name, ms, pairs = idx.last_kernel()
+            if r > 0:
+                times[v].append(ms)
+            if a.check:
+                if ref is None:
+                    ref = out
+                else:
+                    assert all((x == y).all() for x, y in zip(ref, out)), "variant %d differs" % v
+    for v in variants:
+        t = np.array(times[v])
+        print("variant %3d %-20s n_db=%d n_q=%d k=%d: median %.3f ms  min %.3f ms  -> %.3e pairs/s"
+              % (v, name, len(db), len(q), a.k, np.median(t), t.min(), len(db) * len(q) / (np.median(t) * 1e-3)))
+
+
+if __name__ == "__main__":
+    main()
