@@ -31,7 +31,25 @@ import torch
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 B_ALG = {"hamming": 16, "leven": 16}     # algorithmic bytes per guide pair: two 8-byte packed operands
 VALU_LANE_OPS_PER_S = 256 * 128 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz
-OPS_ALG = {"hamming": 3.5}               # xor, bitop3, bcnt(+offset), 1/2 min3 per pair
+
+
+def bitslice_ops_per_pair(L):
+    """VALU ops per guide pair of the bit-sliced Hamming kernel (gm_bitslice.hip.h): per group of 32
+    db entries 2L ops for the mismatch words, 2 per full/half adder of the carry-save tree, 5 for the
+    threshold comparator, 1 v_cmp."""
+    def col(n):          # (ops, carries) to reduce n same-weight words to one
+        if n <= 1:
+            return 0, 0
+        if n == 2:
+            return 2, 1
+        t, rem = divmod(n, 3)
+        ops, car = col(t + rem)
+        return 2 * t + ops, t + car
+    ops, n = 0, L
+    while n > 0:
+        o, n = col(n)
+        ops += o
+    return (2 * L + ops + 5 + 1) / 32.0
 
 
 def parse():
@@ -177,11 +195,13 @@ def main():
                 "note": "algorithmic (no-reuse) operand bytes / HIP-event kernel time; the scan is "
                         "VALU-bound, not HBM-bound, so frac > 1 means LDS/register reuse beats the "
                         "streaming model (SURVEY.md 8d)"}
-        if pool["metric"] in OPS_ALG:
-            ops = launch_pairs * OPS_ALG[pool["metric"]] / kern_s
+        if pool["metric"] == "hamming" and 10 <= L <= 27:
+            opp = bitslice_ops_per_pair(L)
+            ops = launch_pairs * opp / kern_s
             roof["valu"] = {"achieved": ops / 1e12, "peak": VALU_LANE_OPS_PER_S / 1e12,
                             "unit": "T lane-ops/s", "frac": ops / VALU_LANE_OPS_PER_S,
-                            "ops_per_pair": OPS_ALG[pool["metric"]]}
+                            "ops_per_pair": opp,
+                            "note": "the binding roof: int32 VALU issue, 256 CUs x 128 lanes/clk x 2.4 GHz"}
         out = {
             "metric": "guide-pair distance comparisons/sec (whole node)",
             "value": value, "unit": "guide-pair comparisons/s", "n_gpus": world, "steps": args.steps,

@@ -102,7 +102,47 @@ __device__ __forceinline__ void bitslice_count(const uint32_t (&m)[L], uint32_t 
 // Dynamic LDS: k * 64 * 4 B (the lists).  k == 1 doubles as the nearest-distance kernel
 // (NEAREST: write only the distance).
 // ---------------------------------------------------------------------------------------------
-template <int L, bool NEAREST>
+// evaluate one group of 32 db entries for this lane's query: c = bit-sliced distance, returns the
+// hit word (bit j set <=> distance of entry j < thr)
+template <int L>
+__device__ __forceinline__ uint32_t eval_group(const uint32_t* __restrict__ vg, const uint32_t (&QL)[L],
+                                               const uint32_t (&QH)[L], const uint32_t (&T)[5],
+                                               uint32_t (&c)[5]) {
+    uint32_t m[L];
+#pragma unroll
+    for (int p = 0; p < L; ++p) {
+        uint32_t x = vg[2 * p] ^ QL[p];
+        m[p] = GM_BITOP3(x, vg[2 * p + 1], QH[p], TT_A_OR_BXC);
+    }
+    bitslice_count<L>(m, c);
+    uint32_t lt = ~c[0] & T[0];
+#pragma unroll
+    for (int i = 1; i < 5; ++i) lt = GM_BITOP3(c[i], T[i], lt, TT_LT);
+    return lt;
+}
+
+// slow path for one group: walk the lane's hit bits in ascending id order
+__device__ __forceinline__ void take_hits(uint32_t lt, const uint32_t (&c)[5], int id0, int n_db, uint32_t* lp,
+                                          int k, int& cnt, int& thr, uint32_t (&T)[5]) {
+    while (lt != 0u) {
+        int j = __builtin_ctz(lt);
+        lt &= lt - 1u;
+        int d = (int)(((c[0] >> j) & 1u) | (((c[1] >> j) & 1u) << 1) | (((c[2] >> j) & 1u) << 2) |
+                      (((c[3] >> j) & 1u) << 3) | (((c[4] >> j) & 1u) << 4));
+        int id = id0 + j;
+        if (d < thr && id < n_db) {
+            list_insert(lp, WAVE, k, cnt, ((uint32_t)d << ID_BITS) | (uint32_t)id);
+            if (cnt == k) {
+                thr = (int)(lp[(k - 1) * WAVE] >> ID_BITS);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) T[i] = 0u - (((uint32_t)thr >> i) & 1u);
+            }
+        }
+    }
+}
+
+// G = groups evaluated per loop iteration (one hit test per G groups); n_groups % G == 0
+template <int L, bool NEAREST, int G>
 __global__ __launch_bounds__(WAVE) void k_hamming_knn_bs(const uint32_t* __restrict__ V, int n_db,
                                                          int n_groups, const uint2* __restrict__ q,
                                                          int64_t n_q, int k, int32_t* __restrict__ ids,
@@ -128,36 +168,20 @@ __global__ __launch_bounds__(WAVE) void k_hamming_knn_bs(const uint32_t* __restr
     for (int i = 0; i < 5; ++i) T[i] = 0u - (((uint32_t)thr >> i) & 1u);
     uint32_t* lp = list + lane;
 
-    for (int g = 0; g < n_groups; ++g) {
+    for (int g = 0; g < n_groups; g += G) {
         const uint32_t* __restrict__ vg = V + (size_t)g * W;     // wave-uniform -> scalar loads
-        uint32_t m[L];
+        uint32_t c[G][5], lt[G];
+        uint32_t any = 0u;
 #pragma unroll
-        for (int p = 0; p < L; ++p) {
-            uint32_t x = vg[2 * p] ^ QL[p];
-            m[p] = GM_BITOP3(x, vg[2 * p + 1], QH[p], TT_A_OR_BXC);
+        for (int u = 0; u < G; ++u) {
+            lt[u] = eval_group<L>(vg + u * W, QL, QH, T, c[u]);
+            any |= lt[u];
         }
-        uint32_t c[5];
-        bitslice_count<L>(m, c);
-        uint32_t lt = ~c[0] & T[0];
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(any != 0u) != 0ull, 0)) {
 #pragma unroll
-        for (int i = 1; i < 5; ++i) lt = GM_BITOP3(c[i], T[i], lt, TT_LT);
-
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(lt != 0u) != 0ull, 0)) {
-            // slow path: walk this lane's hit bits in ascending id order
-            while (lt != 0u) {
-                int j = __builtin_ctz(lt);
-                lt &= lt - 1u;
-                int d = (int)(((c[0] >> j) & 1u) | (((c[1] >> j) & 1u) << 1) | (((c[2] >> j) & 1u) << 2) |
-                              (((c[3] >> j) & 1u) << 3) | (((c[4] >> j) & 1u) << 4));
-                int id = g * GROUP + j;
-                if (d < thr && id < n_db) {
-                    list_insert(lp, WAVE, k, cnt, ((uint32_t)d << ID_BITS) | (uint32_t)id);
-                    if (cnt == k) {
-                        thr = (int)(lp[(k - 1) * WAVE] >> ID_BITS);
-#pragma unroll
-                        for (int i = 0; i < 5; ++i) T[i] = 0u - (((uint32_t)thr >> i) & 1u);
-                    }
-                }
+            for (int u = 0; u < G; ++u) {
+                // thresholds may have tightened since lt[u] was formed: take_hits re-tests d < thr
+                take_hits(lt[u], c[u], (g + u) * GROUP, n_db, lp, k, cnt, thr, T);
             }
         }
     }

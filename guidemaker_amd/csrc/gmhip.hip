@@ -119,13 +119,22 @@ int launch_leven_knn(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* d
     return GM_OK;
 }
 
+constexpr int BS_GROUP_PAD = 4;   // n_groups is padded to a multiple of this (kernels take G | 4)
+
 template <int L, bool NEAREST>
 int launch_bs(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* dists, int32_t* counts,
               hipStream_t st) {
     int64_t blocks = (n_q + gm::WAVE - 1) / gm::WAVE;
     size_t lds = sizeof(uint32_t) * (size_t)k * gm::WAVE;
-    hipLaunchKernelGGL((gm::k_hamming_knn_bs<L, NEAREST>), dim3((unsigned)blocks), dim3(gm::WAVE), lds, st,
-                       idx->d_vert, (int)idx->n_db, (int)idx->n_groups, idx->d_q, n_q, k, ids, dists, counts);
+    if (L == 20 && idx->variant == 2) {   // A/B knob: one group per iteration
+        hipLaunchKernelGGL((gm::k_hamming_knn_bs<20, NEAREST, 1>), dim3((unsigned)blocks), dim3(gm::WAVE), lds,
+                           st, idx->d_vert, (int)idx->n_db, (int)idx->n_groups, idx->d_q, n_q, k, ids, dists,
+                           counts);
+    } else {
+        hipLaunchKernelGGL((gm::k_hamming_knn_bs<L, NEAREST, 2>), dim3((unsigned)blocks), dim3(gm::WAVE), lds,
+                           st, idx->d_vert, (int)idx->n_db, (int)idx->n_groups, idx->d_q, n_q, k, ids, dists,
+                           counts);
+    }
     HIP_TRY(hipGetLastError());
     return GM_OK;
 }
@@ -144,7 +153,7 @@ int launch_bs_by_len(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* d
 }
 
 bool use_bitslice(const gm_index* idx) {
-    return idx->metric == GM_METRIC_HAMMING && idx->d_vert != nullptr && idx->variant == 0;
+    return idx->metric == GM_METRIC_HAMMING && idx->d_vert != nullptr && idx->variant != 1;
 }
 
 int timing_begin(gm_index* idx, hipStream_t st) {
@@ -256,7 +265,7 @@ int gm_index_create_dev(const void* d_packed, int64_t n_db, int guidelen, int me
         }
         if (metric == GM_METRIC_HAMMING && guidelen >= 10 && guidelen <= 27) {
             const int W = gm::vert_stride(guidelen);
-            idx->n_groups = (n_db + gm::GROUP - 1) / gm::GROUP;
+            idx->n_groups = round_up((n_db + gm::GROUP - 1) / gm::GROUP, BS_GROUP_PAD);
             if (hipMalloc(&idx->d_vert, sizeof(uint32_t) * idx->n_groups * W) != hipSuccess) {
                 gm_index_free(idx);
                 return fail(GM_ERR_ALLOC, "hipMalloc(db bit-sliced groups) failed");
