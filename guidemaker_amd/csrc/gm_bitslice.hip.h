@@ -121,6 +121,33 @@ __device__ __forceinline__ uint32_t eval_group(const uint32_t* __restrict__ vg, 
     return lt;
 }
 
+// the same on a group whose 2L words were fetched earlier (software-pipelined scalar loads)
+template <int L>
+struct GroupWords {
+    uint32_t w[2 * L];
+};
+template <int L>
+__device__ __forceinline__ void fetch_group(GroupWords<L>& a, const uint32_t* __restrict__ vg) {
+#pragma unroll
+    for (int i = 0; i < 2 * L; ++i) a.w[i] = vg[i];
+}
+template <int L>
+__device__ __forceinline__ uint32_t eval_words(const GroupWords<L>& a, const uint32_t (&QL)[L],
+                                               const uint32_t (&QH)[L], const uint32_t (&T)[5],
+                                               uint32_t (&c)[5]) {
+    uint32_t m[L];
+#pragma unroll
+    for (int p = 0; p < L; ++p) {
+        uint32_t x = a.w[2 * p] ^ QL[p];
+        m[p] = GM_BITOP3(x, a.w[2 * p + 1], QH[p], TT_A_OR_BXC);
+    }
+    bitslice_count<L>(m, c);
+    uint32_t lt = ~c[0] & T[0];
+#pragma unroll
+    for (int i = 1; i < 5; ++i) lt = GM_BITOP3(c[i], T[i], lt, TT_LT);
+    return lt;
+}
+
 // slow path for one group: walk the lane's hit bits in ascending id order
 __device__ __forceinline__ void take_hits(uint32_t lt, const uint32_t (&c)[5], int id0, int n_db, uint32_t* lp,
                                           int k, int& cnt, int& thr, uint32_t (&T)[5]) {
@@ -141,61 +168,96 @@ __device__ __forceinline__ void take_hits(uint32_t lt, const uint32_t (&c)[5], i
     }
 }
 
-// G = groups evaluated per loop iteration (one hit test per G groups); n_groups % G == 0
-template <int L, bool NEAREST, int G>
-__global__ __launch_bounds__(WAVE) void k_hamming_knn_bs(const uint32_t* __restrict__ V, int n_db,
-                                                         int n_groups, const uint2* __restrict__ q,
-                                                         int64_t n_q, int k, int32_t* __restrict__ ids,
-                                                         int32_t* __restrict__ dists,
-                                                         int32_t* __restrict__ counts) {
-    extern __shared__ __align__(16) uint32_t list[];    // [k][64]
+// G = groups evaluated per loop iteration (one hit test per G groups); n_groups % 4 == 0.
+// NW = waves per workgroup.  Every wave streams the SAME db words through the scalar cache; waves of
+// one workgroup are kept within SYNC groups of each other by a barrier so that one wave's scalar-cache
+// miss serves the others (a lone wave's scalar loads are latency-bound: ~2k cycles per miss).
+constexpr int BS_SYNC = 32;
+template <int L, bool NEAREST, int G, int NW>
+__global__ __launch_bounds__(WAVE * NW) void k_hamming_knn_bs(const uint32_t* __restrict__ V, int n_db,
+                                                              int n_groups, const uint2* __restrict__ q,
+                                                              int64_t n_q, int k, int chunks_per_wave,
+                                                              int32_t* __restrict__ ids,
+                                                              int32_t* __restrict__ dists,
+                                                              int32_t* __restrict__ counts) {
+    extern __shared__ __align__(16) uint32_t list[];    // [NW][k][64]
     constexpr int W = vert_stride(L);
-    const int lane = threadIdx.x;
-    const int64_t qi = (int64_t)blockIdx.x * WAVE + lane;
-    const bool valid = qi < n_q;
-    const uint2 qv = valid ? q[qi] : make_uint2(0u, 0u);
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = threadIdx.x / WAVE;
+    uint32_t* lp = list + wave * k * WAVE + lane;
+    const int64_t wave_global = (int64_t)blockIdx.x * NW + wave;
 
-    uint32_t QL[L], QH[L];
-#pragma unroll
-    for (int p = 0; p < L; ++p) {
-        QL[p] = 0u - ((qv.x >> p) & 1u);
-        QH[p] = 0u - ((qv.y >> p) & 1u);
-    }
-    int thr = valid ? 31 : 0;      // counts are <= 27 < 31: "31" accepts everything until the list is full
-    int cnt = 0;
-    uint32_t T[5];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) T[i] = 0u - (((uint32_t)thr >> i) & 1u);
-    uint32_t* lp = list + lane;
+    // a wave owns `chunks_per_wave` consecutive 64-query chunks: the host sizes the grid so that all
+    // waves are resident at once and every SIMD gets the same number of chunks (no half-empty tail)
+    for (int ch = 0; ch < chunks_per_wave; ++ch) {
+        // (no early exit: every wave of the workgroup must reach every barrier)
+        const int64_t qi = (wave_global * chunks_per_wave + ch) * WAVE + lane;
+        const bool valid = qi < n_q;
+        const uint2 qv = valid ? q[qi] : make_uint2(0u, 0u);
 
-    for (int g = 0; g < n_groups; g += G) {
-        const uint32_t* __restrict__ vg = V + (size_t)g * W;     // wave-uniform -> scalar loads
-        uint32_t c[G][5], lt[G];
-        uint32_t any = 0u;
+        uint32_t QL[L], QH[L];
 #pragma unroll
-        for (int u = 0; u < G; ++u) {
-            lt[u] = eval_group<L>(vg + u * W, QL, QH, T, c[u]);
-            any |= lt[u];
+        for (int p = 0; p < L; ++p) {
+            QL[p] = 0u - ((qv.x >> p) & 1u);
+            QH[p] = 0u - ((qv.y >> p) & 1u);
         }
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(any != 0u) != 0ull, 0)) {
+        int thr = valid ? 31 : 0;   // counts are <= 27 < 31: "31" accepts everything until the list is full
+        int cnt = 0;
+        uint32_t T[5];
 #pragma unroll
-            for (int u = 0; u < G; ++u) {
-                // thresholds may have tightened since lt[u] was formed: take_hits re-tests d < thr
-                take_hits(lt[u], c[u], (g + u) * GROUP, n_db, lp, k, cnt, thr, T);
+        for (int i = 0; i < 5; ++i) T[i] = 0u - (((uint32_t)thr >> i) & 1u);
+
+        if constexpr (G == 3) {
+            // ping-pong software pipeline: while group g is evaluated the scalar loads of g+1 are in
+            // flight, and vice versa (n_groups is even)
+            GroupWords<L> A, B;
+            fetch_group<L>(A, V);
+            for (int g = 0; g < n_groups; g += 2) {
+                if constexpr (NW > 1) { if ((g & (BS_SYNC - 1)) == 0) __syncthreads(); }
+                uint32_t cA[5], cB[5];
+                fetch_group<L>(B, V + (size_t)(g + 1) * W);
+                uint32_t ltA = eval_words<L>(A, QL, QH, T, cA);
+                const int gn = g + 2 < n_groups ? g + 2 : g;         // last iteration refetches (unused)
+                fetch_group<L>(A, V + (size_t)gn * W);
+                uint32_t ltB = eval_words<L>(B, QL, QH, T, cB);
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64((ltA | ltB) != 0u) != 0ull, 0)) {
+                    take_hits(ltA, cA, g * GROUP, n_db, lp, k, cnt, thr, T);
+                    take_hits(ltB, cB, (g + 1) * GROUP, n_db, lp, k, cnt, thr, T);
+                }
+            }
+        } else
+        for (int g = 0; g < n_groups; g += (G == 4 ? 2 : G)) {
+            if constexpr (NW > 1) { if ((g & (BS_SYNC - 1)) == 0) __syncthreads(); }
+            // G == 4 is a timing-only ablation: every iteration re-reads groups 0..1 (scalar-cache hits)
+            const uint32_t* __restrict__ vg = V + (G == 4 ? (size_t)(g & 2) * W : (size_t)g * W);
+            constexpr int GG = (G == 4 ? 2 : G);
+            uint32_t c[GG][5], lt[GG];
+            uint32_t any = 0u;
+#pragma unroll
+            for (int u = 0; u < GG; ++u) {
+                lt[u] = eval_group<L>(vg + u * W, QL, QH, T, c[u]);
+                any |= lt[u];
+            }
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(any != 0u) != 0ull, 0)) {
+#pragma unroll
+                for (int u = 0; u < GG; ++u) {
+                    // thresholds may have tightened since lt[u] was formed: take_hits re-tests d < thr
+                    take_hits(lt[u], c[u], (g + u) * GROUP, n_db, lp, k, cnt, thr, T);
+                }
             }
         }
-    }
 
-    if (valid) {
-        if constexpr (NEAREST) {
-            dists[qi] = cnt > 0 ? (int32_t)(lp[0] >> ID_BITS) : -1;
-        } else {
-            counts[qi] = cnt;
-            for (int t = 0; t < k; ++t) {
-                bool ok = t < cnt;
-                uint32_t key = ok ? lp[t * WAVE] : 0u;
-                ids[qi * k + t] = ok ? (int32_t)(key & ID_MASK) : -1;
-                dists[qi * k + t] = ok ? (int32_t)(key >> ID_BITS) : -1;
+        if (valid) {
+            if constexpr (NEAREST) {
+                dists[qi] = cnt > 0 ? (int32_t)(lp[0] >> ID_BITS) : -1;
+            } else {
+                counts[qi] = cnt;
+                for (int t = 0; t < k; ++t) {
+                    bool ok = t < cnt;
+                    uint32_t key = ok ? lp[t * WAVE] : 0u;
+                    ids[qi * k + t] = ok ? (int32_t)(key & ID_MASK) : -1;
+                    dists[qi * k + t] = ok ? (int32_t)(key >> ID_BITS) : -1;
+                }
             }
         }
     }

@@ -51,6 +51,7 @@ struct gm_index {
     const char* last_kernel = "";
     int64_t last_pairs = 0;
     int variant = 0;
+    int n_simd = 1024;            // CUs x 4
 };
 
 namespace {
@@ -121,22 +122,53 @@ int launch_leven_knn(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* d
 
 constexpr int BS_GROUP_PAD = 4;   // n_groups is padded to a multiple of this (kernels take G | 4)
 
+template <int L, bool NEAREST, int G, int NW>
+int launch_bs_cfg(gm_index* idx, int64_t n_q, int k, int wps_cap, bool one_chunk, int32_t* ids, int32_t* dists,
+                  int32_t* counts, hipStream_t st) {
+    // Work split: one chunk = 64 queries, one wave takes c consecutive chunks.  All workgroups must be
+    // resident at once (otherwise the last, partly filled round runs at low occupancy for a whole wave
+    // lifetime), so c = ceil(chunks / resident wave slots).
+    auto kern = gm::k_hamming_knn_bs<L, NEAREST, G, NW>;
+    const int64_t chunks = (n_q + gm::WAVE - 1) / gm::WAVE;
+    size_t lds = sizeof(uint32_t) * (size_t)k * gm::WAVE * NW;
+    int per_cu = 0;     // resident workgroups per CU for this instantiation and list size
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern),
+                                                          gm::WAVE * NW, lds));
+    int wps = per_cu * NW / 4 > 0 ? per_cu * NW / 4 : 1;
+    if (wps_cap > 0 && wps_cap < wps) wps = wps_cap;
+    const int64_t slots = (int64_t)idx->n_simd * wps;
+    int64_t cpw = one_chunk ? 1 : (chunks + slots - 1) / slots;
+    const int64_t waves = (chunks + cpw - 1) / cpw;
+    const int64_t blocks = (waves + NW - 1) / NW;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(gm::WAVE * NW), lds, st, idx->d_vert, (int)idx->n_db,
+                       (int)idx->n_groups, idx->d_q, n_q, k, (int)cpw, ids, dists, counts);
+    HIP_TRY(hipGetLastError());
+    return GM_OK;
+}
+
 template <int L, bool NEAREST>
 int launch_bs(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* dists, int32_t* counts,
               hipStream_t st) {
-    int64_t blocks = (n_q + gm::WAVE - 1) / gm::WAVE;
-    size_t lds = sizeof(uint32_t) * (size_t)k * gm::WAVE;
-    if (L == 20 && idx->variant == 2) {   // A/B knob: one group per iteration
-        hipLaunchKernelGGL((gm::k_hamming_knn_bs<20, NEAREST, 1>), dim3((unsigned)blocks), dim3(gm::WAVE), lds,
-                           st, idx->d_vert, (int)idx->n_db, (int)idx->n_groups, idx->d_q, n_q, k, ids, dists,
-                           counts);
-    } else {
-        hipLaunchKernelGGL((gm::k_hamming_knn_bs<L, NEAREST, 2>), dim3((unsigned)blocks), dim3(gm::WAVE), lds,
-                           st, idx->d_vert, (int)idx->n_db, (int)idx->n_groups, idx->d_q, n_q, k, ids, dists,
-                           counts);
+    const int v = idx->variant;
+    if (L == 20) {   // A/B knobs (experiments): 2x = one chunk per wave, 3x = balanced chunks; x = config
+        switch (v) {
+            case 20: return launch_bs_cfg<20, NEAREST, 2, 1>(idx, n_q, k, 0, true, ids, dists, counts, st);
+            case 21: return launch_bs_cfg<20, NEAREST, 1, 1>(idx, n_q, k, 0, true, ids, dists, counts, st);
+            case 22: return launch_bs_cfg<20, NEAREST, 3, 1>(idx, n_q, k, 0, true, ids, dists, counts, st);
+            case 23: return launch_bs_cfg<20, NEAREST, 2, 4>(idx, n_q, k, 0, true, ids, dists, counts, st);
+            case 24: return launch_bs_cfg<20, NEAREST, 2, 8>(idx, n_q, k, 0, true, ids, dists, counts, st);
+            case 25: return launch_bs_cfg<20, NEAREST, 1, 8>(idx, n_q, k, 0, true, ids, dists, counts, st);
+            case 26: return launch_bs_cfg<20, NEAREST, 2, 16>(idx, n_q, k, 0, true, ids, dists, counts, st);
+            case 27: return launch_bs_cfg<20, NEAREST, 4, 1>(idx, n_q, k, 0, true, ids, dists, counts, st);
+            case 30: return launch_bs_cfg<20, NEAREST, 2, 1>(idx, n_q, k, 0, false, ids, dists, counts, st);
+            case 33: return launch_bs_cfg<20, NEAREST, 2, 4>(idx, n_q, k, 0, false, ids, dists, counts, st);
+            case 34: return launch_bs_cfg<20, NEAREST, 2, 8>(idx, n_q, k, 0, false, ids, dists, counts, st);
+            case 35: return launch_bs_cfg<20, NEAREST, 1, 8>(idx, n_q, k, 0, false, ids, dists, counts, st);
+            case 36: return launch_bs_cfg<20, NEAREST, 2, 16>(idx, n_q, k, 0, false, ids, dists, counts, st);
+            default: break;
+        }
     }
-    HIP_TRY(hipGetLastError());
-    return GM_OK;
+    return launch_bs_cfg<L, NEAREST, 2, 1>(idx, n_q, k, 0, true, ids, dists, counts, st);
 }
 
 template <bool NEAREST>
@@ -252,6 +284,11 @@ int gm_index_create_dev(const void* d_packed, int64_t n_db, int guidelen, int me
     idx->metric = metric;
     idx->n_db = n_db;
     idx->n_db_pad = n_db > 0 ? round_up(n_db, gm::TILE) : 0;
+    {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        idx->n_simd = prop.multiProcessorCount * 4;
+    }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (n_db > 0) {
         if (hipMalloc(&idx->d_db, sizeof(uint2) * idx->n_db_pad) != hipSuccess) {
