@@ -97,15 +97,23 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d"
                              % (args.gpus, args.gpus))
     import torch.distributed as dist
-    from guidemaker_amd import _lib, workloads
+    from guidemaker_amd import _lib, distributed, workloads
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libgmhip has no CPU fallback")
+    # GM_BENCH_BACKEND=gloo rehearses the multi-process plumbing with every rank on GPU 0 (a one-GPU
+    # box cannot host two RCCL ranks); the driver's runs use the default, nccl = RCCL over xGMI
+    backend = os.environ.get("GM_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     pool = workloads.make_pool(args.workload)
     L, k = pool["guidelen"], pool["k"]
@@ -132,19 +140,17 @@ def main():
     ids = torch.empty((n_q, k), dtype=torch.int32, device=dev)
     dists = torch.empty((n_q, k), dtype=torch.int32, device=dev)
     counts = torch.empty((n_q,), dtype=torch.int32, device=dev)
-    if world > 1:
-        g_ids = torch.empty((world * n_q, k), dtype=torch.int32, device=dev)
-        g_dists = torch.empty((world * n_q, k), dtype=torch.int32, device=dev)
-        g_counts = torch.empty((world * n_q,), dtype=torch.int32, device=dev)
+    gathered = [None, None, None]
     stream = torch.cuda.current_stream().cuda_stream
     idx = _lib.Index.from_device(d_db.data_ptr(), n_db, L, metric_code, local_rank, stream)
 
     def step():
         idx.knn_dev(d_q.data_ptr(), n_q, k, ids.data_ptr(), dists.data_ptr(), counts.data_ptr(), stream)
         if world > 1:   # the one exchange of the path: per-shard neighbour lists over RCCL/xGMI
-            dist.all_gather_into_tensor(g_ids, ids)
-            dist.all_gather_into_tensor(g_dists, dists)
-            dist.all_gather_into_tensor(g_counts, counts)
+            if backend == "nccl":
+                gathered[:] = distributed.all_gather_neighbors(ids, dists, counts, world * n_q)
+            else:
+                gathered[:] = distributed.all_gather_neighbors(ids.cpu(), dists.cpu(), counts.cpu(), world * n_q)
 
     for _ in range(args.warmup):
         step()
@@ -162,7 +168,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms = idx.timing_read()

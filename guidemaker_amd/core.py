@@ -293,7 +293,12 @@ class TargetProcessor:
         _ = config['NMSLIB']['ef']
         unique_targets = self._query_targets()
         qpacked = _lib.pack(unique_targets, self._guidelen)
-        ids, dists, counts = self.nmslib_index.knn(qpacked, self.knum)
+        from . import distributed
+        if distributed.is_distributed():
+            # one process per GPU: scan this rank's shard of the candidates, one all-gather of the lists
+            ids, dists, counts = distributed.sharded_knn(self.nmslib_index.knn, qpacked, self.knum)
+        else:
+            ids, dists, counts = self.nmslib_index.knn(qpacked, self.knum)
         self.last_knn = (ids, dists, counts)
         if len(unique_targets) and (self.knum < 2 or int(counts.min()) < 2):
             raise IndexError("list index out of range")      # editdist[1] in the reference (core.py:512)

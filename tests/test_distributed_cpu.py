@@ -1,0 +1,74 @@
+"""World-size-2 tests of the multi-GPU decomposition on CPU (gloo).  The per-rank scan is replaced by
+the oracle (no GPU here); what is under test is the sharding, padding, the single all-gather per
+tensor, and that the gathered result equals the unsharded one (shard-count invariance)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import random_pool
+
+from guidemaker_amd import _lib, distributed
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_q, k, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as orc
+        L = 20
+        db = list(dict.fromkeys(random_pool(700, L, seed=3)))
+        q = (db + random_pool(400, L, seed=4))[:n_q]
+        assert len(q) == n_q
+        calls = []
+
+        def local_knn(q_shard, kk):     # stand-in for Index.knn on this rank's GPU
+            calls.append(len(q_shard))
+            ids, dists, counts = orc.knn(db, _lib.unpack(q_shard, L), L, "hamming", kk)
+            return ids, np.where(dists >= 0, dists // 2, -1), counts
+
+        assert distributed.is_distributed()
+        got = distributed.sharded_knn(local_knn, _lib.pack(q, L), k)
+        lo, hi, per = distributed.shard_range(n_q, world, rank)
+        assert calls == ([hi - lo] if hi > lo else [])
+        want = local_knn(_lib.pack(q, L), k) if n_q else (np.empty((0, k), np.int32),) * 2 + (np.empty(0, np.int32),)
+        for g, w in zip(got, want):
+            assert g.shape == w.shape and (g == w).all()
+        np.save(os.path.join(out_dir, "ok_%d.npy" % rank), np.array([1]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_q,k", [(1000, 10), (777, 3), (1, 2), (0, 2)])
+def test_sharded_knn_world2(tmp_path, n_q, k):
+    from oracle import oracle as orc
+    orc.build()
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), n_q, k, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / ("ok_%d.npy" % r)) for r in range(world))
+
+
+def test_shard_range_covers_everything():
+    for n in (0, 1, 7, 8, 9, 1000, 1001):
+        for world in (1, 2, 4, 8):
+            spans = [distributed.shard_range(n, world, r) for r in range(world)]
+            per = spans[0][2]
+            assert all(s[2] == per for s in spans) and per * world >= n
+            covered = [i for lo, hi, _ in spans for i in range(lo, hi)]
+            assert covered == list(range(n))
+            assert all(hi - lo <= per for lo, hi, _ in spans)
+
+
+def test_not_distributed_by_default():
+    assert not distributed.is_distributed()
