@@ -33,10 +33,11 @@ B_ALG = {"hamming": 16, "leven": 16}     # algorithmic bytes per guide pair: two
 VALU_LANE_OPS_PER_S = 256 * 128 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz
 
 
-def bitslice_ops_per_pair(L):
-    """VALU ops per guide pair of the bit-sliced Hamming kernel (gm_bitslice.hip.h): per group of 32
-    db entries 2L ops for the mismatch words, 2 per full/half adder of the carry-save tree, 5 for the
-    threshold comparator, 1 v_cmp."""
+def lookup_ops_per_pair(L):
+    """VALU ops per guide pair of the look-up Hamming kernel K1L (gm_lookup.hip.h): per group of 64
+    pool targets and per half (32 targets) 2 ops per full/half adder of the carry-save tree over the L
+    match words + 5 for the threshold comparator, plus 1 v_cmp per group.  The match words themselves
+    come from LDS (L ds_read_b64 per group), not from the VALU."""
     def col(n):          # (ops, carries) to reduce n same-weight words to one
         if n <= 1:
             return 0, 0
@@ -49,7 +50,7 @@ def bitslice_ops_per_pair(L):
     while n > 0:
         o, n = col(n)
         ops += o
-    return (2 * L + ops + 5 + 1) / 32.0
+    return (2 * (ops + 5) + 1) / 64.0
 
 
 def parse():
@@ -202,12 +203,14 @@ def main():
                         "VALU-bound, not HBM-bound, so frac > 1 means LDS/register reuse beats the "
                         "streaming model (SURVEY.md 8d)"}
         if pool["metric"] == "hamming" and 10 <= L <= 27:
-            opp = bitslice_ops_per_pair(L)
+            opp = lookup_ops_per_pair(L)
             ops = launch_pairs * opp / kern_s
             roof["valu"] = {"achieved": ops / 1e12, "peak": VALU_LANE_OPS_PER_S / 1e12,
                             "unit": "T lane-ops/s", "frac": ops / VALU_LANE_OPS_PER_S,
                             "ops_per_pair": opp,
-                            "note": "the binding roof: int32 VALU issue, 256 CUs x 128 lanes/clk x 2.4 GHz"}
+                            "lds_reads_per_pair": L / 64.0,
+                            "note": "the binding roofs: int32 VALU issue (256 CUs x 128 lanes/clk x 2.4 GHz) "
+                                    "and LDS read issue (L ds_read_b64 per 64 pairs per lane)"}
         out = {
             "metric": "guide-pair distance comparisons/sec (whole node)",
             "value": value, "unit": "guide-pair comparisons/s", "n_gpus": world, "steps": args.steps,

@@ -1,0 +1,218 @@
+// gm_lookup.hip.h -- bit-sliced Hamming k-NN with per-lane LDS table look-ups (K1L) for gfx950.
+//
+// Measured on MI355X (tools/valu_pattern.hip): a VALU op with an SGPR source issues at half rate, so
+// in K1v (gm_bitslice.hip.h) the 2L ops that form the mismatch words from scalar-loaded pool words
+// cost as much as the whole adder tree.  K1L removes them: the pool is stored ONE-HOT and bit-sliced,
+//
+//   table[G][p][b][h]  (uint32)   G = group of 64 pool ids, p = base position, b = base code A0 C1 G2 T3,
+//                                 h = half (ids 64G+32h .. +31); bit j set <=> that target has base b at p
+//
+// a wave stages tiles of TG groups into its private LDS buffer (coalesced 16-byte loads, double
+// buffered), and every lane (= one candidate) fetches, for position p, the 8 bytes at
+// [p][its own base at p][0..1] with ONE ds_read_b64 -- the MATCH flags of 64 targets, no VALU op.
+// Lanes read only 4 distinct addresses per instruction (8 banks): conflict-free, 256 B/clk.
+// Then per half: carry-save adder tree over the L match words -> bit-sliced match count, ripple
+// comparator `matches >= L + 1 - thr` (<=> distance < thr) -> hit word; same slow path / k-lists as K1v.
+// Per 64 pairs per lane: 20 ds_read_b64 + 2 x (36 + 5) v_bitop3 + 1 v_cmp at L=20 (1.3 VALU ops/pair).
+#pragma once
+#include "gm_bitslice.hip.h"
+
+namespace gm {
+
+constexpr int LK_GROUP = 64;   // pool ids per table group
+constexpr int LK_TG = 4;       // groups per LDS tile
+__host__ __device__ constexpr int lk_group_words(int L) { return 8 * L; }           // [L][4][2]
+__host__ __device__ constexpr int lk_tile_bytes(int L) { return LK_TG * 32 * L; }
+
+constexpr int TT_A_OR_NOTB = 0xF3;   // a | ~b                      (c ignored)
+constexpr int TT_GE = 0xB2;          // (a & ~b) | (~(a ^ b) & c)   a = count bit, b = bound bit, c = ge so far
+static_assert(((0xF0 | ~0xCC) & 0xFF) == TT_A_OR_NOTB, "a | ~b");
+static_assert((((0xF0 & ~0xCC) | (~(0xF0 ^ 0xCC) & 0xAA)) & 0xFF) == TT_GE, "ge stage");
+
+// planes -> one-hot bit-sliced table.  One thread per output word; ids past n_db replicate the last.
+__global__ void k_to_onehot(const uint2* __restrict__ planes, int64_t n_db, uint32_t* __restrict__ table,
+                            int64_t n_groups, int L) {
+    const int gw = lk_group_words(L);
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_groups * gw) return;
+    int64_t G = t / gw;
+    int w = (int)(t % gw);
+    int p = w >> 3, b = (w >> 1) & 3, h = w & 1;
+    uint32_t out = 0;
+    for (int j = 0; j < 32; ++j) {
+        int64_t id = G * LK_GROUP + 32 * h + j;
+        if (id >= n_db) id = n_db - 1;
+        uint2 e = planes[id];
+        uint32_t code = ((e.x >> p) & 1u) | (((e.y >> p) & 1u) << 1);
+        out |= (uint32_t)(code == (uint32_t)b) << j;
+    }
+    table[t] = out;
+}
+
+// hit word of one half group: bit j set <=> matches(j) >= bound  (bound bits broadcast in Tb)
+template <int L>
+__device__ __forceinline__ uint32_t lk_eval_half(const uint32_t (&m)[L], const uint32_t (&Tb)[5],
+                                                 uint32_t (&c)[5]) {
+    bitslice_count<L>(m, c);
+    uint32_t ge = GM_BITOP3(c[0], Tb[0], Tb[0], TT_A_OR_NOTB);
+#pragma unroll
+    for (int i = 1; i < 5; ++i) ge = GM_BITOP3(c[i], Tb[i], ge, TT_GE);
+    return ge;
+}
+
+template <int L>
+__device__ __forceinline__ void lk_take_hits(uint32_t hits, const uint32_t (&c)[5], int id0, int n_db,
+                                             uint32_t* lp, int k, int& cnt, int& thr, uint32_t (&Tb)[5]) {
+    while (hits != 0u) {
+        int j = __builtin_ctz(hits);
+        hits &= hits - 1u;
+        int matches = (int)(((c[0] >> j) & 1u) | (((c[1] >> j) & 1u) << 1) | (((c[2] >> j) & 1u) << 2) |
+                            (((c[3] >> j) & 1u) << 3) | (((c[4] >> j) & 1u) << 4));
+        int d = L - matches;
+        int id = id0 + j;
+        if (d < thr && id < n_db) {
+            list_insert(lp, WAVE, k, cnt, ((uint32_t)d << ID_BITS) | (uint32_t)id);
+            if (cnt == k) {
+                thr = (int)(lp[(k - 1) * WAVE] >> ID_BITS);
+                const uint32_t bound = (uint32_t)(L + 1 - thr);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) Tb[i] = 0u - ((bound >> i) & 1u);
+            }
+        }
+    }
+}
+
+// stage one tile with the LDS-DMA path (global_load_lds_dwordx4: 16 B per lane straight into LDS, no
+// VGPR staging): round r copies units [64r, 64r+64) of 16 bytes; completion is tracked by vmcnt
+template <int L>
+__device__ __forceinline__ void lk_stage(const uint32_t* __restrict__ table, int64_t tile, uint32_t* dst,
+                                         int lane) {
+    constexpr int UNITS = lk_tile_bytes(L) / 16;
+    constexpr int ROUNDS = (UNITS + WAVE - 1) / WAVE;
+    const uint32_t* src = table + tile * (lk_tile_bytes(L) / 4);
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int u = r * WAVE + lane;
+        if (u < UNITS) __builtin_amdgcn_global_load_lds(src + u * 4, dst + r * WAVE * 4, 16, 0, 0);
+    }
+}
+__device__ __forceinline__ void lk_stage_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// the 2L match words of one 64-target group, as fetched by this lane
+template <int L>
+struct LkGroupRegs {
+    uint32_t m0[L], m1[L];
+};
+template <int L>
+__device__ __forceinline__ void lk_read_group(LkGroupRegs<L>& r, const uint32_t* gb, const int (&off)[L]) {
+#pragma unroll
+    for (int p = 0; p < L; ++p) {
+        uint2 w = *reinterpret_cast<const uint2*>(gb + off[p]);    // ds_read_b64, per-lane address
+        r.m0[p] = w.x;
+        r.m1[p] = w.y;
+    }
+}
+template <int L>
+__device__ __forceinline__ void lk_process_group(const LkGroupRegs<L>& r, int id0, int n_db, uint32_t* lp, int k,
+                                                 int& cnt, int& thr, uint32_t (&Tb)[5]) {
+    uint32_t c0[5], c1[5];
+    uint32_t h0 = lk_eval_half<L>(r.m0, Tb, c0);
+    uint32_t h1 = lk_eval_half<L>(r.m1, Tb, c1);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64((h0 | h1) != 0u) != 0ull, 0)) {
+        lk_take_hits<L>(h0, c0, id0, n_db, lp, k, cnt, thr, Tb);
+        lk_take_hits<L>(h1, c1, id0 + 32, n_db, lp, k, cnt, thr, Tb);
+    }
+}
+
+// K1L.  grid = ceil(n_q / 64) single-wave workgroups.  Dynamic LDS: 2 tiles + k * 64 * 4 B lists.
+// PIPE: software-pipelined -- the ds_reads of group g+1 are issued before group g is evaluated, so a
+// wave overlaps its own LDS and VALU phases (otherwise the waves of a CU fall into lockstep:
+// everybody reads, then everybody computes, and the two pipes are used in turn, not in parallel).
+template <int L, bool NEAREST, bool PIPE>
+__global__ __launch_bounds__(WAVE) void k_hamming_knn_lk(const uint32_t* __restrict__ table, int n_db,
+                                                         int n_tiles, const uint2* __restrict__ q, int64_t n_q,
+                                                         int k, int32_t* __restrict__ ids,
+                                                         int32_t* __restrict__ dists,
+                                                         int32_t* __restrict__ counts) {
+    extern __shared__ __align__(16) uint32_t smem[];
+    constexpr int TILE_W = lk_tile_bytes(L) / 4;         // words per tile
+    constexpr int GW = lk_group_words(L);
+    uint32_t* tiles = smem;                              // [2][TILE_W]
+    uint32_t* list = smem + 2 * TILE_W;                  // [k][64]
+    const int lane = threadIdx.x;
+    uint32_t* lp = list + lane;
+
+    const int64_t qi = (int64_t)blockIdx.x * WAVE + lane;
+    const bool valid = qi < n_q;
+    const uint2 qv = valid ? q[qi] : make_uint2(0u, 0u);
+
+    // word offset of this lane's (position, base) pair inside a group block
+    int off[L];
+#pragma unroll
+    for (int p = 0; p < L; ++p) {
+        uint32_t code = ((qv.x >> p) & 1u) | (((qv.y >> p) & 1u) << 1);
+        off[p] = p * 8 + (int)code * 2;
+    }
+    int thr = valid ? L + 1 : 0;       // L + 1 accepts every distance until the list is full
+    int cnt = 0;
+    uint32_t Tb[5];
+    {
+        const uint32_t bound = (uint32_t)(L + 1 - thr);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) Tb[i] = 0u - ((bound >> i) & 1u);
+    }
+
+    // single-wave workgroup: LDS operations of one wave execute in issue order, no barrier needed;
+    // tile t+1 is DMA'd into the other buffer while tile t is evaluated
+    lk_stage<L>(table, 0, tiles, lane);
+
+    if constexpr (PIPE) {
+        static_assert(LK_TG == 4, "pipeline below is written for 4 groups per tile");
+        LkGroupRegs<L> A, B;
+        lk_stage_wait();
+        lk_read_group<L>(A, tiles, off);
+        for (int t = 0; t < n_tiles; ++t) {
+            const uint32_t* cur = tiles + (t & 1) * TILE_W;
+            uint32_t* nxt = tiles + ((t + 1) & 1) * TILE_W;
+            const int id0 = t * LK_TG * LK_GROUP;
+            lk_stage<L>(table, t + 1 < n_tiles ? t + 1 : t, nxt, lane);   // clamped: last iteration restages
+            lk_read_group<L>(B, cur + 1 * GW, off);
+            lk_process_group<L>(A, id0, n_db, lp, k, cnt, thr, Tb);
+            lk_read_group<L>(A, cur + 2 * GW, off);
+            lk_process_group<L>(B, id0 + LK_GROUP, n_db, lp, k, cnt, thr, Tb);
+            lk_read_group<L>(B, cur + 3 * GW, off);
+            lk_process_group<L>(A, id0 + 2 * LK_GROUP, n_db, lp, k, cnt, thr, Tb);
+            lk_stage_wait();
+            lk_read_group<L>(A, nxt, off);                                 // first group of the next tile
+            lk_process_group<L>(B, id0 + 3 * LK_GROUP, n_db, lp, k, cnt, thr, Tb);
+        }
+    } else {
+        for (int t = 0; t < n_tiles; ++t) {
+            const uint32_t* cur = tiles + (t & 1) * TILE_W;
+            lk_stage_wait();                                               // tile t has landed
+            if (t + 1 < n_tiles) lk_stage<L>(table, t + 1, tiles + ((t + 1) & 1) * TILE_W, lane);
+#pragma unroll
+            for (int gl = 0; gl < LK_TG; ++gl) {
+                LkGroupRegs<L> r;
+                lk_read_group<L>(r, cur + gl * GW, off);
+                lk_process_group<L>(r, (t * LK_TG + gl) * LK_GROUP, n_db, lp, k, cnt, thr, Tb);
+            }
+        }
+    }
+
+    if (valid) {
+        if constexpr (NEAREST) {
+            dists[qi] = cnt > 0 ? (int32_t)(lp[0] >> ID_BITS) : -1;
+        } else {
+            counts[qi] = cnt;
+            for (int s = 0; s < k; ++s) {
+                bool ok = s < cnt;
+                uint32_t key = ok ? lp[s * WAVE] : 0u;
+                ids[qi * k + s] = ok ? (int32_t)(key & ID_MASK) : -1;
+                dists[qi * k + s] = ok ? (int32_t)(key >> ID_BITS) : -1;
+            }
+        }
+    }
+}
+
+}  // namespace gm

@@ -2,6 +2,7 @@
 // Host side of libgmhip.so: handle management, HBM workspaces, launches, HIP-event timing.
 #include "gm_kernels.hip.h"
 #include "gm_bitslice.hip.h"
+#include "gm_lookup.hip.h"
 
 #include <string>
 #include <vector>
@@ -38,6 +39,8 @@ struct gm_index {
     int64_t n_db_pad = 0;
     uint2* d_db = nullptr;        // bit planes, padded to a multiple of gm::TILE
     uint32_t* d_vert = nullptr;   // bit-sliced groups of 32 entries (Hamming, 10 <= L <= 27)
+    uint32_t* d_onehot = nullptr; // one-hot bit-sliced table, groups of 64 entries (K1L)
+    int64_t n_lk_tiles = 0;
     int64_t n_groups = 0;
     // workspaces (grow-only), so repeated queries do not allocate
     uint2* d_q = nullptr;
@@ -184,8 +187,44 @@ int launch_bs_by_len(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* d
     }
 }
 
+template <int L, bool NEAREST>
+int launch_lk(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* dists, int32_t* counts,
+              hipStream_t st) {
+    const int64_t blocks = (n_q + gm::WAVE - 1) / gm::WAVE;
+    size_t lds = 2 * (size_t)gm::lk_tile_bytes(L) + sizeof(uint32_t) * (size_t)k * gm::WAVE;
+    if (L == 20 && idx->variant == 6) {   // A/B knob: group-level software pipelining (more VGPRs, occupancy 3)
+        hipLaunchKernelGGL((gm::k_hamming_knn_lk<20, NEAREST, true>), dim3((unsigned)blocks), dim3(gm::WAVE), lds,
+                           st, idx->d_onehot, (int)idx->n_db, (int)idx->n_lk_tiles, idx->d_q, n_q, k, ids, dists,
+                           counts);
+    } else {
+        hipLaunchKernelGGL((gm::k_hamming_knn_lk<L, NEAREST, false>), dim3((unsigned)blocks), dim3(gm::WAVE), lds,
+                           st, idx->d_onehot, (int)idx->n_db, (int)idx->n_lk_tiles, idx->d_q, n_q, k, ids, dists,
+                           counts);
+    }
+    HIP_TRY(hipGetLastError());
+    return GM_OK;
+}
+
+template <bool NEAREST>
+int launch_lk_by_len(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* dists, int32_t* counts,
+                     hipStream_t st) {
+    switch (idx->L) {
+#define GM_CASE(LEN) case LEN: return launch_lk<LEN, NEAREST>(idx, n_q, k, ids, dists, counts, st);
+        GM_CASE(10) GM_CASE(11) GM_CASE(12) GM_CASE(13) GM_CASE(14) GM_CASE(15) GM_CASE(16) GM_CASE(17)
+        GM_CASE(18) GM_CASE(19) GM_CASE(20) GM_CASE(21) GM_CASE(22) GM_CASE(23) GM_CASE(24) GM_CASE(25)
+        GM_CASE(26) GM_CASE(27)
+#undef GM_CASE
+        default: return fail(GM_ERR_ARG, "look-up kernel: guidelen out of range");
+    }
+}
+
+// variant 0 = default (K1L look-up kernel), 1 = popcount kernel K1, 5 and 2x/3x = K1v knobs
+bool use_lookup(const gm_index* idx) {
+    return idx->metric == GM_METRIC_HAMMING && idx->d_onehot != nullptr && (idx->variant == 0 || idx->variant == 6);
+}
+
 bool use_bitslice(const gm_index* idx) {
-    return idx->metric == GM_METRIC_HAMMING && idx->d_vert != nullptr && idx->variant != 1;
+    return idx->metric == GM_METRIC_HAMMING && idx->d_vert != nullptr && idx->variant != 1 && !use_lookup(idx);
 }
 
 int timing_begin(gm_index* idx, hipStream_t st) {
@@ -314,6 +353,20 @@ int gm_index_create_dev(const void* d_packed, int64_t n_db, int guidelen, int me
                 gm_index_free(idx);
                 return fail(GM_ERR_DEVICE, "k_to_vertical launch failed");
             }
+            // one-hot table for the look-up kernel
+            const int64_t lk_groups = round_up((n_db + gm::LK_GROUP - 1) / gm::LK_GROUP, gm::LK_TG);
+            idx->n_lk_tiles = lk_groups / gm::LK_TG;
+            const int64_t lk_words = lk_groups * gm::lk_group_words(guidelen);
+            if (hipMalloc(&idx->d_onehot, sizeof(uint32_t) * lk_words) != hipSuccess) {
+                gm_index_free(idx);
+                return fail(GM_ERR_ALLOC, "hipMalloc(db one-hot table) failed");
+            }
+            hipLaunchKernelGGL(gm::k_to_onehot, dim3((unsigned)((lk_words + 255) / 256)), dim3(256), 0, st,
+                               idx->d_db, n_db, idx->d_onehot, lk_groups, guidelen);
+            if (hipGetLastError() != hipSuccess) {
+                gm_index_free(idx);
+                return fail(GM_ERR_DEVICE, "k_to_onehot launch failed");
+            }
         }
     }
     if (hipEventCreate(&idx->ev0) != hipSuccess || hipEventCreate(&idx->ev1) != hipSuccess) {
@@ -360,6 +413,7 @@ void gm_index_free(gm_index* idx) {
     (void)hipSetDevice(idx->device);
     if (idx->d_db) (void)hipFree(idx->d_db);
     if (idx->d_vert) (void)hipFree(idx->d_vert);
+    if (idx->d_onehot) (void)hipFree(idx->d_onehot);
     if (idx->d_q) (void)hipFree(idx->d_q);
     if (idx->d_stage) (void)hipFree(idx->d_stage);
     timing_clear(idx);
@@ -402,7 +456,10 @@ int gm_knn_query_dev(gm_index* idx, const void* d_q, int64_t n_q, int k, void* d
     rc = timing_begin(idx, st);
     if (rc) return rc;
     const int R = pick_r(k);
-    if (use_bitslice(idx)) {
+    if (use_lookup(idx)) {
+        idx->last_kernel = "k_hamming_knn_lk";
+        rc = launch_lk_by_len<false>(idx, n_q, k, ids, dists, counts, st);
+    } else if (use_bitslice(idx)) {
         idx->last_kernel = "k_hamming_knn_bs";
         rc = launch_bs_by_len<false>(idx, n_q, k, ids, dists, counts, st);
     } else if (idx->metric == GM_METRIC_HAMMING) {
@@ -461,7 +518,11 @@ int gm_nearest_dist_dev(gm_index* idx, const void* d_q, int64_t n_q, void* d_d1,
     int n_tiles = (int)(idx->n_db_pad / gm::TILE);
     rc = timing_begin(idx, st);
     if (rc) return rc;
-    if (use_bitslice(idx)) {
+    if (use_lookup(idx)) {
+        idx->last_kernel = "k_hamming_knn_lk(nearest)";
+        rc = launch_lk_by_len<true>(idx, n_q, 1, nullptr, d1, nullptr, st);
+        if (rc) return rc;
+    } else if (use_bitslice(idx)) {
         idx->last_kernel = "k_hamming_knn_bs(nearest)";
         rc = launch_bs_by_len<true>(idx, n_q, 1, nullptr, d1, nullptr, st);
         if (rc) return rc;
