@@ -103,11 +103,13 @@ template <int L>
 struct LkGroupRegs {
     uint32_t m0[L], m1[L];
 };
-template <int L>
-__device__ __forceinline__ void lk_read_group(LkGroupRegs<L>& r, const uint32_t* gb, const int (&off)[L]) {
+// ptr[p] = this lane's LDS address of (position p, its base at p) in group 0 of buffer 0; WOFF = constant
+// word offset of the group to read (folds into the ds_read_b64 immediate offset field)
+template <int L, int WOFF>
+__device__ __forceinline__ void lk_read_group(LkGroupRegs<L>& r, const uint32_t* const (&ptr)[L]) {
 #pragma unroll
     for (int p = 0; p < L; ++p) {
-        uint2 w = *reinterpret_cast<const uint2*>(gb + off[p]);    // ds_read_b64, per-lane address
+        uint2 w = *reinterpret_cast<const uint2*>(ptr[p] + WOFF);    // ds_read_b64, per-lane address
         r.m0[p] = w.x;
         r.m1[p] = w.y;
     }
@@ -125,10 +127,7 @@ __device__ __forceinline__ void lk_process_group(const LkGroupRegs<L>& r, int id
 }
 
 // K1L.  grid = ceil(n_q / 64) single-wave workgroups.  Dynamic LDS: 2 tiles + k * 64 * 4 B lists.
-// PIPE: software-pipelined -- the ds_reads of group g+1 are issued before group g is evaluated, so a
-// wave overlaps its own LDS and VALU phases (otherwise the waves of a CU fall into lockstep:
-// everybody reads, then everybody computes, and the two pipes are used in turn, not in parallel).
-template <int L, bool NEAREST, bool PIPE>
+template <int L, bool NEAREST>
 __global__ __launch_bounds__(WAVE) void k_hamming_knn_lk(const uint32_t* __restrict__ table, int n_db,
                                                          int n_tiles, const uint2* __restrict__ q, int64_t n_q,
                                                          int k, int32_t* __restrict__ ids,
@@ -146,12 +145,12 @@ __global__ __launch_bounds__(WAVE) void k_hamming_knn_lk(const uint32_t* __restr
     const bool valid = qi < n_q;
     const uint2 qv = valid ? q[qi] : make_uint2(0u, 0u);
 
-    // word offset of this lane's (position, base) pair inside a group block
-    int off[L];
+    // LDS address of this lane's (position, base) pair inside group 0 of buffer 0
+    const uint32_t* ptr[L];
 #pragma unroll
     for (int p = 0; p < L; ++p) {
         uint32_t code = ((qv.x >> p) & 1u) | (((qv.y >> p) & 1u) << 1);
-        off[p] = p * 8 + (int)code * 2;
+        ptr[p] = tiles + p * 8 + (int)code * 2;
     }
     int thr = valid ? L + 1 : 0;       // L + 1 accepts every distance until the list is full
     int cnt = 0;
@@ -163,40 +162,31 @@ __global__ __launch_bounds__(WAVE) void k_hamming_knn_lk(const uint32_t* __restr
     }
 
     // single-wave workgroup: LDS operations of one wave execute in issue order, no barrier needed;
-    // tile t+1 is DMA'd into the other buffer while tile t is evaluated
+    // tile t+1 is DMA'd into the other buffer while tile t is evaluated.  The tile loop is unrolled by
+    // two so that the buffer offset is a compile-time constant (n_tiles is even).
     lk_stage<L>(table, 0, tiles, lane);
-
-    if constexpr (PIPE) {
-        static_assert(LK_TG == 4, "pipeline below is written for 4 groups per tile");
-        LkGroupRegs<L> A, B;
-        lk_stage_wait();
-        lk_read_group<L>(A, tiles, off);
-        for (int t = 0; t < n_tiles; ++t) {
-            const uint32_t* cur = tiles + (t & 1) * TILE_W;
-            uint32_t* nxt = tiles + ((t + 1) & 1) * TILE_W;
-            const int id0 = t * LK_TG * LK_GROUP;
-            lk_stage<L>(table, t + 1 < n_tiles ? t + 1 : t, nxt, lane);   // clamped: last iteration restages
-            lk_read_group<L>(B, cur + 1 * GW, off);
-            lk_process_group<L>(A, id0, n_db, lp, k, cnt, thr, Tb);
-            lk_read_group<L>(A, cur + 2 * GW, off);
-            lk_process_group<L>(B, id0 + LK_GROUP, n_db, lp, k, cnt, thr, Tb);
-            lk_read_group<L>(B, cur + 3 * GW, off);
-            lk_process_group<L>(A, id0 + 2 * LK_GROUP, n_db, lp, k, cnt, thr, Tb);
-            lk_stage_wait();
-            lk_read_group<L>(A, nxt, off);                                 // first group of the next tile
-            lk_process_group<L>(B, id0 + 3 * LK_GROUP, n_db, lp, k, cnt, thr, Tb);
-        }
-    } else {
-        for (int t = 0; t < n_tiles; ++t) {
-            const uint32_t* cur = tiles + (t & 1) * TILE_W;
-            lk_stage_wait();                                               // tile t has landed
-            if (t + 1 < n_tiles) lk_stage<L>(table, t + 1, tiles + ((t + 1) & 1) * TILE_W, lane);
+    for (int t = 0; t < n_tiles; t += 2) {
+        lk_stage_wait();                                               // tile t has landed in buffer 0
+        lk_stage<L>(table, t + 1, tiles + TILE_W, lane);
 #pragma unroll
-            for (int gl = 0; gl < LK_TG; ++gl) {
-                LkGroupRegs<L> r;
-                lk_read_group<L>(r, cur + gl * GW, off);
-                lk_process_group<L>(r, (t * LK_TG + gl) * LK_GROUP, n_db, lp, k, cnt, thr, Tb);
-            }
+        for (int gl = 0; gl < LK_TG; ++gl) {
+            LkGroupRegs<L> r;
+            if (gl == 0) lk_read_group<L, 0 * GW>(r, ptr);
+            if (gl == 1) lk_read_group<L, 1 * GW>(r, ptr);
+            if (gl == 2) lk_read_group<L, 2 * GW>(r, ptr);
+            if (gl == 3) lk_read_group<L, 3 * GW>(r, ptr);
+            lk_process_group<L>(r, (t * LK_TG + gl) * LK_GROUP, n_db, lp, k, cnt, thr, Tb);
+        }
+        lk_stage_wait();                                               // tile t+1 has landed in buffer 1
+        if (t + 2 < n_tiles) lk_stage<L>(table, t + 2, tiles, lane);
+#pragma unroll
+        for (int gl = 0; gl < LK_TG; ++gl) {
+            LkGroupRegs<L> r;
+            if (gl == 0) lk_read_group<L, TILE_W + 0 * GW>(r, ptr);
+            if (gl == 1) lk_read_group<L, TILE_W + 1 * GW>(r, ptr);
+            if (gl == 2) lk_read_group<L, TILE_W + 2 * GW>(r, ptr);
+            if (gl == 3) lk_read_group<L, TILE_W + 3 * GW>(r, ptr);
+            lk_process_group<L>(r, ((t + 1) * LK_TG + gl) * LK_GROUP, n_db, lp, k, cnt, thr, Tb);
         }
     }
 

@@ -192,15 +192,8 @@ int launch_lk(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* dists, i
               hipStream_t st) {
     const int64_t blocks = (n_q + gm::WAVE - 1) / gm::WAVE;
     size_t lds = 2 * (size_t)gm::lk_tile_bytes(L) + sizeof(uint32_t) * (size_t)k * gm::WAVE;
-    if (L == 20 && idx->variant == 6) {   // A/B knob: group-level software pipelining (more VGPRs, occupancy 3)
-        hipLaunchKernelGGL((gm::k_hamming_knn_lk<20, NEAREST, true>), dim3((unsigned)blocks), dim3(gm::WAVE), lds,
-                           st, idx->d_onehot, (int)idx->n_db, (int)idx->n_lk_tiles, idx->d_q, n_q, k, ids, dists,
-                           counts);
-    } else {
-        hipLaunchKernelGGL((gm::k_hamming_knn_lk<L, NEAREST, false>), dim3((unsigned)blocks), dim3(gm::WAVE), lds,
-                           st, idx->d_onehot, (int)idx->n_db, (int)idx->n_lk_tiles, idx->d_q, n_q, k, ids, dists,
-                           counts);
-    }
+    hipLaunchKernelGGL((gm::k_hamming_knn_lk<L, NEAREST>), dim3((unsigned)blocks), dim3(gm::WAVE), lds, st,
+                       idx->d_onehot, (int)idx->n_db, (int)idx->n_lk_tiles, idx->d_q, n_q, k, ids, dists, counts);
     HIP_TRY(hipGetLastError());
     return GM_OK;
 }
@@ -220,7 +213,7 @@ int launch_lk_by_len(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* d
 
 // variant 0 = default (K1L look-up kernel), 1 = popcount kernel K1, 5 and 2x/3x = K1v knobs
 bool use_lookup(const gm_index* idx) {
-    return idx->metric == GM_METRIC_HAMMING && idx->d_onehot != nullptr && (idx->variant == 0 || idx->variant == 6);
+    return idx->metric == GM_METRIC_HAMMING && idx->d_onehot != nullptr && idx->variant == 0;
 }
 
 bool use_bitslice(const gm_index* idx) {
@@ -354,7 +347,7 @@ int gm_index_create_dev(const void* d_packed, int64_t n_db, int guidelen, int me
                 return fail(GM_ERR_DEVICE, "k_to_vertical launch failed");
             }
             // one-hot table for the look-up kernel
-            const int64_t lk_groups = round_up((n_db + gm::LK_GROUP - 1) / gm::LK_GROUP, gm::LK_TG);
+            const int64_t lk_groups = round_up((n_db + gm::LK_GROUP - 1) / gm::LK_GROUP, 2 * gm::LK_TG);   // even tile count
             idx->n_lk_tiles = lk_groups / gm::LK_TG;
             const int64_t lk_words = lk_groups * gm::lk_group_words(guidelen);
             if (hipMalloc(&idx->d_onehot, sizeof(uint32_t) * lk_words) != hipSuccess) {
