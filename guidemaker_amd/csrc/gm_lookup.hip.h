@@ -16,6 +16,7 @@
 // Per 64 pairs per lane: 20 ds_read_b64 + 2 x (36 + 5) v_bitop3 + 1 v_cmp at L=20 (1.3 VALU ops/pair).
 #pragma once
 #include "gm_bitslice.hip.h"
+#include <type_traits>
 
 namespace gm {
 
@@ -60,9 +61,96 @@ __device__ __forceinline__ uint32_t lk_eval_half(const uint32_t (&m)[L], const u
     return ge;
 }
 
-template <int L>
+// ---------------------------------------------------------------------------------------------
+// k-list policies.  Keys are (dist << 27 | id); smaller key = better neighbour.
+//   RegList<KCAP>: the list lives in KCAP VGPRs, always sorted; an insert is a min/max ripple of
+//     2*KCAP ops with no LDS round trips and no divergent loop.  Runtime k <= KCAP: the first KCAP-k
+//     slots hold the sentinel 0 (keys are stored +1, so 0 beats every real key and never moves).
+//   LdsList: sorted list in LDS (any k <= 64), see list_insert().
+// Both expose: threshold(L) (distance the next neighbour must beat; L+1 while the list is not full),
+// insert(key), and store().
+// ---------------------------------------------------------------------------------------------
+template <int KCAP>
+struct RegList {
+    static constexpr uint32_t EMPTY = 0xffffffffu;
+    uint32_t v[KCAP];
+    __device__ __forceinline__ void init(int k, uint32_t*, int) {
+#pragma unroll
+        for (int s = 0; s < KCAP; ++s) v[s] = s < KCAP - k ? 0u : EMPTY;
+    }
+    __device__ __forceinline__ int threshold(int L) const {
+        return v[KCAP - 1] == EMPTY ? L + 1 : (int)((v[KCAP - 1] - 1u) >> ID_BITS);
+    }
+    __device__ __forceinline__ void insert(uint32_t key) {
+        uint32_t x = key + 1u;
+#pragma unroll
+        for (int s = 0; s < KCAP; ++s) {
+            uint32_t lo = v[s] < x ? v[s] : x;
+            x = v[s] < x ? x : v[s];
+            v[s] = lo;
+        }
+    }
+    __device__ __forceinline__ void store(int k, int64_t qi, int32_t* __restrict__ ids,
+                                          int32_t* __restrict__ dists, int32_t* __restrict__ counts,
+                                          bool nearest) const {
+        if (nearest) {
+            dists[qi] = v[KCAP - 1] == EMPTY ? -1 : (int32_t)((v[KCAP - 1] - 1u) >> ID_BITS);
+            return;
+        }
+        int cnt = 0;
+#pragma unroll
+        for (int s = 0; s < KCAP; ++s) {
+            const int j = s - (KCAP - k);
+            if (j >= 0) {
+                const bool ok = v[s] != EMPTY;
+                const uint32_t key = v[s] - 1u;
+                ids[qi * k + j] = ok ? (int32_t)(key & ID_MASK) : -1;
+                dists[qi * k + j] = ok ? (int32_t)(key >> ID_BITS) : -1;
+                cnt += ok ? 1 : 0;
+            }
+        }
+        counts[qi] = cnt;
+    }
+};
+
+struct LdsList {
+    uint32_t* lp;
+    int k, cnt;
+    __device__ __forceinline__ void init(int k_, uint32_t* lists, int lane) {
+        lp = lists + lane;
+        k = k_;
+        cnt = 0;
+    }
+    __device__ __forceinline__ int threshold(int L) const {
+        return cnt == k ? (int)(lp[(k - 1) * WAVE] >> ID_BITS) : L + 1;
+    }
+    __device__ __forceinline__ void insert(uint32_t key) { list_insert(lp, WAVE, k, cnt, key); }
+    __device__ __forceinline__ void store(int, int64_t qi, int32_t* __restrict__ ids, int32_t* __restrict__ dists,
+                                          int32_t* __restrict__ counts, bool nearest) const {
+        if (nearest) {
+            dists[qi] = cnt > 0 ? (int32_t)(lp[0] >> ID_BITS) : -1;
+            return;
+        }
+        counts[qi] = cnt;
+        for (int s = 0; s < k; ++s) {
+            const bool ok = s < cnt;
+            const uint32_t key = ok ? lp[s * WAVE] : 0u;
+            ids[qi * k + s] = ok ? (int32_t)(key & ID_MASK) : -1;
+            dists[qi * k + s] = ok ? (int32_t)(key >> ID_BITS) : -1;
+        }
+    }
+};
+
+__device__ __forceinline__ void lk_set_bound(uint32_t (&Tb)[5], int L, int thr) {
+    const uint32_t bound = (uint32_t)(L + 1 - thr);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) Tb[i] = 0u - ((bound >> i) & 1u);
+}
+
+// slow path of one half group: walk this lane's hit bits in ascending id order
+template <int L, class List>
 __device__ __forceinline__ void lk_take_hits(uint32_t hits, const uint32_t (&c)[5], int id0, int n_db,
-                                             uint32_t* lp, int k, int& cnt, int& thr, uint32_t (&Tb)[5]) {
+                                             List& list, int& thr, uint32_t (&Tb)[5]) {
     while (hits != 0u) {
         int j = __builtin_ctz(hits);
         hits &= hits - 1u;
@@ -71,12 +159,11 @@ __device__ __forceinline__ void lk_take_hits(uint32_t hits, const uint32_t (&c)[
         int d = L - matches;
         int id = id0 + j;
         if (d < thr && id < n_db) {
-            list_insert(lp, WAVE, k, cnt, ((uint32_t)d << ID_BITS) | (uint32_t)id);
-            if (cnt == k) {
-                thr = (int)(lp[(k - 1) * WAVE] >> ID_BITS);
-                const uint32_t bound = (uint32_t)(L + 1 - thr);
-#pragma unroll
-                for (int i = 0; i < 5; ++i) Tb[i] = 0u - ((bound >> i) & 1u);
+            list.insert(((uint32_t)d << ID_BITS) | (uint32_t)id);
+            const int nt = list.threshold(L);
+            if (nt != thr) {
+                thr = nt;
+                lk_set_bound(Tb, L, thr);
             }
         }
     }
@@ -114,20 +201,22 @@ __device__ __forceinline__ void lk_read_group(LkGroupRegs<L>& r, const uint32_t*
         r.m1[p] = w.y;
     }
 }
-template <int L>
-__device__ __forceinline__ void lk_process_group(const LkGroupRegs<L>& r, int id0, int n_db, uint32_t* lp, int k,
-                                                 int& cnt, int& thr, uint32_t (&Tb)[5]) {
+template <int L, class List>
+__device__ __forceinline__ void lk_process_group(const LkGroupRegs<L>& r, int id0, int n_db, List& list, int& thr,
+                                                 uint32_t (&Tb)[5]) {
     uint32_t c0[5], c1[5];
     uint32_t h0 = lk_eval_half<L>(r.m0, Tb, c0);
     uint32_t h1 = lk_eval_half<L>(r.m1, Tb, c1);
     if (__builtin_expect(__builtin_amdgcn_ballot_w64((h0 | h1) != 0u) != 0ull, 0)) {
-        lk_take_hits<L>(h0, c0, id0, n_db, lp, k, cnt, thr, Tb);
-        lk_take_hits<L>(h1, c1, id0 + 32, n_db, lp, k, cnt, thr, Tb);
+        lk_take_hits<L, List>(h0, c0, id0, n_db, list, thr, Tb);
+        lk_take_hits<L, List>(h1, c1, id0 + 32, n_db, list, thr, Tb);
     }
 }
 
-// K1L.  grid = ceil(n_q / 64) single-wave workgroups.  Dynamic LDS: 2 tiles + k * 64 * 4 B lists.
-template <int L, bool NEAREST>
+// K1L.  grid = ceil(n_q / 64) single-wave workgroups.  Dynamic LDS: 2 tiles (+ k * 64 * 4 B of lists when
+// KCAP == 0).  KCAP > 0: register-resident list of capacity KCAP >= k; KCAP == 0: LDS list (k <= 64).
+// NEAREST (k == 1): write only the nearest distance.
+template <int L, int KCAP, bool NEAREST>
 __global__ __launch_bounds__(WAVE) void k_hamming_knn_lk(const uint32_t* __restrict__ table, int n_db,
                                                          int n_tiles, const uint2* __restrict__ q, int64_t n_q,
                                                          int k, int32_t* __restrict__ ids,
@@ -137,9 +226,7 @@ __global__ __launch_bounds__(WAVE) void k_hamming_knn_lk(const uint32_t* __restr
     constexpr int TILE_W = lk_tile_bytes(L) / 4;         // words per tile
     constexpr int GW = lk_group_words(L);
     uint32_t* tiles = smem;                              // [2][TILE_W]
-    uint32_t* list = smem + 2 * TILE_W;                  // [k][64]
     const int lane = threadIdx.x;
-    uint32_t* lp = list + lane;
 
     const int64_t qi = (int64_t)blockIdx.x * WAVE + lane;
     const bool valid = qi < n_q;
@@ -152,14 +239,12 @@ __global__ __launch_bounds__(WAVE) void k_hamming_knn_lk(const uint32_t* __restr
         uint32_t code = ((qv.x >> p) & 1u) | (((qv.y >> p) & 1u) << 1);
         ptr[p] = tiles + p * 8 + (int)code * 2;
     }
+    using List = typename std::conditional<(KCAP > 0), RegList<(KCAP > 0 ? KCAP : 1)>, LdsList>::type;
+    List list;
+    list.init(k, smem + 2 * TILE_W, lane);
     int thr = valid ? L + 1 : 0;       // L + 1 accepts every distance until the list is full
-    int cnt = 0;
     uint32_t Tb[5];
-    {
-        const uint32_t bound = (uint32_t)(L + 1 - thr);
-#pragma unroll
-        for (int i = 0; i < 5; ++i) Tb[i] = 0u - ((bound >> i) & 1u);
-    }
+    lk_set_bound(Tb, L, thr);
 
     // single-wave workgroup: LDS operations of one wave execute in issue order, no barrier needed;
     // tile t+1 is DMA'd into the other buffer while tile t is evaluated.  The tile loop is unrolled by
@@ -175,7 +260,7 @@ __global__ __launch_bounds__(WAVE) void k_hamming_knn_lk(const uint32_t* __restr
             if (gl == 1) lk_read_group<L, 1 * GW>(r, ptr);
             if (gl == 2) lk_read_group<L, 2 * GW>(r, ptr);
             if (gl == 3) lk_read_group<L, 3 * GW>(r, ptr);
-            lk_process_group<L>(r, (t * LK_TG + gl) * LK_GROUP, n_db, lp, k, cnt, thr, Tb);
+            lk_process_group<L, List>(r, (t * LK_TG + gl) * LK_GROUP, n_db, list, thr, Tb);
         }
         lk_stage_wait();                                               // tile t+1 has landed in buffer 1
         if (t + 2 < n_tiles) lk_stage<L>(table, t + 2, tiles, lane);
@@ -186,23 +271,11 @@ __global__ __launch_bounds__(WAVE) void k_hamming_knn_lk(const uint32_t* __restr
             if (gl == 1) lk_read_group<L, TILE_W + 1 * GW>(r, ptr);
             if (gl == 2) lk_read_group<L, TILE_W + 2 * GW>(r, ptr);
             if (gl == 3) lk_read_group<L, TILE_W + 3 * GW>(r, ptr);
-            lk_process_group<L>(r, ((t + 1) * LK_TG + gl) * LK_GROUP, n_db, lp, k, cnt, thr, Tb);
+            lk_process_group<L, List>(r, ((t + 1) * LK_TG + gl) * LK_GROUP, n_db, list, thr, Tb);
         }
     }
 
-    if (valid) {
-        if constexpr (NEAREST) {
-            dists[qi] = cnt > 0 ? (int32_t)(lp[0] >> ID_BITS) : -1;
-        } else {
-            counts[qi] = cnt;
-            for (int s = 0; s < k; ++s) {
-                bool ok = s < cnt;
-                uint32_t key = ok ? lp[s * WAVE] : 0u;
-                ids[qi * k + s] = ok ? (int32_t)(key & ID_MASK) : -1;
-                dists[qi * k + s] = ok ? (int32_t)(key >> ID_BITS) : -1;
-            }
-        }
-    }
+    if (valid) list.store(k, qi, ids, dists, counts, NEAREST);
 }
 
 }  // namespace gm

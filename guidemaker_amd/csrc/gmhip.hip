@@ -187,15 +187,27 @@ int launch_bs_by_len(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* d
     }
 }
 
-template <int L, bool NEAREST>
-int launch_lk(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* dists, int32_t* counts,
-              hipStream_t st) {
+template <int L, int KCAP, bool NEAREST>
+int launch_lk_cfg(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* dists, int32_t* counts,
+                  hipStream_t st) {
     const int64_t blocks = (n_q + gm::WAVE - 1) / gm::WAVE;
-    size_t lds = 2 * (size_t)gm::lk_tile_bytes(L) + sizeof(uint32_t) * (size_t)k * gm::WAVE;
-    hipLaunchKernelGGL((gm::k_hamming_knn_lk<L, NEAREST>), dim3((unsigned)blocks), dim3(gm::WAVE), lds, st,
+    size_t lds = 2 * (size_t)gm::lk_tile_bytes(L) + (KCAP == 0 ? sizeof(uint32_t) * (size_t)k * gm::WAVE : 0);
+    hipLaunchKernelGGL((gm::k_hamming_knn_lk<L, KCAP, NEAREST>), dim3((unsigned)blocks), dim3(gm::WAVE), lds, st,
                        idx->d_onehot, (int)idx->n_db, (int)idx->n_lk_tiles, idx->d_q, n_q, k, ids, dists, counts);
     HIP_TRY(hipGetLastError());
     return GM_OK;
+}
+
+// list capacity by k: registers for k <= 20 (the reference CLI's range is 2..20, cli.py:55-56), LDS beyond
+template <int L, bool NEAREST>
+int launch_lk(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* dists, int32_t* counts,
+              hipStream_t st) {
+    if (NEAREST) return launch_lk_cfg<L, 1, true>(idx, n_q, 1, ids, dists, counts, st);
+    if (idx->variant == 7) return launch_lk_cfg<L, 0, false>(idx, n_q, k, ids, dists, counts, st);   // A/B: LDS lists
+    if (k <= 4) return launch_lk_cfg<L, 4, false>(idx, n_q, k, ids, dists, counts, st);
+    if (k <= 10) return launch_lk_cfg<L, 10, false>(idx, n_q, k, ids, dists, counts, st);
+    if (k <= 20) return launch_lk_cfg<L, 20, false>(idx, n_q, k, ids, dists, counts, st);
+    return launch_lk_cfg<L, 0, false>(idx, n_q, k, ids, dists, counts, st);
 }
 
 template <bool NEAREST>
@@ -213,7 +225,7 @@ int launch_lk_by_len(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* d
 
 // variant 0 = default (K1L look-up kernel), 1 = popcount kernel K1, 5 and 2x/3x = K1v knobs
 bool use_lookup(const gm_index* idx) {
-    return idx->metric == GM_METRIC_HAMMING && idx->d_onehot != nullptr && idx->variant == 0;
+    return idx->metric == GM_METRIC_HAMMING && idx->d_onehot != nullptr && (idx->variant == 0 || idx->variant == 7);
 }
 
 bool use_bitslice(const gm_index* idx) {
