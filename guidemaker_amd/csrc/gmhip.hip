@@ -192,6 +192,14 @@ int launch_lk_cfg(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* dist
                   hipStream_t st) {
     const int64_t blocks = (n_q + gm::WAVE - 1) / gm::WAVE;
     size_t lds = 2 * (size_t)gm::lk_tile_bytes(L) + (KCAP == 0 ? sizeof(uint32_t) * (size_t)k * gm::WAVE : 0);
+    // (Capping the occupancy to make the number of workgroup rounds integral was measured and does not
+    // pay: throughput rises with resident waves up to the VGPR/LDS limit -- profiles/r01/NOTES.md.)
+    if (idx->variant >= 40 && idx->variant < 50) {     // A/B knob: cap resident waves per SIMD via LDS padding
+        const size_t pad = (size_t)160 * 1024 / (4 * (size_t)(idx->variant - 40 > 0 ? idx->variant - 40 : 1)) / 512 * 512;
+        if (pad > lds) lds = pad;
+    }
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gm::k_hamming_knn_lk<L, KCAP, NEAREST>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((gm::k_hamming_knn_lk<L, KCAP, NEAREST>), dim3((unsigned)blocks), dim3(gm::WAVE), lds, st,
                        idx->d_onehot, (int)idx->n_db, (int)idx->n_lk_tiles, idx->d_q, n_q, k, ids, dists, counts);
     HIP_TRY(hipGetLastError());
@@ -225,7 +233,7 @@ int launch_lk_by_len(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* d
 
 // variant 0 = default (K1L look-up kernel), 1 = popcount kernel K1, 5 and 2x/3x = K1v knobs
 bool use_lookup(const gm_index* idx) {
-    return idx->metric == GM_METRIC_HAMMING && idx->d_onehot != nullptr && (idx->variant == 0 || idx->variant == 7);
+    return idx->metric == GM_METRIC_HAMMING && idx->d_onehot != nullptr && (idx->variant == 0 || idx->variant == 7 || (idx->variant >= 40 && idx->variant < 50));
 }
 
 bool use_bitslice(const gm_index* idx) {
