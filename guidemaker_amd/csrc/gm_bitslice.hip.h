@@ -39,7 +39,7 @@ static_assert((((0xF0 & 0xCC) | (0xAA & (0xF0 ^ 0xCC))) & 0xFF) == TT_MAJ, "maj"
 // ---------------------------------------------------------------------------------------------
 // horizontal planes -> vertical groups.  One thread per output word.
 // ---------------------------------------------------------------------------------------------
-__global__ void k_to_vertical(const uint2* __restrict__ planes, int64_t n_db, uint32_t* __restrict__ V,
+static __global__ void k_to_vertical(const uint2* __restrict__ planes, int64_t n_db, uint32_t* __restrict__ V,
                               int64_t n_groups, int L, int W) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_groups * W) return;

@@ -53,7 +53,7 @@ __device__ __forceinline__ uint32_t even_bits(uint64_t x) {
     return (uint32_t)x;
 }
 
-__global__ void k_to_planes(const uint64_t* __restrict__ in, uint2* __restrict__ out, int64_t n,
+static __global__ void k_to_planes(const uint64_t* __restrict__ in, uint2* __restrict__ out, int64_t n,
                             int64_t n_pad) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pad) return;
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(WAVE) void k_leven_nearest(const uint2* __restrict_
 // K3: CFD (cfd_score_calculator.py:60-85): float64 product in ascending position; the table holds
 // 1.0 on the Watson-Crick (= matching) entries, and x * 1.0 is exact, so the loop is branch-free.
 // ---------------------------------------------------------------------------------------------
-__global__ void k_cfd(const uint64_t* __restrict__ guides, const uint64_t* __restrict__ offs, int64_t n,
+static __global__ void k_cfd(const uint64_t* __restrict__ guides, const uint64_t* __restrict__ offs, int64_t n,
                       int L, const double* __restrict__ mm, double* __restrict__ out) {
     __shared__ double smm[320];
     for (int i = threadIdx.x; i < 320; i += blockDim.x) smm[i] = mm[i];

@@ -31,7 +31,7 @@ static_assert(((0xF0 | ~0xCC) & 0xFF) == TT_A_OR_NOTB, "a | ~b");
 static_assert((((0xF0 & ~0xCC) | (~(0xF0 ^ 0xCC) & 0xAA)) & 0xFF) == TT_GE, "ge stage");
 
 // planes -> one-hot bit-sliced table.  One thread per output word; ids past n_db replicate the last.
-__global__ void k_to_onehot(const uint2* __restrict__ planes, int64_t n_db, uint32_t* __restrict__ table,
+static __global__ void k_to_onehot(const uint2* __restrict__ planes, int64_t n_db, uint32_t* __restrict__ table,
                             int64_t n_groups, int L) {
     const int gw = lk_group_words(L);
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -1,61 +1,23 @@
 // gmhip.hip -- C ABI (include/gmhip.h) over the gfx950 kernels in gm_kernels.hip.h.
 // Host side of libgmhip.so: handle management, HBM workspaces, launches, HIP-event timing.
+#include "gm_host.h"
 #include "gm_kernels.hip.h"
-#include "gm_bitslice.hip.h"
-#include "gm_lookup.hip.h"
+#include "gm_lookup.hip.h"   // k_to_onehot only; the scan kernels are instantiated in gm_inst_lk.hip
+#include "gm_leven.hip.h"    // k_to_peq, k_leven_merge; the scan kernels are instantiated in gm_inst_lv.hip
 
-#include <string>
-#include <vector>
 #include <cstdio>
 #include <cstring>
 
-#include "gmhip.h"
-
 namespace {
-
 thread_local std::string g_err;
+}
 
-int fail(int code, const std::string& msg) {
+int gm_fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
 }
 
-#define HIP_TRY(expr)                                                                       \
-    do {                                                                                    \
-        hipError_t e_ = (expr);                                                             \
-        if (e_ != hipSuccess)                                                               \
-            return fail(GM_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
-    } while (0)
-
-int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
-
-}  // namespace
-
-struct gm_index {
-    int device = 0;
-    int L = 0;
-    int metric = 0;
-    int64_t n_db = 0;
-    int64_t n_db_pad = 0;
-    uint2* d_db = nullptr;        // bit planes, padded to a multiple of gm::TILE
-    uint32_t* d_vert = nullptr;   // bit-sliced groups of 32 entries (Hamming, 10 <= L <= 27)
-    uint32_t* d_onehot = nullptr; // one-hot bit-sliced table, groups of 64 entries (K1L)
-    int64_t n_lk_tiles = 0;
-    int64_t n_groups = 0;
-    // workspaces (grow-only), so repeated queries do not allocate
-    uint2* d_q = nullptr;
-    int64_t q_cap = 0;
-    void* d_stage = nullptr;      // host-pointer API: packed queries in / results out
-    int64_t stage_cap = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed = false;
-    std::vector<hipEvent_t> hist0, hist1;   // optional per-launch history (gm_timing_reserve)
-    int64_t hist_count = 0;
-    const char* last_kernel = "";
-    int64_t last_pairs = 0;
-    int variant = 0;
-    int n_simd = 1024;            // CUs x 4
-};
+#define fail gm_fail
 
 namespace {
 
@@ -123,112 +85,86 @@ int launch_leven_knn(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* d
     return GM_OK;
 }
 
-constexpr int BS_GROUP_PAD = 4;   // n_groups is padded to a multiple of this (kernels take G | 4)
-
-template <int L, bool NEAREST, int G, int NW>
-int launch_bs_cfg(gm_index* idx, int64_t n_q, int k, int wps_cap, bool one_chunk, int32_t* ids, int32_t* dists,
-                  int32_t* counts, hipStream_t st) {
-    // Work split: one chunk = 64 queries, one wave takes c consecutive chunks.  All workgroups must be
-    // resident at once (otherwise the last, partly filled round runs at low occupancy for a whole wave
-    // lifetime), so c = ceil(chunks / resident wave slots).
-    auto kern = gm::k_hamming_knn_bs<L, NEAREST, G, NW>;
-    const int64_t chunks = (n_q + gm::WAVE - 1) / gm::WAVE;
-    size_t lds = sizeof(uint32_t) * (size_t)k * gm::WAVE * NW;
-    int per_cu = 0;     // resident workgroups per CU for this instantiation and list size
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern),
-                                                          gm::WAVE * NW, lds));
-    int wps = per_cu * NW / 4 > 0 ? per_cu * NW / 4 : 1;
-    if (wps_cap > 0 && wps_cap < wps) wps = wps_cap;
-    const int64_t slots = (int64_t)idx->n_simd * wps;
-    int64_t cpw = one_chunk ? 1 : (chunks + slots - 1) / slots;
-    const int64_t waves = (chunks + cpw - 1) / cpw;
-    const int64_t blocks = (waves + NW - 1) / NW;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(gm::WAVE * NW), lds, st, idx->d_vert, (int)idx->n_db,
-                       (int)idx->n_groups, idx->d_q, n_q, k, (int)cpw, ids, dists, counts);
-    HIP_TRY(hipGetLastError());
-    return GM_OK;
-}
-
-template <int L, bool NEAREST>
-int launch_bs(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* dists, int32_t* counts,
-              hipStream_t st) {
-    const int v = idx->variant;
-    if (L == 20) {   // A/B knobs (experiments): 2x = one chunk per wave, 3x = balanced chunks; x = config
-        switch (v) {
-            case 20: return launch_bs_cfg<20, NEAREST, 2, 1>(idx, n_q, k, 0, true, ids, dists, counts, st);
-            case 21: return launch_bs_cfg<20, NEAREST, 1, 1>(idx, n_q, k, 0, true, ids, dists, counts, st);
-            case 22: return launch_bs_cfg<20, NEAREST, 3, 1>(idx, n_q, k, 0, true, ids, dists, counts, st);
-            case 23: return launch_bs_cfg<20, NEAREST, 2, 4>(idx, n_q, k, 0, true, ids, dists, counts, st);
-            case 24: return launch_bs_cfg<20, NEAREST, 2, 8>(idx, n_q, k, 0, true, ids, dists, counts, st);
-            case 25: return launch_bs_cfg<20, NEAREST, 1, 8>(idx, n_q, k, 0, true, ids, dists, counts, st);
-            case 26: return launch_bs_cfg<20, NEAREST, 2, 16>(idx, n_q, k, 0, true, ids, dists, counts, st);
-            case 27: return launch_bs_cfg<20, NEAREST, 4, 1>(idx, n_q, k, 0, true, ids, dists, counts, st);
-            case 30: return launch_bs_cfg<20, NEAREST, 2, 1>(idx, n_q, k, 0, false, ids, dists, counts, st);
-            case 33: return launch_bs_cfg<20, NEAREST, 2, 4>(idx, n_q, k, 0, false, ids, dists, counts, st);
-            case 34: return launch_bs_cfg<20, NEAREST, 2, 8>(idx, n_q, k, 0, false, ids, dists, counts, st);
-            case 35: return launch_bs_cfg<20, NEAREST, 1, 8>(idx, n_q, k, 0, false, ids, dists, counts, st);
-            case 36: return launch_bs_cfg<20, NEAREST, 2, 16>(idx, n_q, k, 0, false, ids, dists, counts, st);
-            default: break;
-        }
-    }
-    return launch_bs_cfg<L, NEAREST, 2, 1>(idx, n_q, k, 0, true, ids, dists, counts, st);
-}
-
-template <bool NEAREST>
-int launch_bs_by_len(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* dists, int32_t* counts,
-                     hipStream_t st) {
+int launch_lk_by_len(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t* ids, int32_t* dists,
+                     int32_t* counts, hipStream_t st) {
     switch (idx->L) {
-#define GM_CASE(LEN) case LEN: return launch_bs<LEN, NEAREST>(idx, n_q, k, ids, dists, counts, st);
-        GM_CASE(10) GM_CASE(11) GM_CASE(12) GM_CASE(13) GM_CASE(14) GM_CASE(15) GM_CASE(16) GM_CASE(17)
-        GM_CASE(18) GM_CASE(19) GM_CASE(20) GM_CASE(21) GM_CASE(22) GM_CASE(23) GM_CASE(24) GM_CASE(25)
-        GM_CASE(26) GM_CASE(27)
-#undef GM_CASE
-        default: return fail(GM_ERR_ARG, "bit-sliced kernel: guidelen out of range");
-    }
-}
-
-template <int L, int KCAP, bool NEAREST>
-int launch_lk_cfg(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* dists, int32_t* counts,
-                  hipStream_t st) {
-    const int64_t blocks = (n_q + gm::WAVE - 1) / gm::WAVE;
-    size_t lds = 2 * (size_t)gm::lk_tile_bytes(L) + (KCAP == 0 ? sizeof(uint32_t) * (size_t)k * gm::WAVE : 0);
-    // (Capping the occupancy to make the number of workgroup rounds integral was measured and does not
-    // pay: throughput rises with resident waves up to the VGPR/LDS limit -- profiles/r01/NOTES.md.)
-    if (idx->variant >= 40 && idx->variant < 50) {     // A/B knob: cap resident waves per SIMD via LDS padding
-        const size_t pad = (size_t)160 * 1024 / (4 * (size_t)(idx->variant - 40 > 0 ? idx->variant - 40 : 1)) / 512 * 512;
-        if (pad > lds) lds = pad;
-    }
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gm::k_hamming_knn_lk<L, KCAP, NEAREST>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((gm::k_hamming_knn_lk<L, KCAP, NEAREST>), dim3((unsigned)blocks), dim3(gm::WAVE), lds, st,
-                       idx->d_onehot, (int)idx->n_db, (int)idx->n_lk_tiles, idx->d_q, n_q, k, ids, dists, counts);
-    HIP_TRY(hipGetLastError());
-    return GM_OK;
-}
-
-// list capacity by k: registers for k <= 20 (the reference CLI's range is 2..20, cli.py:55-56), LDS beyond
-template <int L, bool NEAREST>
-int launch_lk(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* dists, int32_t* counts,
-              hipStream_t st) {
-    if (NEAREST) return launch_lk_cfg<L, 1, true>(idx, n_q, 1, ids, dists, counts, st);
-    if (idx->variant == 7) return launch_lk_cfg<L, 0, false>(idx, n_q, k, ids, dists, counts, st);   // A/B: LDS lists
-    if (k <= 4) return launch_lk_cfg<L, 4, false>(idx, n_q, k, ids, dists, counts, st);
-    if (k <= 10) return launch_lk_cfg<L, 10, false>(idx, n_q, k, ids, dists, counts, st);
-    if (k <= 20) return launch_lk_cfg<L, 20, false>(idx, n_q, k, ids, dists, counts, st);
-    return launch_lk_cfg<L, 0, false>(idx, n_q, k, ids, dists, counts, st);
-}
-
-template <bool NEAREST>
-int launch_lk_by_len(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* dists, int32_t* counts,
-                     hipStream_t st) {
-    switch (idx->L) {
-#define GM_CASE(LEN) case LEN: return launch_lk<LEN, NEAREST>(idx, n_q, k, ids, dists, counts, st);
-        GM_CASE(10) GM_CASE(11) GM_CASE(12) GM_CASE(13) GM_CASE(14) GM_CASE(15) GM_CASE(16) GM_CASE(17)
-        GM_CASE(18) GM_CASE(19) GM_CASE(20) GM_CASE(21) GM_CASE(22) GM_CASE(23) GM_CASE(24) GM_CASE(25)
-        GM_CASE(26) GM_CASE(27)
+#define GM_CASE(LEN) case LEN: return gm_launch_lk_L##LEN(idx, nearest, n_q, k, ids, dists, counts, st);
+        GM_FOR_EACH_LEN(GM_CASE)
 #undef GM_CASE
         default: return fail(GM_ERR_ARG, "look-up kernel: guidelen out of range");
     }
+}
+
+int launch_lv_by_len(gm_index* idx, int kcap, int64_t n_q, int k, int n_seg, int tiles_per_seg,
+                     const int32_t* seed_d, const int32_t* seed_c, int seed_k, uint32_t* keys, hipStream_t st) {
+    switch (idx->L) {
+#define GM_CASE(LEN) \
+    case LEN: return gm_launch_lv_L##LEN(idx, kcap, n_q, k, n_seg, tiles_per_seg, seed_d, seed_c, seed_k, keys, st);
+        GM_FOR_EACH_LEN(GM_CASE)
+#undef GM_CASE
+        default: return fail(GM_ERR_ARG, "leven look-up kernel: guidelen out of range");
+    }
+}
+
+int launch_lv_merge(int kcap, const uint32_t* keys, int n_seg, int64_t n_q, int k, int32_t* ids, int32_t* dists,
+                    int32_t* counts, bool nearest, hipStream_t st) {
+    const dim3 grid((unsigned)((n_q + 255) / 256)), block(256);
+    switch (kcap) {
+        case 1: hipLaunchKernelGGL(gm::k_leven_merge<1>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nearest ? 1 : 0); break;
+        case 4: hipLaunchKernelGGL(gm::k_leven_merge<4>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nearest ? 1 : 0); break;
+        case 10: hipLaunchKernelGGL(gm::k_leven_merge<10>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nearest ? 1 : 0); break;
+        default: hipLaunchKernelGGL(gm::k_leven_merge<20>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nearest ? 1 : 0); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return GM_OK;
+}
+
+int timing_begin(gm_index* idx, hipStream_t st);
+int timing_end(gm_index* idx, hipStream_t st, int64_t pairs);
+int launch_lk_by_len(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t* ids, int32_t* dists,
+                     int32_t* counts, hipStream_t st);
+
+// K2L pipeline: (1) Hamming k-NN with K1L -> seeds (lev <= hamming) written into the caller's output
+// buffers, (2) segmented Levenshtein scan into scratch lists, (3) merge into the output buffers.
+// The query planes are already in idx->d_q.  d1 != nullptr: nearest-distance form (k = 1).
+bool use_leven_lookup(const gm_index* idx, int k) {
+    return idx->metric == GM_METRIC_LEVEN && idx->d_peq != nullptr && idx->d_onehot != nullptr && k <= 20 &&
+           idx->variant == 0;
+}
+
+int run_leven_lookup(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* dists, int32_t* counts,
+                     int32_t* d1, hipStream_t st) {
+    const bool nearest = d1 != nullptr;
+    const int kcap = nearest ? 1 : (k <= 4 ? 4 : (k <= 10 ? 10 : 20));
+    int rc = nearest ? launch_lk_by_len(idx, true, n_q, 1, nullptr, d1, nullptr, st)
+                     : launch_lk_by_len(idx, false, n_q, k, ids, dists, counts, st);
+    if (rc) return rc;
+    // enough (chunk, segment) workgroups to fill the chip several times over, segments of whole tiles
+    const int64_t chunks = (n_q + gm::WAVE - 1) / gm::WAVE;
+    int64_t want = ((int64_t)idx->n_simd * 8 + chunks - 1) / chunks;
+    if (want < 1) want = 1;
+    if (want > idx->n_lv_tiles) want = idx->n_lv_tiles;
+    const int tiles_per_seg = (int)((idx->n_lv_tiles + want - 1) / want);
+    const int n_seg = (int)((idx->n_lv_tiles + tiles_per_seg - 1) / tiles_per_seg);
+    const int64_t need = (int64_t)n_seg * n_q * kcap;
+    if (need > idx->keys_cap) {
+        if (idx->d_keys) (void)hipFree(idx->d_keys);
+        idx->d_keys = nullptr;
+        idx->keys_cap = 0;
+        if (hipMalloc(&idx->d_keys, sizeof(uint32_t) * need) != hipSuccess)
+            return fail(GM_ERR_ALLOC, "hipMalloc(segment lists) failed");
+        idx->keys_cap = need;
+    }
+    rc = timing_begin(idx, st);
+    if (rc) return rc;
+    idx->last_kernel = nearest ? "k_leven_knn_lk(nearest)" : "k_leven_knn_lk";
+    rc = nearest ? launch_lv_by_len(idx, kcap, n_q, 1, n_seg, tiles_per_seg, d1, nullptr, 1, idx->d_keys, st)
+                 : launch_lv_by_len(idx, kcap, n_q, k, n_seg, tiles_per_seg, dists, counts, k, idx->d_keys, st);
+    if (rc) return rc;
+    rc = timing_end(idx, st, n_q * idx->n_db);
+    if (rc) return rc;
+    return nearest ? launch_lv_merge(kcap, idx->d_keys, n_seg, n_q, 1, nullptr, d1, nullptr, true, st)
+                   : launch_lv_merge(kcap, idx->d_keys, n_seg, n_q, k, ids, dists, counts, false, st);
 }
 
 // variant 0 = default (K1L look-up kernel), 1 = popcount kernel K1, 5 and 2x/3x = K1v knobs
@@ -352,19 +288,13 @@ int gm_index_create_dev(const void* d_packed, int64_t n_db, int guidelen, int me
             gm_index_free(idx);
             return rc;
         }
-        if (metric == GM_METRIC_HAMMING && guidelen >= 10 && guidelen <= 27) {
-            const int W = gm::vert_stride(guidelen);
-            idx->n_groups = round_up((n_db + gm::GROUP - 1) / gm::GROUP, BS_GROUP_PAD);
-            if (hipMalloc(&idx->d_vert, sizeof(uint32_t) * idx->n_groups * W) != hipSuccess) {
-                gm_index_free(idx);
-                return fail(GM_ERR_ALLOC, "hipMalloc(db bit-sliced groups) failed");
-            }
-            int64_t words = idx->n_groups * W;
-            hipLaunchKernelGGL(gm::k_to_vertical, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st,
-                               idx->d_db, n_db, idx->d_vert, idx->n_groups, guidelen, W);
-            if (hipGetLastError() != hipSuccess) {
-                gm_index_free(idx);
-                return fail(GM_ERR_DEVICE, "k_to_vertical launch failed");
+        if (guidelen >= 10 && guidelen <= 27) {
+            if (metric == GM_METRIC_HAMMING && guidelen == 20) {      // K1v A/B baseline exists for L = 20 only
+                int rcv = gm_build_vertical(idx, st);
+                if (rcv != GM_OK) {
+                    gm_index_free(idx);
+                    return rcv;
+                }
             }
             // one-hot table for the look-up kernel
             const int64_t lk_groups = round_up((n_db + gm::LK_GROUP - 1) / gm::LK_GROUP, 2 * gm::LK_TG);   // even tile count
@@ -379,6 +309,20 @@ int gm_index_create_dev(const void* d_packed, int64_t n_db, int guidelen, int me
             if (hipGetLastError() != hipSuccess) {
                 gm_index_free(idx);
                 return fail(GM_ERR_DEVICE, "k_to_onehot launch failed");
+            }
+            if (metric == GM_METRIC_LEVEN) {   // K2L: per-target match masks
+                const int64_t n_pad = round_up(n_db, gm::LV_TILE);
+                idx->n_lv_tiles = n_pad / gm::LV_TILE;
+                if (hipMalloc(&idx->d_peq, sizeof(uint4) * n_pad) != hipSuccess) {
+                    gm_index_free(idx);
+                    return fail(GM_ERR_ALLOC, "hipMalloc(db match masks) failed");
+                }
+                hipLaunchKernelGGL(gm::k_to_peq, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, st, idx->d_db,
+                                   n_db, idx->d_peq, n_pad, guidelen);
+                if (hipGetLastError() != hipSuccess) {
+                    gm_index_free(idx);
+                    return fail(GM_ERR_DEVICE, "k_to_peq launch failed");
+                }
             }
         }
     }
@@ -427,6 +371,8 @@ void gm_index_free(gm_index* idx) {
     if (idx->d_db) (void)hipFree(idx->d_db);
     if (idx->d_vert) (void)hipFree(idx->d_vert);
     if (idx->d_onehot) (void)hipFree(idx->d_onehot);
+    if (idx->d_peq) (void)hipFree(idx->d_peq);
+    if (idx->d_keys) (void)hipFree(idx->d_keys);
     if (idx->d_q) (void)hipFree(idx->d_q);
     if (idx->d_stage) (void)hipFree(idx->d_stage);
     timing_clear(idx);
@@ -466,15 +412,16 @@ int gm_knn_query_dev(gm_index* idx, const void* d_q, int64_t n_q, int k, void* d
     if (rc) return rc;
     rc = planes_launch(static_cast<const uint64_t*>(d_q), idx->d_q, n_q, n_q, st);
     if (rc) return rc;
+    if (use_leven_lookup(idx, k)) return run_leven_lookup(idx, n_q, k, ids, dists, counts, nullptr, st);
     rc = timing_begin(idx, st);
     if (rc) return rc;
     const int R = pick_r(k);
     if (use_lookup(idx)) {
         idx->last_kernel = "k_hamming_knn_lk";
-        rc = launch_lk_by_len<false>(idx, n_q, k, ids, dists, counts, st);
+        rc = launch_lk_by_len(idx, false, n_q, k, ids, dists, counts, st);
     } else if (use_bitslice(idx)) {
         idx->last_kernel = "k_hamming_knn_bs";
-        rc = launch_bs_by_len<false>(idx, n_q, k, ids, dists, counts, st);
+        rc = gm_launch_bs20(idx, false, n_q, k, ids, dists, counts, st);
     } else if (idx->metric == GM_METRIC_HAMMING) {
         idx->last_kernel = "k_hamming_knn";
         rc = R == 4 ? launch_hamming_knn<4>(idx, n_q, k, ids, dists, counts, st)
@@ -528,16 +475,17 @@ int gm_nearest_dist_dev(gm_index* idx, const void* d_q, int64_t n_q, void* d_d1,
     if (rc) return rc;
     rc = planes_launch(static_cast<const uint64_t*>(d_q), idx->d_q, n_q, n_q, st);
     if (rc) return rc;
+    if (use_leven_lookup(idx, 1)) return run_leven_lookup(idx, n_q, 1, nullptr, nullptr, nullptr, d1, st);
     int n_tiles = (int)(idx->n_db_pad / gm::TILE);
     rc = timing_begin(idx, st);
     if (rc) return rc;
     if (use_lookup(idx)) {
         idx->last_kernel = "k_hamming_knn_lk(nearest)";
-        rc = launch_lk_by_len<true>(idx, n_q, 1, nullptr, d1, nullptr, st);
+        rc = launch_lk_by_len(idx, true, n_q, 1, nullptr, d1, nullptr, st);
         if (rc) return rc;
     } else if (use_bitslice(idx)) {
         idx->last_kernel = "k_hamming_knn_bs(nearest)";
-        rc = launch_bs_by_len<true>(idx, n_q, 1, nullptr, d1, nullptr, st);
+        rc = gm_launch_bs20(idx, true, n_q, 1, nullptr, d1, nullptr, st);
         if (rc) return rc;
     } else if (idx->metric == GM_METRIC_HAMMING) {
         constexpr int R = 4;
