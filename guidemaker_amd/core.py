@@ -23,9 +23,11 @@ Deliberate, documented differences (DESIGN.md "Parity contract"):
   * there is no CPU fallback: without the HIP library / a GPU every search call raises.
 """
 import hashlib
+import itertools
 import json
 import os
 import statistics
+from collections.abc import Mapping
 from copy import deepcopy
 from itertools import product
 from typing import List
@@ -193,6 +195,58 @@ def _load_cfd_table():
         return np.asarray(json.load(fh)["mm"], dtype=np.float64)
 
 
+class NeighborMap(Mapping):
+    """Read-only dict view of the k-NN result with the reference's schema
+
+        neighbors[seq] == {"target": seq, "neighbors": {"seqs": [...], "dist": [...]}}
+
+    (reference core.py:513-523).  The reference materialises one dict + two lists per retained guide in
+    a Python loop; at 10^6 guides that loop costs seconds while the GPU scan takes milliseconds, so the
+    entries are built on access from the result arrays instead.  Duplicate candidate strings collapse
+    onto one key, the last occurrence winning, as with the reference's dict assignment.  Vectorised
+    consumers use .keys_array / .row_of / .ids / .dists / .counts directly.
+    """
+
+    def __init__(self, query_targets, keep, ids, dists, counts, db_targets):
+        self._q = query_targets                  # list[str], candidate order
+        self.keep = np.asarray(keep, dtype=np.int64)
+        self.ids, self.dists, self.counts = ids, dists, counts
+        self._db = db_targets                    # object array: index id -> sequence
+        self._row = None                         # key -> row in the result arrays (lazy)
+
+    def _rows(self):
+        if self._row is None:
+            q = self._q
+            self._row = {q[i]: i for i in self.keep.tolist()}      # later rows overwrite earlier ones
+        return self._row
+
+    def row_of(self, key):
+        return self._rows()[key]
+
+    @property
+    def keys_array(self):
+        """Retained candidate sequences (object array, candidate order, duplicates kept)."""
+        return np.asarray(self._q, dtype=object)[self.keep]
+
+    def __getitem__(self, key):
+        i = self._rows()[key]
+        c = int(self.counts[i])
+        return {"target": key, "neighbors": {"seqs": self._db[self.ids[i, :c]].tolist(),
+                                             "dist": self.dists[i, :c].tolist()}}
+
+    def __iter__(self):
+        return iter(self._rows())
+
+    def __len__(self):
+        return len(self._rows())
+
+    def __contains__(self, key):
+        return key in self._rows()
+
+    def __repr__(self):
+        return "NeighborMap(%d guides)" % len(self)
+
+
 class TargetProcessor:
     """A set of guide RNA targets and its MI355X-resident neighbour index."""
 
@@ -305,15 +359,7 @@ class TargetProcessor:
         # reference: hamming compares the one-hot distance (2 x mismatches) with 2 * editdist and
         # reports int(x / 2); in true units both reduce to the same test / value
         keep = np.flatnonzero(dists[:, 1] >= self.editdist) if len(unique_targets) else np.empty(0, np.int64)
-        db = self._db_targets
-        neighbor_dict = {}
-        for i in keep.tolist():
-            c = int(counts[i])
-            queryseq = unique_targets[i]
-            neighbor_dict[queryseq] = {"target": queryseq,
-                                       "neighbors": {"seqs": db[ids[i, :c]].tolist(),
-                                                     "dist": dists[i, :c].tolist()}}
-        self.neighbors = neighbor_dict
+        self.neighbors = NeighborMap(unique_targets, keep, ids, dists, counts, self._db_targets)
 
     def export_bed(self) -> object:
         """Targets that are not seed-duplicated, as a BED-like frame."""
@@ -395,21 +441,44 @@ class TargetProcessor:
 # ------------------------------------------------------------------------------------------------
 # CFD
 # ------------------------------------------------------------------------------------------------
+def _pack_rna(seqs: List[str], L: int) -> np.ndarray:
+    """Pack equal-length sequences; case and U/T are normalised on the joined string (one C-level pass)."""
+    joined = "".join(seqs).upper().replace('U', 'T')
+    if len(joined) != len(seqs) * L:
+        raise ValueError("all sequences must have length %d" % L)
+    return _lib.pack_bytes(joined.encode("ascii"), len(seqs), L)
+
+
+def _pack_by_length(seqs: List[str], lens: np.ndarray) -> np.ndarray:
+    """Pack sequences of mixed (valid) lengths; returns uint64 array aligned with seqs."""
+    uniq = np.unique(lens).tolist()
+    if len(uniq) == 1:
+        return _pack_rna(seqs, uniq[0])
+    out = np.empty((len(seqs),), np.uint64)
+    for L in uniq:
+        sel = np.flatnonzero(lens == L)
+        out[sel] = _pack_rna([seqs[i] for i in sel.tolist()], L)
+    return out
+
+
 def calc_cfd_pairs(guides: List[str], offs: List[str], device: int = 0) -> np.ndarray:
     """CFD score of equal-length (guide, off-target) pairs on the GPU (calc_cfd, batched)."""
-    for g, o in zip(guides, offs):
-        assert len(g) == len(o), "The lengths wt and off differ: wt = {}, off = {}".format(
-            str(len(g)), str(len(o)))
-    out = np.empty((len(guides),), np.float64)
-    if not len(guides):
+    n = len(guides)
+    out = np.empty((n,), np.float64)
+    if not n:
         return out
+    glen = np.fromiter(map(len, guides), dtype=np.int64, count=n)
+    olen = np.fromiter(map(len, offs), dtype=np.int64, count=n)
+    bad = np.flatnonzero(glen != olen)
+    if bad.size:
+        i = int(bad[0])
+        raise AssertionError("The lengths wt and off differ: wt = {}, off = {}".format(str(glen[i]), str(olen[i])))
     mm = _load_cfd_table()
-    lens = np.fromiter((len(g) for g in guides), dtype=np.int64, count=len(guides))
-    for L in np.unique(lens).tolist():
-        sel = np.flatnonzero(lens == L)
-        gp = _lib.pack([guides[i].upper().replace('U', 'T') for i in sel.tolist()], L)
-        op = _lib.pack([offs[i].upper().replace('U', 'T') for i in sel.tolist()], L)
-        out[sel] = _lib.cfd_batch(gp, op, L, mm, device)
+    gp = _pack_by_length(guides, glen)
+    op = _pack_by_length(offs, olen)
+    for L in np.unique(glen).tolist():
+        sel = np.flatnonzero(glen == L)
+        out[sel] = _lib.cfd_batch(gp[sel], op[sel], L, mm, device)
     return out
 
 
@@ -419,17 +488,35 @@ def calc_cfd(wt: str, off: str, mm_scores=None) -> float:
 
 
 def cfd_score(df, device: int = 0):
-    """Adds 'CFD Similar Guides' (list of str(float)) and 'Max CFD' (reference core.py:1129-1148)."""
-    guides, offs, owner = [], [], []
-    for row, (g, sim) in enumerate(zip(df['Guide sequence'].tolist(), df['Similar guides'].tolist())):
-        for item in sim.split(';'):
-            guides.append(g)
-            offs.append(item)
-            owner.append(row)
-    scores = calc_cfd_pairs(guides, offs, device)
-    per_row = [[] for _ in range(len(df))]
-    for r, v in zip(owner, scores.tolist()):
-        per_row[r].append(str(v))
-    df['CFD Similar Guides'] = pd.Series(per_row, index=df.index, dtype=object)
-    df['Max CFD'] = df['CFD Similar Guides'].apply(lambda lst: sorted(float(x) for x in lst)[-1])
+    """Adds 'CFD Similar Guides' (list of str(float)) and 'Max CFD' (reference core.py:1129-1148).
+
+    All (guide, similar guide) pairs of the frame go to the GPU in one batch; each distinct guide is
+    packed once."""
+    guides = df['Guide sequence'].tolist()
+    sims = [s.split(';') for s in df['Similar guides'].tolist()]
+    per_row = np.fromiter(map(len, sims), dtype=np.int64, count=len(sims))
+    offs = list(itertools.chain.from_iterable(sims))
+    n = len(offs)
+    glen_row = np.fromiter(map(len, guides), dtype=np.int64, count=len(guides))
+    olen = np.fromiter(map(len, offs), dtype=np.int64, count=n)
+    glen = np.repeat(glen_row, per_row)
+    bad = np.flatnonzero(glen != olen)
+    if bad.size:
+        i = int(bad[0])
+        raise AssertionError("The lengths wt and off differ: wt = {}, off = {}".format(str(glen[i]), str(olen[i])))
+    scores = np.empty((n,), np.float64)
+    if n:
+        mm = _load_cfd_table()
+        gp = np.repeat(_pack_by_length(guides, glen_row), per_row)
+        op = _pack_by_length(offs, olen)
+        for L in np.unique(olen).tolist():
+            sel = np.flatnonzero(olen == L)
+            scores[sel] = _lib.cfd_batch(gp[sel], op[sel], L, mm, device)
+    ends = np.cumsum(per_row)
+    starts = ends - per_row
+    flat = list(map(str, scores.tolist()))               # str(float), as the reference formats them
+    df['CFD Similar Guides'] = pd.Series([flat[a:b] for a, b in zip(starts.tolist(), ends.tolist())],
+                                         index=df.index, dtype=object)
+    # ''.split(';') yields [''] so every row has at least one entry, as in the reference
+    df['Max CFD'] = np.maximum.reduceat(scores, starts) if n else np.empty((0,), np.float64)
     return df

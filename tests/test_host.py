@@ -142,3 +142,21 @@ def test_control_draw_consumes_rng_like_np_random_choice():
 def test_cfd_length_assert():
     with pytest.raises(AssertionError, match="lengths wt and off differ"):
         core.calc_cfd("ACGT", "ACG")
+
+
+def test_neighbor_map_schema_and_duplicates():
+    # reference core.py:513-523: dict keyed by candidate string; later duplicates overwrite earlier ones
+    ids = np.array([[0, 1, -1], [1, 0, 2], [0, 2, 1], [2, 1, 0]], np.int32)
+    dists = np.array([[0, 3, -1], [0, 3, 4], [0, 5, 6], [0, 1, 2]], np.int32)
+    counts = np.array([2, 3, 3, 3], np.int32)
+    db = np.array(["AA", "CC", "GG"], dtype=object)
+    nm = core.NeighborMap(["AA", "CC", "AA", "GG"], [0, 1, 2], ids, dists, counts, db)   # row 3 not retained
+    assert len(nm) == 2 and list(nm.keys()) == ["AA", "CC"] and "GG" not in nm
+    assert nm["AA"] == {"target": "AA", "neighbors": {"seqs": ["AA", "GG", "CC"], "dist": [0, 5, 6]}}   # last dup
+    assert nm["CC"]["neighbors"]["dist"] == [0, 3, 4]
+    assert dict(nm)["CC"]["neighbors"]["seqs"] == ["CC", "AA", "GG"]
+    assert nm.keys_array.tolist() == ["AA", "CC", "AA"]
+    with pytest.raises(KeyError):
+        nm["GG"]
+    empty = core.NeighborMap([], [], ids[:0], dists[:0], counts[:0], db)
+    assert len(empty) == 0 and list(empty) == []
