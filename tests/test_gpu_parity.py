@@ -278,3 +278,53 @@ def test_cfd_score_frame(oracle, cfd_table):
     assert out["CFD Similar Guides"].tolist() == want_lists
     assert out["Max CFD"].tolist() == want_max
     assert out["Max CFD"][0] > 0                      # reference tests/test_core.py:315
+
+
+# ------------------------------------------------------------------ every kernel family / dispatch branch
+@pytest.mark.parametrize("L", [4, 7, 9])
+def test_short_guides_use_popcount_kernel(oracle, L):
+    # L < 10 is outside the bit-sliced kernels' range: popcount kernel K1 / plane-based Levenshtein
+    db = list(dict.fromkeys(random_pool(900, L, seed=40 + L)))
+    q = db[::2] + random_pool(64, L, seed=41)
+    for metric in ("hamming", "leven"):
+        ids, dists, counts = _gpu_knn(db, q, L, metric, 6)
+        oi, od, oc = _oracle_true_units(oracle, db, q, L, metric, 6)
+        assert (counts == oc).all() and (dists == od).all() and (ids == oi).all(), (L, metric)
+
+
+@pytest.mark.parametrize("k", [1, 3, 4, 11, 21, 33, 64])
+def test_list_capacity_boundaries(oracle, k):
+    # register lists hold k <= 4 / 10 / 20; beyond 20 the lists live in LDS (Hamming) or the
+    # plane-based kernel is used (Levenshtein)
+    L = 20
+    db = list(dict.fromkeys(random_pool(1500, L, seed=77, indel=True)))
+    q = db[:300] + random_pool(50, L, seed=78)
+    for metric in ("hamming", "leven"):
+        ids, dists, counts = _gpu_knn(db, q, L, metric, k)
+        oi, od, oc = _oracle_true_units(oracle, db, q, L, metric, k)
+        assert (counts == oc).all() and (dists == od).all() and (ids == oi).all(), (k, metric)
+
+
+def test_kernel_variants_agree(oracle):
+    # A/B knobs must not change results: K1 popcount (1), K1v scalar-load bit-slice (20), K1L LDS lists (7)
+    L = 20
+    db = list(dict.fromkeys(random_pool(4000, L, seed=90)))
+    q = db[::3]
+    idx = _lib.Index(_lib.pack(db, L), L, _lib.METRIC_HAMMING)
+    ref = idx.knn(_lib.pack(q, L), 10)
+    for v in (1, 7, 20, 22):
+        idx.set_variant(v)
+        got = idx.knn(_lib.pack(q, L), 10)
+        assert all((a == b).all() for a, b in zip(ref, got)), v
+        assert (idx.nearest(_lib.pack(q, L)) == ref[1][:, 0]).all(), v
+    idx.close()
+
+
+def test_many_segments_leven(oracle):
+    # few candidates x larger pool -> the Levenshtein scan splits the pool into many segments + merge
+    L = 23
+    db = list(dict.fromkeys(random_pool(9000, L, seed=5, indel=True)))
+    q = db[:70]
+    ids, dists, counts = _gpu_knn(db, q, L, "leven", 5)
+    oi, od, oc = _oracle_true_units(oracle, db, q, L, "leven", 5)
+    assert (counts == oc).all() and (dists == od).all() and (ids == oi).all()
