@@ -216,8 +216,12 @@ __device__ __forceinline__ void lk_process_group(const LkGroupRegs<L>& r, int id
 // K1L.  grid = ceil(n_q / 64) single-wave workgroups.  Dynamic LDS: 2 tiles (+ k * 64 * 4 B of lists when
 // KCAP == 0).  KCAP > 0: register-resident list of capacity KCAP >= k; KCAP == 0: LDS list (k <= 64).
 // NEAREST (k == 1): write only the nearest distance.
+// register budget: for L <= 20 with a list of <= 10 keys the allocator lands 2 VGPRs above the 80 that allow
+// 6 waves/SIMD; asking for 6 costs no spills there (checked with -Rpass-analysis=kernel-resource-usage)
+__host__ __device__ constexpr int lk_min_waves(int L, int KCAP) { return (L <= 20 && KCAP <= 10) ? 6 : 1; }
+
 template <int L, int KCAP, bool NEAREST>
-__global__ __launch_bounds__(WAVE) void k_hamming_knn_lk(const uint32_t* __restrict__ table, int n_db,
+__global__ __launch_bounds__(WAVE, lk_min_waves(L, KCAP)) void k_hamming_knn_lk(const uint32_t* __restrict__ table, int n_db,
                                                          int n_tiles, const uint2* __restrict__ q, int64_t n_q,
                                                          int k, int32_t* __restrict__ ids,
                                                          int32_t* __restrict__ dists,
