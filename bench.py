@@ -202,6 +202,15 @@ def main():
                 "note": "algorithmic (no-reuse) operand bytes / HIP-event kernel time; the scan is "
                         "VALU-bound, not HBM-bound, so frac > 1 means LDS/register reuse beats the "
                         "streaming model (SURVEY.md 8d)"}
+        if pool["metric"] != "hamming" and 10 <= L <= 27:
+            opp = 11.0 * L + 12.0      # K2L: 11 VALU ops per text position + distance/threshold tail
+            ops = launch_pairs * opp / kern_s
+            roof["valu"] = {"achieved": ops / 1e12, "peak": VALU_LANE_OPS_PER_S / 1e12,
+                            "unit": "T lane-ops/s", "frac": ops / VALU_LANE_OPS_PER_S, "ops_per_pair": opp,
+                            "lds_reads_per_pair": float(L),
+                            "note": "the binding roof for the Myers scan: int32 VALU issue "
+                                    "(256 CUs x 128 lanes/clk x 2.4 GHz); the HBM figure above is not meaningful "
+                                    "for Levenshtein (SURVEY.md 8d)"}
         if pool["metric"] == "hamming" and 10 <= L <= 27:
             opp = lookup_ops_per_pair(L)
             ops = launch_pairs * opp / kern_s
