@@ -71,6 +71,13 @@ def lib():
     L.gm_timing_reserve.restype = i32
     L.gm_timing_read.argtypes = [vp, vp, i32]
     L.gm_timing_read.restype = i32
+    L.gm_pam_count.argtypes = [c.c_char_p, i64, c.c_char_p, i32, i32, i32, i32, c.POINTER(vp), c.POINTER(i64),
+                               c.POINTER(i64)]
+    L.gm_pam_count.restype = i32
+    L.gm_pam_emit.argtypes = [vp, vp, vp, vp]
+    L.gm_pam_emit.restype = i32
+    L.gm_pam_free.argtypes = [vp]
+    L.gm_pam_free.restype = None
     for name in ("gm_pack", "gm_unpack", "gm_index_create", "gm_index_create_dev", "gm_index_guidelen",
                  "gm_index_metric", "gm_knn_query", "gm_knn_query_dev", "gm_nearest_dist",
                  "gm_nearest_dist_dev", "gm_cfd_batch", "gm_cfd_batch_dev", "gm_set_variant"):
@@ -85,7 +92,7 @@ EXPORTS = [
     "gm_index_create_dev", "gm_index_free", "gm_index_size", "gm_index_guidelen", "gm_index_metric",
     "gm_knn_query", "gm_knn_query_dev", "gm_nearest_dist", "gm_nearest_dist_dev", "gm_cfd_batch",
     "gm_cfd_batch_dev", "gm_last_kernel_ms", "gm_last_kernel_name", "gm_last_kernel_pairs",
-    "gm_set_variant", "gm_timing_reserve", "gm_timing_read",
+    "gm_set_variant", "gm_timing_reserve", "gm_timing_read", "gm_pam_count", "gm_pam_emit", "gm_pam_free",
 ]
 
 
@@ -228,6 +235,26 @@ def cfd_batch(guides_packed, offs_packed, guidelen, mm, device=0):
     if g.size:
         _check(lib().gm_cfd_batch(_ptr(g), _ptr(o), g.size, guidelen, _ptr(table), _ptr(out), device))
     return out
+
+
+def pam_scan(seq, pam, five_prime, guidelen, device=0):
+    """GPU PAM scan of one record (upper-case str or bytes).  Returns (packed uint64, tstart int64,
+    mstart int64, n_fwd): forward hits first (ascending), then reverse hits (ascending)."""
+    buf = seq.encode("ascii", "replace") if isinstance(seq, str) else bytes(seq)
+    h = ctypes.c_void_p()
+    nf, nr = ctypes.c_int64(), ctypes.c_int64()
+    _check(lib().gm_pam_count(buf, len(buf), pam.encode("ascii"), len(pam), 1 if five_prime else 0, guidelen,
+                              device, ctypes.byref(h), ctypes.byref(nf), ctypes.byref(nr)))
+    try:
+        n = nf.value + nr.value
+        packed = np.empty((n,), np.uint64)
+        tstart = np.empty((n,), np.int64)
+        mstart = np.empty((n,), np.int64)
+        if n:
+            _check(lib().gm_pam_emit(h, _ptr(packed), _ptr(tstart), _ptr(mstart)))
+    finally:
+        lib().gm_pam_free(h)
+    return packed, tstart, mstart, int(nf.value)
 
 
 def device_count():

@@ -115,6 +115,43 @@ def scan_targets(seq: str, pam: str, pam_orientation: str, target_len: int):
     return {k: np.concatenate(v) for k, v in out.items()}
 
 
+def scan_targets_gpu(seq: str, pam: str, pam_orientation: str, target_len: int, device: int = 0):
+    """The same scan on the GPU (libgmhip gm_pam_count / gm_pam_emit).  Returns the dict of scan_targets
+    with 'packed' (uint64, the boundary format of include/gmhip.h) in place of 'codes'."""
+    five = pam_orientation == "5prime"
+    packed, tstart, mstart, n_fwd = _lib.pam_scan(seq, pam, five, target_len, device)
+    strand = np.zeros(packed.shape, dtype=bool)
+    strand[:n_fwd] = True
+    return {"packed": packed, "start": tstart, "stop": tstart + target_len, "strand": strand,
+            "mstart": mstart, "mend": mstart + len(pam)}
+
+
+_RC_BYTES = np.arange(256, dtype=np.uint8)
+for _a, _b in zip(b"ACGTMRWSYKVHDBXNacgtmrwsykvhdbxn", b"TGCAKYWSRMBDHVXNtgcakywsrmbdhvxn"):
+    _RC_BYTES[_a] = _b
+
+
+def _cut_windows(seq: str, lo: np.ndarray, width: int, forward: np.ndarray) -> List[str]:
+    """seq[lo:lo+width] per row (reverse-complemented where forward is False) as a list of str.
+    Windows inside the record are gathered in one numpy pass; the few that are not fall back to
+    python slicing so that its wrap/clip behaviour is reproduced exactly."""
+    n = len(seq)
+    buf = np.frombuffer(seq.encode("ascii", "replace"), dtype=np.uint8)
+    inside = (lo >= 0) & (lo + width <= n)
+    out = np.empty(lo.shape, dtype=object)
+    if inside.any():
+        idx = lo[inside][:, None] + np.arange(width)[None, :]
+        win = buf[idx]
+        rev = ~forward[inside]
+        win[rev] = _RC_BYTES[win[rev]][:, ::-1]
+        out[inside] = np.ascontiguousarray(win).view("S%d" % width).ravel().astype(str)
+    for i in np.flatnonzero(~inside).tolist():
+        a = int(lo[i])
+        piece = seq[a:a + width]
+        out[i] = piece if forward[i] else reverse_complement(piece)
+    return out.tolist()
+
+
 def codes_to_strings(codes: np.ndarray) -> List[str]:
     if codes.shape[0] == 0:
         return []
@@ -148,24 +185,28 @@ class PamTarget:
         """All targets next to the PAM on both strands, as the reference's dataframe."""
         five = self.pam_orientation == "5prime"
         frames = []
+        # the PAM scan runs on the GPU when one is visible (and the guide fits the packed format);
+        # the numpy scanner is the host implementation of the same step
+        on_gpu = target_len <= _lib.MAX_GUIDELEN and len(self.pam) <= 16 and _lib.device_count() > 0
         for record in seq_record_iter:
             seq = str(record.seq)
-            res = scan_targets(seq, self.pam, self.pam_orientation, target_len)
+            if on_gpu:
+                res = scan_targets_gpu(seq, self.pam, self.pam_orientation, target_len)
+            else:
+                res = scan_targets(seq, self.pam, self.pam_orientation, target_len)
             if res["start"].size == 0:
                 continue
             strand = res["strand"]
             ms, me = res["mstart"], res["mend"]
-            # 30-mer context: python slice semantics (a negative start wraps, core.py:156,184,211,237)
+            # 30-mer context and exact PAM, cut out of the record as byte windows; rows whose window
+            # leaves the record keep python slice semantics (a negative start wraps, the end clips:
+            # core.py:156,184,211,237)
             lo = np.where(strand == five, ms - 3, me - 27)
-            seq30 = []
-            for a, fw in zip(lo.tolist(), strand.tolist()):
-                s30 = seq[a:a + 30]
-                seq30.append(s30 if fw else reverse_complement(s30))
-            pams = []
-            for a, b, fw in zip(ms.tolist(), me.tolist(), strand.tolist()):
-                pams.append(seq[a:b] if fw else reverse_complement(seq[a:b]))
+            seq30 = _cut_windows(seq, lo, 30, strand)
+            pams = _cut_windows(seq, ms, len(self.pam), strand)
             df = pd.DataFrame({
-                "target": codes_to_strings(res["codes"]),
+                "target": (_lib.unpack(res["packed"], target_len) if on_gpu
+                           else codes_to_strings(res["codes"])),
                 "exact_pam": pams,
                 "start": res["start"], "stop": res["stop"], "strand": strand,
                 "pam_orientation": np.full(strand.shape, five, dtype=bool),

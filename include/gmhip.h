@@ -93,6 +93,20 @@ int gm_cfd_batch(const uint64_t* guides, const uint64_t* offs, int64_t n_pairs, 
 int gm_cfd_batch_dev(const void* d_guides, const void* d_offs, int64_t n_pairs, int guidelen,
                      const void* d_mm, void* d_out, void* stream);
 
+/* PAM scan + target extraction (replaces the regex loops of PamTarget.find_targets,
+ * guidemaker/core.py:142-246).  seq: n upper-case ASCII bases of ONE record; pam: IUPAC string;
+ * five_prime: 1 = 5'-[pam][target]-3', 0 = 5'-[target][pam]-3'.  gm_pam_count uploads the record, finds
+ * every (overlapping) PAM occurrence on both strands whose adjacent guidelen-mer lies inside the record
+ * and is pure ACGT, and returns the number of forward / reverse hits; gm_pam_emit writes, forward hits
+ * (ascending) first, then reverse hits (ascending): the packed target (reverse-complemented for the
+ * minus strand), the target's start coordinate and the PAM match's start coordinate, all on the
+ * forward strand.  Arrays must hold n_fwd + n_rev elements. */
+typedef struct gm_scan gm_scan;
+int gm_pam_count(const char* seq, int64_t n, const char* pam, int pam_len, int five_prime, int guidelen,
+                 int device, gm_scan** out, int64_t* n_fwd, int64_t* n_rev);
+int gm_pam_emit(gm_scan* scan, uint64_t* packed, int64_t* tstart, int64_t* mstart);
+void gm_pam_free(gm_scan* scan);
+
 /* Measurement hooks: HIP-event duration (ms) of the dominant scan kernel of the last query on this
  * handle (blocks until that kernel has finished), its name, and the pairs it evaluated. */
 double gm_last_kernel_ms(gm_index* idx);
