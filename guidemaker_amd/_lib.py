@@ -62,6 +62,8 @@ def lib():
     L.gm_cfd_batch_dev.argtypes = [vp, vp, i64, i32, vp, vp, vp]
     L.gm_last_kernel_ms.argtypes = [vp]
     L.gm_last_kernel_ms.restype = c.c_double
+    L.gm_last_query_ms.argtypes = [vp]
+    L.gm_last_query_ms.restype = c.c_double
     L.gm_last_kernel_name.argtypes = [vp]
     L.gm_last_kernel_name.restype = c.c_char_p
     L.gm_last_kernel_pairs.argtypes = [vp]
@@ -91,7 +93,7 @@ EXPORTS = [
     "gm_version", "gm_last_error", "gm_device_count", "gm_pack", "gm_unpack", "gm_index_create",
     "gm_index_create_dev", "gm_index_free", "gm_index_size", "gm_index_guidelen", "gm_index_metric",
     "gm_knn_query", "gm_knn_query_dev", "gm_nearest_dist", "gm_nearest_dist_dev", "gm_cfd_batch",
-    "gm_cfd_batch_dev", "gm_last_kernel_ms", "gm_last_kernel_name", "gm_last_kernel_pairs",
+    "gm_cfd_batch_dev", "gm_last_kernel_ms", "gm_last_query_ms", "gm_last_kernel_name", "gm_last_kernel_pairs",
     "gm_set_variant", "gm_timing_reserve", "gm_timing_read", "gm_pam_count", "gm_pam_emit", "gm_pam_free",
 ]
 
@@ -203,6 +205,10 @@ class Index:
     def nearest_dev(self, q_ptr, nq, d1_ptr, stream=None):
         _check(lib().gm_nearest_dist_dev(self._h, ctypes.c_void_p(q_ptr), nq, ctypes.c_void_p(d1_ptr),
                                          ctypes.c_void_p(stream or 0)))
+
+    def last_query_ms(self):
+        """Device time (ms) of every kernel the last knn / nearest call enqueued (HIP events)."""
+        return lib().gm_last_query_ms(self._h)
 
     def set_variant(self, v):
         _check(lib().gm_set_variant(self._h, v))

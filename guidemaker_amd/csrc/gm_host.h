@@ -22,8 +22,10 @@ struct gm_index {
     int64_t n_lk_tiles = 0;
     uint4* d_peq = nullptr;       // Levenshtein: match masks {A,C,G,T} per target (K2L), padded to LV_TILE
     int64_t n_lv_tiles = 0;
-    uint32_t* d_keys = nullptr;   // K2L scratch: per-segment k-lists [n_seg][n_q][KCAP]
+    uint32_t* d_keys = nullptr;   // K1L scratch: per-segment k-lists [n_seg][n_q][KCAP]
     int64_t keys_cap = 0;
+    uint32_t* d_keys2 = nullptr;  // K2L scratch (its Hamming seeder uses d_keys at the same time)
+    int64_t keys2_cap = 0;
     int64_t n_groups = 0;
     // workspaces (grow-only), so repeated queries do not allocate
     uint2* d_q = nullptr;
@@ -31,6 +33,7 @@ struct gm_index {
     void* d_stage = nullptr;      // host-pointer API: packed queries in / results out
     int64_t stage_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t evq0 = nullptr, evq1 = nullptr;   // around the whole query (all kernels of one gm_*_dev call)
     bool timed = false;
     std::vector<hipEvent_t> hist0, hist1;   // optional per-launch history (gm_timing_reserve)
     int64_t hist_count = 0;
@@ -54,9 +57,18 @@ inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 // K1L launchers, one per guide length (gm_inst_lk.hip)
 #define GM_FOR_EACH_LEN(X) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) \
     X(24) X(25) X(26) X(27)
-#define GM_DECL_LK(LEN)                                                                                   \
-    int gm_launch_lk_L##LEN(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t* ids, int32_t* dists, \
-                            int32_t* counts, hipStream_t st);
+// arguments of one K1L launch (see k_hamming_knn_lk): kcap = list capacity (1 = nearest distance, 0 = LDS
+// lists); single pass: n_seg = 1, tiles_per_seg = all tiles, out_keys = seed_keys = nullptr
+struct gm_lk_args {
+    int kcap = 10;
+    int64_t n_q = 0;
+    int k = 0;
+    int n_seg = 1, tiles_per_seg = 0, seg_base = 0;
+    const uint32_t* seed_keys = nullptr;
+    uint32_t* out_keys = nullptr;
+    int32_t *ids = nullptr, *dists = nullptr, *counts = nullptr;
+};
+#define GM_DECL_LK(LEN) int gm_launch_lk_L##LEN(gm_index* idx, const gm_lk_args* a, hipStream_t st);
 GM_FOR_EACH_LEN(GM_DECL_LK)
 #undef GM_DECL_LK
 

@@ -144,24 +144,4 @@ __global__ __launch_bounds__(WAVE) void k_leven_knn_lk(const uint4* __restrict__
     }
 }
 
-// fold the per-segment lists into the final top-k.  One thread per candidate.
-template <int KCAP>
-__global__ void k_leven_merge(const uint32_t* __restrict__ keys, int n_seg, int64_t n_q, int k,
-                              int32_t* __restrict__ ids, int32_t* __restrict__ dists,
-                              int32_t* __restrict__ counts, int nearest) {
-    const int64_t qi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (qi >= n_q) return;
-    RegList<KCAP> list;
-    list.init(k, nullptr, 0);
-    for (int s = 0; s < n_seg; ++s) {
-        const uint32_t* in = keys + ((int64_t)s * n_q + qi) * KCAP;
-#pragma unroll
-        for (int i = 0; i < KCAP; ++i) {
-            const uint32_t v = in[i];
-            if (v != 0u && v != RegList<KCAP>::EMPTY) list.insert(v - 1u);
-        }
-    }
-    list.store(k, qi, ids, dists, counts, nearest != 0);
-}
-
 }  // namespace gm

@@ -150,7 +150,7 @@ __device__ __forceinline__ void lk_set_bound(uint32_t (&Tb)[5], int L, int thr) 
 // slow path of one half group: walk this lane's hit bits in ascending id order
 template <int L, class List>
 __device__ __forceinline__ void lk_take_hits(uint32_t hits, const uint32_t (&c)[5], int id0, int n_db,
-                                             List& list, int& thr, uint32_t (&Tb)[5]) {
+                                             List& list, int& thr, int thr_seed, uint32_t (&Tb)[5]) {
     while (hits != 0u) {
         int j = __builtin_ctz(hits);
         hits &= hits - 1u;
@@ -160,7 +160,8 @@ __device__ __forceinline__ void lk_take_hits(uint32_t hits, const uint32_t (&c)[
         int id = id0 + j;
         if (d < thr && id < n_db) {
             list.insert(((uint32_t)d << ID_BITS) | (uint32_t)id);
-            const int nt = list.threshold(L);
+            int nt = list.threshold(L);
+            nt = nt < thr_seed ? nt : thr_seed;      // a seeded bound never loosens while the list fills
             if (nt != thr) {
                 thr = nt;
                 lk_set_bound(Tb, L, thr);
@@ -203,29 +204,38 @@ __device__ __forceinline__ void lk_read_group(LkGroupRegs<L>& r, const uint32_t*
 }
 template <int L, class List>
 __device__ __forceinline__ void lk_process_group(const LkGroupRegs<L>& r, int id0, int n_db, List& list, int& thr,
-                                                 uint32_t (&Tb)[5]) {
+                                                 int thr_seed, uint32_t (&Tb)[5]) {
     uint32_t c0[5], c1[5];
     uint32_t h0 = lk_eval_half<L>(r.m0, Tb, c0);
     uint32_t h1 = lk_eval_half<L>(r.m1, Tb, c1);
     if (__builtin_expect(__builtin_amdgcn_ballot_w64((h0 | h1) != 0u) != 0ull, 0)) {
-        lk_take_hits<L, List>(h0, c0, id0, n_db, list, thr, Tb);
-        lk_take_hits<L, List>(h1, c1, id0 + 32, n_db, list, thr, Tb);
+        lk_take_hits<L, List>(h0, c0, id0, n_db, list, thr, thr_seed, Tb);
+        lk_take_hits<L, List>(h1, c1, id0 + 32, n_db, list, thr, thr_seed, Tb);
     }
 }
 
-// K1L.  grid = ceil(n_q / 64) single-wave workgroups.  Dynamic LDS: 2 tiles (+ k * 64 * 4 B of lists when
-// KCAP == 0).  KCAP > 0: register-resident list of capacity KCAP >= k; KCAP == 0: LDS list (k <= 64).
-// NEAREST (k == 1): write only the nearest distance.
+// K1L.  grid = (ceil(n_q / 64), segments) single-wave workgroups.  Dynamic LDS: 2 tiles (+ k * 64 * 4 B of
+// lists when KCAP == 0).  KCAP > 0: register-resident list of capacity KCAP >= k; KCAP == 0: LDS list
+// (k <= 64, single segment only).  NEAREST (k == 1): write only the nearest distance.
+//
+// Segmented two-phase scan (out_keys != nullptr): the pool is cut into segments of `tiles_per_seg` tiles;
+// workgroup (x, y) scans segment seg_base + y for candidate chunk x and writes its raw k-list to
+// out_keys[segment][candidate][KCAP].  Phase A (SEEDED = false) scans segment 0 from scratch; phase B
+// (SEEDED = true) scans the other segments with the bound seeded from segment 0's list (k-th key of a
+// subset of the pool bounds the k-th key of the whole pool; later ids lose ties, so the strict test
+// d < seed is exact).  k_merge_lists folds the segment lists.  This gives chunks x segments equal work
+// items instead of `chunks` long ones: no half-empty last round, and small candidate sets fill the chip.
+//
 // register budget: for L <= 20 with a list of <= 10 keys the allocator lands 2 VGPRs above the 80 that allow
 // 6 waves/SIMD; asking for 6 costs no spills there (checked with -Rpass-analysis=kernel-resource-usage)
 __host__ __device__ constexpr int lk_min_waves(int L, int KCAP) { return (L <= 20 && KCAP <= 10) ? 6 : 1; }
 
-template <int L, int KCAP, bool NEAREST>
-__global__ __launch_bounds__(WAVE, lk_min_waves(L, KCAP)) void k_hamming_knn_lk(const uint32_t* __restrict__ table, int n_db,
-                                                         int n_tiles, const uint2* __restrict__ q, int64_t n_q,
-                                                         int k, int32_t* __restrict__ ids,
-                                                         int32_t* __restrict__ dists,
-                                                         int32_t* __restrict__ counts) {
+template <int L, int KCAP, bool NEAREST, bool SEEDED>
+__global__ __launch_bounds__(WAVE, lk_min_waves(L, KCAP)) void k_hamming_knn_lk(
+    const uint32_t* __restrict__ table, int n_db, int n_tiles, int tiles_per_seg, int seg_base,
+    const uint2* __restrict__ q, int64_t n_q, int k, const uint32_t* __restrict__ seed_keys,
+    uint32_t* __restrict__ out_keys, int32_t* __restrict__ ids, int32_t* __restrict__ dists,
+    int32_t* __restrict__ counts) {
     extern __shared__ __align__(16) uint32_t smem[];
     constexpr int TILE_W = lk_tile_bytes(L) / 4;         // words per tile
     constexpr int GW = lk_group_words(L);
@@ -246,15 +256,26 @@ __global__ __launch_bounds__(WAVE, lk_min_waves(L, KCAP)) void k_hamming_knn_lk(
     using List = typename std::conditional<(KCAP > 0), RegList<(KCAP > 0 ? KCAP : 1)>, LdsList>::type;
     List list;
     list.init(k, smem + 2 * TILE_W, lane);
-    int thr = valid ? L + 1 : 0;       // L + 1 accepts every distance until the list is full
+    int thr_seed = L + 1;              // L + 1 accepts every distance until the list is full
+    if constexpr (SEEDED && KCAP > 0) {
+        if (valid) {
+            const uint32_t top = seed_keys[qi * KCAP + (KCAP - 1)];
+            if (top != 0xffffffffu) thr_seed = (int)((top - 1u) >> ID_BITS);
+        }
+    }
+    int thr = valid ? thr_seed : 0;
     uint32_t Tb[5];
     lk_set_bound(Tb, L, thr);
 
+    const int seg = seg_base + (int)blockIdx.y;
+    const int t0 = seg * tiles_per_seg;                  // tiles_per_seg and n_tiles are even
+    const int t1 = t0 + tiles_per_seg < n_tiles ? t0 + tiles_per_seg : n_tiles;
+
     // single-wave workgroup: LDS operations of one wave execute in issue order, no barrier needed;
     // tile t+1 is DMA'd into the other buffer while tile t is evaluated.  The tile loop is unrolled by
-    // two so that the buffer offset is a compile-time constant (n_tiles is even).
-    lk_stage<L>(table, 0, tiles, lane);
-    for (int t = 0; t < n_tiles; t += 2) {
+    // two so that the buffer offset is a compile-time constant.
+    if (t0 < t1) lk_stage<L>(table, t0, tiles, lane);
+    for (int t = t0; t < t1; t += 2) {
         lk_stage_wait();                                               // tile t has landed in buffer 0
         lk_stage<L>(table, t + 1, tiles + TILE_W, lane);
 #pragma unroll
@@ -264,10 +285,10 @@ __global__ __launch_bounds__(WAVE, lk_min_waves(L, KCAP)) void k_hamming_knn_lk(
             if (gl == 1) lk_read_group<L, 1 * GW>(r, ptr);
             if (gl == 2) lk_read_group<L, 2 * GW>(r, ptr);
             if (gl == 3) lk_read_group<L, 3 * GW>(r, ptr);
-            lk_process_group<L, List>(r, (t * LK_TG + gl) * LK_GROUP, n_db, list, thr, Tb);
+            lk_process_group<L, List>(r, (t * LK_TG + gl) * LK_GROUP, n_db, list, thr, thr_seed, Tb);
         }
         lk_stage_wait();                                               // tile t+1 has landed in buffer 1
-        if (t + 2 < n_tiles) lk_stage<L>(table, t + 2, tiles, lane);
+        if (t + 2 < t1) lk_stage<L>(table, t + 2, tiles, lane);
 #pragma unroll
         for (int gl = 0; gl < LK_TG; ++gl) {
             LkGroupRegs<L> r;
@@ -275,11 +296,41 @@ __global__ __launch_bounds__(WAVE, lk_min_waves(L, KCAP)) void k_hamming_knn_lk(
             if (gl == 1) lk_read_group<L, TILE_W + 1 * GW>(r, ptr);
             if (gl == 2) lk_read_group<L, TILE_W + 2 * GW>(r, ptr);
             if (gl == 3) lk_read_group<L, TILE_W + 3 * GW>(r, ptr);
-            lk_process_group<L, List>(r, ((t + 1) * LK_TG + gl) * LK_GROUP, n_db, list, thr, Tb);
+            lk_process_group<L, List>(r, ((t + 1) * LK_TG + gl) * LK_GROUP, n_db, list, thr, thr_seed, Tb);
         }
     }
 
-    if (valid) list.store(k, qi, ids, dists, counts, NEAREST);
+    if (valid) {
+        if constexpr (KCAP > 0) {
+            if (out_keys != nullptr) {
+                uint32_t* out = out_keys + ((int64_t)seg * n_q + qi) * KCAP;
+#pragma unroll
+                for (int s = 0; s < KCAP; ++s) out[s] = list.v[s];
+                return;
+            }
+        }
+        list.store(k, qi, ids, dists, counts, NEAREST);
+    }
+}
+
+// fold per-segment raw RegList<KCAP> lists [n_seg][n_q][KCAP] into the final top-k.  One thread per candidate.
+template <int KCAP>
+__global__ void k_merge_lists(const uint32_t* __restrict__ keys, int n_seg, int64_t n_q, int k,
+                              int32_t* __restrict__ ids, int32_t* __restrict__ dists,
+                              int32_t* __restrict__ counts, int nearest) {
+    const int64_t qi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi >= n_q) return;
+    RegList<KCAP> list;
+    list.init(k, nullptr, 0);
+    for (int s = 0; s < n_seg; ++s) {
+        const uint32_t* in = keys + ((int64_t)s * n_q + qi) * KCAP;
+#pragma unroll
+        for (int i = 0; i < KCAP; ++i) {
+            const uint32_t v = in[i];
+            if (v != 0u && v != RegList<KCAP>::EMPTY) list.insert(v - 1u);
+        }
+    }
+    list.store(k, qi, ids, dists, counts, nearest != 0);
 }
 
 }  // namespace gm

@@ -85,14 +85,94 @@ int launch_leven_knn(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* d
     return GM_OK;
 }
 
-int launch_lk_by_len(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t* ids, int32_t* dists,
-                     int32_t* counts, hipStream_t st) {
+int launch_lk_len(gm_index* idx, const gm_lk_args& a, hipStream_t st) {
     switch (idx->L) {
-#define GM_CASE(LEN) case LEN: return gm_launch_lk_L##LEN(idx, nearest, n_q, k, ids, dists, counts, st);
+#define GM_CASE(LEN) case LEN: return gm_launch_lk_L##LEN(idx, &a, st);
         GM_FOR_EACH_LEN(GM_CASE)
 #undef GM_CASE
         default: return fail(GM_ERR_ARG, "look-up kernel: guidelen out of range");
     }
+}
+
+int timing_begin(gm_index* idx, hipStream_t st);
+int timing_end(gm_index* idx, hipStream_t st, int64_t pairs);
+
+int ensure_u32(uint32_t** buf, int64_t* cap, int64_t need) {
+    if (need <= *cap) return GM_OK;
+    if (*buf) (void)hipFree(*buf);
+    *buf = nullptr;
+    *cap = 0;
+    if (hipMalloc(buf, sizeof(uint32_t) * need) != hipSuccess)
+        return fail(GM_ERR_ALLOC, "hipMalloc(segment lists) failed");
+    *cap = need;
+    return GM_OK;
+}
+
+int launch_merge(int kcap, const uint32_t* keys, int n_seg, int64_t n_q, int k, int32_t* ids, int32_t* dists,
+                 int32_t* counts, bool nearest, hipStream_t st) {
+    const dim3 grid((unsigned)((n_q + 255) / 256)), block(256);
+    const int nr = nearest ? 1 : 0;
+    switch (kcap) {
+        case 1: hipLaunchKernelGGL(gm::k_merge_lists<1>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
+        case 4: hipLaunchKernelGGL(gm::k_merge_lists<4>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
+        case 10: hipLaunchKernelGGL(gm::k_merge_lists<10>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
+        default: hipLaunchKernelGGL(gm::k_merge_lists<20>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return GM_OK;
+}
+
+// K1L Hamming scan of the candidates in idx->d_q.  nearest: k = 1, distances only (into dists).
+// timed: record the HIP events around the dominant launch (false when used as the Levenshtein seeder).
+int run_hamming_lookup(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t* ids, int32_t* dists,
+                       int32_t* counts, bool timed, hipStream_t st) {
+    gm_lk_args a;
+    a.kcap = nearest ? 1 : (idx->variant == 7 || k > 20 ? 0 : (k <= 4 ? 4 : (k <= 10 ? 10 : 20)));
+    a.n_q = n_q;
+    a.k = nearest ? 1 : k;
+    a.ids = ids;
+    a.dists = dists;
+    a.counts = counts;
+    const int64_t chunks = (n_q + gm::WAVE - 1) / gm::WAVE;
+    const int64_t n_tiles = idx->n_lk_tiles;                       // even
+    // work items wanted per resident wave slot: more items = smaller tail round, but every extra segment
+    // re-collects up to k keys and lengthens the merge, so fewer for long lists (measured on S1-sized
+    // pools, profiles/r01/NOTES.md: best segment count 32+ / 8 / 6 / 4 for list capacity 1 / 4 / 10 / 20)
+    const int per_slot = a.kcap == 1 ? 40 : (a.kcap == 4 ? 14 : (a.kcap == 10 ? 10 : 7));
+    const int64_t want_items = (int64_t)idx->n_simd * 5 * per_slot;
+    int64_t n_seg = (want_items + chunks - 1) / chunks;
+    if (n_seg > n_tiles / 2) n_seg = n_tiles / 2;
+    if (n_seg > 512) n_seg = 512;
+    if (idx->variant >= 50 && idx->variant < 100) n_seg = idx->variant - 50;     // A/B knob: force the segment count
+    int rc;
+    if (a.kcap == 0 || n_seg < 2 || idx->variant == 9) {           // single pass over the whole pool
+        a.n_seg = 1;
+        a.tiles_per_seg = (int)n_tiles;
+        if (timed && (rc = timing_begin(idx, st))) return rc;
+        idx->last_kernel = nearest ? "k_hamming_knn_lk(nearest)" : "k_hamming_knn_lk";
+        if ((rc = launch_lk_len(idx, a, st))) return rc;
+        return timed ? timing_end(idx, st, n_q * idx->n_db) : GM_OK;
+    }
+    // two-phase segmented scan: segment 0 unseeded, the others seeded from it, then merge
+    int64_t tps = (n_tiles + n_seg - 1) / n_seg;
+    tps += tps & 1;
+    n_seg = (n_tiles + tps - 1) / tps;
+    if ((rc = ensure_u32(&idx->d_keys, &idx->keys_cap, n_seg * n_q * a.kcap))) return rc;
+    a.tiles_per_seg = (int)tps;
+    a.out_keys = idx->d_keys;
+    a.n_seg = 1;
+    a.seg_base = 0;
+    if ((rc = launch_lk_len(idx, a, st))) return rc;               // phase A
+    a.n_seg = (int)n_seg - 1;
+    a.seg_base = 1;
+    a.seed_keys = idx->d_keys;
+    if (timed && (rc = timing_begin(idx, st))) return rc;
+    idx->last_kernel = nearest ? "k_hamming_knn_lk(nearest,seeded)" : "k_hamming_knn_lk(seeded)";
+    if ((rc = launch_lk_len(idx, a, st))) return rc;               // phase B: the dominant launch
+    const int64_t seg0 = tps * gm::LK_TG * gm::LK_GROUP;          // pool targets covered by segment 0
+    const int64_t in_b = idx->n_db > seg0 ? idx->n_db - seg0 : 0;
+    if (timed && (rc = timing_end(idx, st, n_q * in_b))) return rc;
+    return launch_merge(a.kcap, idx->d_keys, (int)n_seg, n_q, a.k, ids, dists, counts, nearest, st);
 }
 
 int launch_lv_by_len(gm_index* idx, int kcap, int64_t n_q, int k, int n_seg, int tiles_per_seg,
@@ -106,24 +186,6 @@ int launch_lv_by_len(gm_index* idx, int kcap, int64_t n_q, int k, int n_seg, int
     }
 }
 
-int launch_lv_merge(int kcap, const uint32_t* keys, int n_seg, int64_t n_q, int k, int32_t* ids, int32_t* dists,
-                    int32_t* counts, bool nearest, hipStream_t st) {
-    const dim3 grid((unsigned)((n_q + 255) / 256)), block(256);
-    switch (kcap) {
-        case 1: hipLaunchKernelGGL(gm::k_leven_merge<1>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nearest ? 1 : 0); break;
-        case 4: hipLaunchKernelGGL(gm::k_leven_merge<4>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nearest ? 1 : 0); break;
-        case 10: hipLaunchKernelGGL(gm::k_leven_merge<10>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nearest ? 1 : 0); break;
-        default: hipLaunchKernelGGL(gm::k_leven_merge<20>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nearest ? 1 : 0); break;
-    }
-    HIP_TRY(hipGetLastError());
-    return GM_OK;
-}
-
-int timing_begin(gm_index* idx, hipStream_t st);
-int timing_end(gm_index* idx, hipStream_t st, int64_t pairs);
-int launch_lk_by_len(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t* ids, int32_t* dists,
-                     int32_t* counts, hipStream_t st);
-
 // K2L pipeline: (1) Hamming k-NN with K1L -> seeds (lev <= hamming) written into the caller's output
 // buffers, (2) segmented Levenshtein scan into scratch lists, (3) merge into the output buffers.
 // The query planes are already in idx->d_q.  d1 != nullptr: nearest-distance form (k = 1).
@@ -136,8 +198,8 @@ int run_leven_lookup(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* d
                      int32_t* d1, hipStream_t st) {
     const bool nearest = d1 != nullptr;
     const int kcap = nearest ? 1 : (k <= 4 ? 4 : (k <= 10 ? 10 : 20));
-    int rc = nearest ? launch_lk_by_len(idx, true, n_q, 1, nullptr, d1, nullptr, st)
-                     : launch_lk_by_len(idx, false, n_q, k, ids, dists, counts, st);
+    int rc = nearest ? run_hamming_lookup(idx, true, n_q, 1, nullptr, d1, nullptr, false, st)
+                     : run_hamming_lookup(idx, false, n_q, k, ids, dists, counts, false, st);
     if (rc) return rc;
     // enough (chunk, segment) workgroups to fill the chip several times over, segments of whole tiles
     const int64_t chunks = (n_q + gm::WAVE - 1) / gm::WAVE;
@@ -146,30 +208,23 @@ int run_leven_lookup(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* d
     if (want > idx->n_lv_tiles) want = idx->n_lv_tiles;
     const int tiles_per_seg = (int)((idx->n_lv_tiles + want - 1) / want);
     const int n_seg = (int)((idx->n_lv_tiles + tiles_per_seg - 1) / tiles_per_seg);
-    const int64_t need = (int64_t)n_seg * n_q * kcap;
-    if (need > idx->keys_cap) {
-        if (idx->d_keys) (void)hipFree(idx->d_keys);
-        idx->d_keys = nullptr;
-        idx->keys_cap = 0;
-        if (hipMalloc(&idx->d_keys, sizeof(uint32_t) * need) != hipSuccess)
-            return fail(GM_ERR_ALLOC, "hipMalloc(segment lists) failed");
-        idx->keys_cap = need;
-    }
+    // own scratch: the Hamming seeder enqueued above may still be using idx->d_keys
+    if ((rc = ensure_u32(&idx->d_keys2, &idx->keys2_cap, (int64_t)n_seg * n_q * kcap))) return rc;
     rc = timing_begin(idx, st);
     if (rc) return rc;
     idx->last_kernel = nearest ? "k_leven_knn_lk(nearest)" : "k_leven_knn_lk";
-    rc = nearest ? launch_lv_by_len(idx, kcap, n_q, 1, n_seg, tiles_per_seg, d1, nullptr, 1, idx->d_keys, st)
-                 : launch_lv_by_len(idx, kcap, n_q, k, n_seg, tiles_per_seg, dists, counts, k, idx->d_keys, st);
+    rc = nearest ? launch_lv_by_len(idx, kcap, n_q, 1, n_seg, tiles_per_seg, d1, nullptr, 1, idx->d_keys2, st)
+                 : launch_lv_by_len(idx, kcap, n_q, k, n_seg, tiles_per_seg, dists, counts, k, idx->d_keys2, st);
     if (rc) return rc;
     rc = timing_end(idx, st, n_q * idx->n_db);
     if (rc) return rc;
-    return nearest ? launch_lv_merge(kcap, idx->d_keys, n_seg, n_q, 1, nullptr, d1, nullptr, true, st)
-                   : launch_lv_merge(kcap, idx->d_keys, n_seg, n_q, k, ids, dists, counts, false, st);
+    return nearest ? launch_merge(kcap, idx->d_keys2, n_seg, n_q, 1, nullptr, d1, nullptr, true, st)
+                   : launch_merge(kcap, idx->d_keys2, n_seg, n_q, k, ids, dists, counts, false, st);
 }
 
 // variant 0 = default (K1L look-up kernel), 1 = popcount kernel K1, 5 and 2x/3x = K1v knobs
 bool use_lookup(const gm_index* idx) {
-    return idx->metric == GM_METRIC_HAMMING && idx->d_onehot != nullptr && (idx->variant == 0 || idx->variant == 7 || (idx->variant >= 40 && idx->variant < 50));
+    return idx->metric == GM_METRIC_HAMMING && idx->d_onehot != nullptr && (idx->variant == 0 || idx->variant == 7 || idx->variant == 9 || (idx->variant >= 40 && idx->variant < 100));
 }
 
 bool use_bitslice(const gm_index* idx) {
@@ -326,7 +381,8 @@ int gm_index_create_dev(const void* d_packed, int64_t n_db, int guidelen, int me
             }
         }
     }
-    if (hipEventCreate(&idx->ev0) != hipSuccess || hipEventCreate(&idx->ev1) != hipSuccess) {
+    if (hipEventCreate(&idx->ev0) != hipSuccess || hipEventCreate(&idx->ev1) != hipSuccess ||
+        hipEventCreate(&idx->evq0) != hipSuccess || hipEventCreate(&idx->evq1) != hipSuccess) {
         gm_index_free(idx);
         return fail(GM_ERR_DEVICE, "hipEventCreate failed");
     }
@@ -373,9 +429,12 @@ void gm_index_free(gm_index* idx) {
     if (idx->d_onehot) (void)hipFree(idx->d_onehot);
     if (idx->d_peq) (void)hipFree(idx->d_peq);
     if (idx->d_keys) (void)hipFree(idx->d_keys);
+    if (idx->d_keys2) (void)hipFree(idx->d_keys2);
     if (idx->d_q) (void)hipFree(idx->d_q);
     if (idx->d_stage) (void)hipFree(idx->d_stage);
     timing_clear(idx);
+    if (idx->evq0) (void)hipEventDestroy(idx->evq0);
+    if (idx->evq1) (void)hipEventDestroy(idx->evq1);
     if (idx->ev0) (void)hipEventDestroy(idx->ev0);
     if (idx->ev1) (void)hipEventDestroy(idx->ev1);
     delete idx;
@@ -391,8 +450,22 @@ int gm_set_variant(gm_index* idx, int variant) {
     return GM_OK;
 }
 
+static int knn_query_dev_impl(gm_index* idx, const void* d_q, int64_t n_q, int k, void* d_ids, void* d_dists,
+                              void* d_counts, void* stream);
+
 int gm_knn_query_dev(gm_index* idx, const void* d_q, int64_t n_q, int k, void* d_ids, void* d_dists,
                      void* d_counts, void* stream) {
+    if (check_index(idx)) return GM_ERR_ARG;
+    HIP_TRY(hipSetDevice(idx->device));
+    HIP_TRY(hipEventRecord(idx->evq0, reinterpret_cast<hipStream_t>(stream)));
+    int rc = knn_query_dev_impl(idx, d_q, n_q, k, d_ids, d_dists, d_counts, stream);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(idx->evq1, reinterpret_cast<hipStream_t>(stream)));
+    return GM_OK;
+}
+
+static int knn_query_dev_impl(gm_index* idx, const void* d_q, int64_t n_q, int k, void* d_ids, void* d_dists,
+                              void* d_counts, void* stream) {
     if (check_index(idx)) return GM_ERR_ARG;
     if (n_q < 0 || k < 1 || k > GM_MAX_K) return fail(GM_ERR_ARG, "gm_knn_query: need n_q >= 0, 1 <= k <= 64");
     if (n_q == 0) return GM_OK;
@@ -413,13 +486,11 @@ int gm_knn_query_dev(gm_index* idx, const void* d_q, int64_t n_q, int k, void* d
     rc = planes_launch(static_cast<const uint64_t*>(d_q), idx->d_q, n_q, n_q, st);
     if (rc) return rc;
     if (use_leven_lookup(idx, k)) return run_leven_lookup(idx, n_q, k, ids, dists, counts, nullptr, st);
+    if (use_lookup(idx)) return run_hamming_lookup(idx, false, n_q, k, ids, dists, counts, true, st);
     rc = timing_begin(idx, st);
     if (rc) return rc;
     const int R = pick_r(k);
-    if (use_lookup(idx)) {
-        idx->last_kernel = "k_hamming_knn_lk";
-        rc = launch_lk_by_len(idx, false, n_q, k, ids, dists, counts, st);
-    } else if (use_bitslice(idx)) {
+    if (use_bitslice(idx)) {
         idx->last_kernel = "k_hamming_knn_bs";
         rc = gm_launch_bs20(idx, false, n_q, k, ids, dists, counts, st);
     } else if (idx->metric == GM_METRIC_HAMMING) {
@@ -459,7 +530,19 @@ int gm_knn_query(gm_index* idx, const uint64_t* q, int64_t n_q, int k, int32_t* 
     return GM_OK;
 }
 
+static int nearest_dist_dev_impl(gm_index* idx, const void* d_q, int64_t n_q, void* d_d1, void* stream);
+
 int gm_nearest_dist_dev(gm_index* idx, const void* d_q, int64_t n_q, void* d_d1, void* stream) {
+    if (check_index(idx)) return GM_ERR_ARG;
+    HIP_TRY(hipSetDevice(idx->device));
+    HIP_TRY(hipEventRecord(idx->evq0, reinterpret_cast<hipStream_t>(stream)));
+    int rc = nearest_dist_dev_impl(idx, d_q, n_q, d_d1, stream);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(idx->evq1, reinterpret_cast<hipStream_t>(stream)));
+    return GM_OK;
+}
+
+static int nearest_dist_dev_impl(gm_index* idx, const void* d_q, int64_t n_q, void* d_d1, void* stream) {
     if (check_index(idx)) return GM_ERR_ARG;
     if (n_q < 0) return fail(GM_ERR_ARG, "gm_nearest_dist: n_q < 0");
     if (n_q == 0) return GM_OK;
@@ -476,14 +559,11 @@ int gm_nearest_dist_dev(gm_index* idx, const void* d_q, int64_t n_q, void* d_d1,
     rc = planes_launch(static_cast<const uint64_t*>(d_q), idx->d_q, n_q, n_q, st);
     if (rc) return rc;
     if (use_leven_lookup(idx, 1)) return run_leven_lookup(idx, n_q, 1, nullptr, nullptr, nullptr, d1, st);
+    if (use_lookup(idx)) return run_hamming_lookup(idx, true, n_q, 1, nullptr, d1, nullptr, true, st);
     int n_tiles = (int)(idx->n_db_pad / gm::TILE);
     rc = timing_begin(idx, st);
     if (rc) return rc;
-    if (use_lookup(idx)) {
-        idx->last_kernel = "k_hamming_knn_lk(nearest)";
-        rc = launch_lk_by_len(idx, true, n_q, 1, nullptr, d1, nullptr, st);
-        if (rc) return rc;
-    } else if (use_bitslice(idx)) {
+    if (use_bitslice(idx)) {
         idx->last_kernel = "k_hamming_knn_bs(nearest)";
         rc = gm_launch_bs20(idx, true, n_q, 1, nullptr, d1, nullptr, st);
         if (rc) return rc;
@@ -605,6 +685,15 @@ int gm_timing_read(gm_index* idx, double* ms_out, int max_n) {
         ms_out[n] = (double)ms;
     }
     return n;
+}
+
+double gm_last_query_ms(gm_index* idx) {
+    if (!idx || !idx->evq0) return -1.0;
+    if (hipSetDevice(idx->device) != hipSuccess) return -1.0;
+    if (hipEventSynchronize(idx->evq1) != hipSuccess) return -1.0;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, idx->evq0, idx->evq1) != hipSuccess) return -1.0;
+    return (double)ms;
 }
 
 const char* gm_last_kernel_name(gm_index* idx) { return idx ? idx->last_kernel : ""; }

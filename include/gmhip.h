@@ -110,6 +110,9 @@ void gm_pam_free(gm_scan* scan);
 /* Measurement hooks: HIP-event duration (ms) of the dominant scan kernel of the last query on this
  * handle (blocks until that kernel has finished), its name, and the pairs it evaluated. */
 double gm_last_kernel_ms(gm_index* idx);
+/* HIP-event duration (ms) of the whole last gm_knn_query_dev / gm_nearest_dist_dev call on this handle:
+ * every kernel it enqueued (packing, all scan phases, merge), device time only. */
+double gm_last_query_ms(gm_index* idx);
 const char* gm_last_kernel_name(gm_index* idx);
 int64_t gm_last_kernel_pairs(gm_index* idx);
 
