@@ -39,7 +39,7 @@ template <int L>
 int launch_lk(gm_index* idx, const gm_lk_args& a, hipStream_t st) {
     switch (a.kcap) {
         case 1: return launch_lk_seed<L, 1, true>(idx, a, st);
-        case 4: return launch_lk_seed<L, 4, false>(idx, a, st);
+        case 5: return launch_lk_seed<L, 5, false>(idx, a, st);
         case 10: return launch_lk_seed<L, 10, false>(idx, a, st);
         case 20: return launch_lk_seed<L, 20, false>(idx, a, st);
         case 0: return launch_lk_cfg<L, 0, false, false>(idx, a, st);

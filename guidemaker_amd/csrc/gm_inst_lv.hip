@@ -30,7 +30,6 @@ int GM_CAT(gm_launch_lv_L, GM_LEN)(gm_index* idx, int kcap, int64_t n_q, int k, 
                                    hipStream_t st) {
     switch (kcap) {
         case 1: return launch_lv_cfg<GM_LEN, 1>(idx, n_q, k, n_seg, tiles_per_seg, seed_d, seed_c, seed_k, keys, st);
-        case 4: return launch_lv_cfg<GM_LEN, 4>(idx, n_q, k, n_seg, tiles_per_seg, seed_d, seed_c, seed_k, keys, st);
         case 10: return launch_lv_cfg<GM_LEN, 10>(idx, n_q, k, n_seg, tiles_per_seg, seed_d, seed_c, seed_k, keys, st);
         case 20: return launch_lv_cfg<GM_LEN, 20>(idx, n_q, k, n_seg, tiles_per_seg, seed_d, seed_c, seed_k, keys, st);
         default: return gm_fail(GM_ERR_ARG, "leven look-up kernel: unsupported list capacity");

@@ -114,7 +114,7 @@ int launch_merge(int kcap, const uint32_t* keys, int n_seg, int64_t n_q, int k, 
     const int nr = nearest ? 1 : 0;
     switch (kcap) {
         case 1: hipLaunchKernelGGL(gm::k_merge_lists<1>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
-        case 4: hipLaunchKernelGGL(gm::k_merge_lists<4>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
+        case 5: hipLaunchKernelGGL(gm::k_merge_lists<5>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
         case 10: hipLaunchKernelGGL(gm::k_merge_lists<10>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
         default: hipLaunchKernelGGL(gm::k_merge_lists<20>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
     }
@@ -127,7 +127,7 @@ int launch_merge(int kcap, const uint32_t* keys, int n_seg, int64_t n_q, int k, 
 int run_hamming_lookup(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t* ids, int32_t* dists,
                        int32_t* counts, bool timed, hipStream_t st) {
     gm_lk_args a;
-    a.kcap = nearest ? 1 : (idx->variant == 7 || k > 20 ? 0 : (k <= 4 ? 4 : (k <= 10 ? 10 : 20)));
+    a.kcap = nearest ? 1 : (idx->variant == 7 || k > 20 ? 0 : (k <= 5 ? 5 : (k <= 10 ? 10 : 20)));
     a.n_q = n_q;
     a.k = nearest ? 1 : k;
     a.ids = ids;
@@ -138,7 +138,7 @@ int run_hamming_lookup(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
     // work items wanted per resident wave slot: more items = smaller tail round, but every extra segment
     // re-collects up to k keys and lengthens the merge, so fewer for long lists (measured on S1-sized
     // pools, profiles/r01/NOTES.md: best segment count 32+ / 8 / 6 / 4 for list capacity 1 / 4 / 10 / 20)
-    const int per_slot = a.kcap == 1 ? 40 : (a.kcap == 4 ? 14 : (a.kcap == 10 ? 10 : 7));
+    const int per_slot = a.kcap == 1 ? 40 : (a.kcap == 5 ? 14 : (a.kcap == 10 ? 10 : 7));
     const int64_t want_items = (int64_t)idx->n_simd * 5 * per_slot;
     int64_t n_seg = (want_items + chunks - 1) / chunks;
     if (n_seg > n_tiles / 2) n_seg = n_tiles / 2;
@@ -197,7 +197,7 @@ bool use_leven_lookup(const gm_index* idx, int k) {
 int run_leven_lookup(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* dists, int32_t* counts,
                      int32_t* d1, hipStream_t st) {
     const bool nearest = d1 != nullptr;
-    const int kcap = nearest ? 1 : (k <= 4 ? 4 : (k <= 10 ? 10 : 20));
+    const int kcap = nearest ? 1 : (k <= 10 ? 10 : 20);    // (a capacity-5 instantiation measured slower than 10)
     int rc = nearest ? run_hamming_lookup(idx, true, n_q, 1, nullptr, d1, nullptr, false, st)
                      : run_hamming_lookup(idx, false, n_q, k, ids, dists, counts, false, st);
     if (rc) return rc;

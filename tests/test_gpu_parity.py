@@ -292,9 +292,9 @@ def test_short_guides_use_popcount_kernel(oracle, L):
         assert (counts == oc).all() and (dists == od).all() and (ids == oi).all(), (L, metric)
 
 
-@pytest.mark.parametrize("k", [1, 3, 4, 11, 21, 33, 64])
+@pytest.mark.parametrize("k", [1, 3, 5, 6, 11, 21, 33, 64])
 def test_list_capacity_boundaries(oracle, k):
-    # register lists hold k <= 4 / 10 / 20; beyond 20 the lists live in LDS (Hamming) or the
+    # register lists hold k <= 5 / 10 / 20; beyond 20 the lists live in LDS (Hamming) or the
     # plane-based kernel is used (Levenshtein)
     L = 20
     db = list(dict.fromkeys(random_pool(1500, L, seed=77, indel=True)))
