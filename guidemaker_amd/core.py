@@ -412,17 +412,22 @@ class TargetProcessor:
         return df
 
     @staticmethod
-    def _draw_control_seqs(count: int, length: int, gc: float) -> List[str]:
-        """`count` random sequences, consuming numpy's global RNG exactly like the reference's
-        per-sequence np.random.choice(["G","C","A","T"], size=length, p=...) calls (core.py:590-592):
-        choice() draws one uniform per base and maps it through the cumulative distribution."""
+    def _draw_control_codes(count: int, length: int, gc: float) -> np.ndarray:
+        """`count` random sequences as (count, length) base codes (A0 C1 G2 T3), consuming numpy's global
+        RNG exactly like the reference's per-sequence np.random.choice(["G","C","A","T"], size=length,
+        p=...) calls (core.py:590-592): choice() draws one uniform per base and maps it through the
+        cumulative distribution."""
         p = np.array([gc / 2, gc / 2, (1 - gc) / 2, (1 - gc) / 2], dtype=np.float64)
         cdf = p.cumsum()
         cdf /= cdf[-1]
         u = np.random.random_sample((count, length))
-        idx = cdf.searchsorted(u, side='right')
-        asc = np.frombuffer(b"GCAT", np.uint8)[idx]
-        return np.ascontiguousarray(asc).view("S%d" % length).ravel().astype(str).tolist()
+        idx = cdf.searchsorted(u, side='right')               # index into ["G", "C", "A", "T"]
+        return np.array([2, 1, 0, 3], dtype=np.uint8)[idx]
+
+    @staticmethod
+    def _draw_control_seqs(count: int, length: int, gc: float) -> List[str]:
+        """The same draw as strings."""
+        return codes_to_strings(TargetProcessor._draw_control_codes(count, length, gc))
 
     def get_control_seqs(self, seq_record_iter: object, configpath, length: int = 20, n: int = 10,
                          num_threads: int = 2) -> pd.DataFrame:
@@ -454,11 +459,13 @@ class TargetProcessor:
             # loop condition (and its walk off the end of the list) as in the reference, core.py:586
             while minimum_hmdist < MINIMUM_HMDIST or search_mult == MAX_CONTROL_SEARCH_MULTIPLE:
                 search_mult = CONTROL_SEARCH_MULTIPLE[sm_count]
-                seqs = self._draw_control_seqs(n * search_mult, length, gc)
-                d1 = self.nmslib_index.nearest(_lib.pack(seqs, length))
+                # candidates stay numeric (codes -> packed words) until the n winners are known: at the
+                # largest multiple this is 10^4 * n sequences
+                codes = self._draw_control_codes(n * search_mult, length, gc)
+                d1 = self.nmslib_index.nearest(pack_codes(codes))
                 # sorted(..., reverse=True, key=dist) is stable: ties stay in draw order
                 order = np.argsort(-d1.astype(np.int64), kind="stable")[0:n]
-                sort_seq = [seqs[i] for i in order.tolist()]
+                sort_seq = codes_to_strings(codes[order])
                 if hamming:
                     sort_dist = [float(d1[i]) for i in order.tolist()]   # reference: raw / 2 -> float
                 else:

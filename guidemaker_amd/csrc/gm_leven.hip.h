@@ -21,7 +21,7 @@
 
 namespace gm {
 
-constexpr int LV_TILE = 256;                 // pool targets per LDS tile (4 KiB)
+constexpr int LV_TILE = 128;                 // pool targets per LDS tile (2 KiB; two tiles double-buffer)
 constexpr int LV_UNROLL = 4;                 // targets per pointer bump
 
 // truth tables, index = (a << 2 | b << 1 | c)
@@ -47,6 +47,14 @@ __device__ __forceinline__ void lv_stage(const uint4* __restrict__ peq, int64_t 
         __builtin_amdgcn_global_load_lds(src + (r * WAVE + lane) * 4, dst + r * WAVE * 4, 16, 0, 0);
 }
 
+// x << 1 as x + x: on gfx950 v_lshlrev_b32 issues at half rate, v_add_u32 at full rate
+// (tools/valu_rate.hip); asm because the compiler canonicalises x + x back into a shift
+__device__ __forceinline__ uint32_t shl1(uint32_t x) {
+    uint32_t r;
+    asm("v_add_u32 %0, %1, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 // WOFF = constant word offset of the target inside the LDS window addressed by ptr[]
 template <int L, int WOFF>
 __device__ __forceinline__ int lv_distance(const uint32_t* const (&ptr)[L], uint32_t mask) {
@@ -62,9 +70,9 @@ __device__ __forceinline__ int lv_distance(const uint32_t* const (&ptr)[L], uint
         const uint32_t Xh = GM_BITOP3(t, Pv, Eq, TT_AXB_OR_C);
         uint32_t Ph = GM_BITOP3(Mv, Xh, Pv, TT_A_OR_NOR_BC);
         const uint32_t Mh = Pv & Xh;
-        Ph = (Ph << 1) | 1u;
+        Ph = shl1(Ph) | 1u;
         const uint32_t n = GM_BITOP3(Xv, Ph, Ph, TT_NOR_AB);
-        Pv = (Mh << 1) | n;
+        Pv = shl1(Mh) | n;
         Mv = Ph & Xv;
     }
     return L + __builtin_popcount(Pv & mask) - __builtin_popcount(Mv & mask);

@@ -43,6 +43,14 @@ __global__ void k_rate(unsigned* out, unsigned seed) {
         if constexpr (OP == 13) { OP8("v_pk_add_u16 %0, %0, %1") OP8("v_pk_add_u16 %0, %0, %2") }
         if constexpr (OP == 14) { OP8("v_mad_u32_u24 %0, %0, %1, %2") OP8("v_mad_u32_u24 %0, %0, %2, %1") }
         if constexpr (OP == 15) { OP8("v_sad_u8 %0, %0, %1, %2") OP8("v_sad_u8 %0, %0, %2, %1") }
+        if constexpr (OP == 16) { OP8("v_lshlrev_b32 %0, 1, %0") OP8("v_lshlrev_b32 %0, 1, %0") }
+        if constexpr (OP == 17) { OP8("v_lshl_add_u32 %0, %0, 1, %1") OP8("v_lshl_add_u32 %0, %0, 1, %2") }
+        if constexpr (OP == 18) { OP8("v_add_u32 %0, %0, %0") OP8("v_add_u32 %0, %0, %0") }
+        if constexpr (OP == 19) { OP8("v_lshrrev_b32 %0, 1, %0") OP8("v_lshrrev_b32 %0, 1, %0") }
+        if constexpr (OP == 20) { OP8("v_and_b32 %0, %1, %0") OP8("v_and_b32 %0, %2, %0") }
+        if constexpr (OP == 21) { OP8("v_or_b32 %0, 1, %0") OP8("v_or_b32 %0, 1, %0") }
+        if constexpr (OP == 22) { OP8("v_bfe_u32 %0, %0, 1, 5") OP8("v_bfe_u32 %0, %0, 1, 5") }
+        if constexpr (OP == 23) { OP8("v_sub_u32 %0, %1, %0") OP8("v_sub_u32 %0, %2, %0") }
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
 }
@@ -99,5 +107,13 @@ int main() {
     run<14>("v_mad_u32_u24", d_out, cus);
     run<15>("v_sad_u8", d_out, cus);
     run<8>("v_fma_f32", d_out, cus);
+    run<16>("v_lshlrev_b32", d_out, cus);
+    run<19>("v_lshrrev_b32", d_out, cus);
+    run<17>("v_lshl_add_u32", d_out, cus);
+    run<18>("v_add_u32 x,x,x", d_out, cus);
+    run<20>("v_and_b32", d_out, cus);
+    run<21>("v_or_b32 inline", d_out, cus);
+    run<22>("v_bfe_u32", d_out, cus);
+    run<23>("v_sub_u32", d_out, cus);
     return 0;
 }
