@@ -73,6 +73,10 @@ def lib():
     L.gm_timing_reserve.restype = i32
     L.gm_timing_read.argtypes = [vp, vp, i32]
     L.gm_timing_read.restype = i32
+    L.gm_pack_keys_dev.argtypes = [vp, vp, i64, i32, vp, vp]
+    L.gm_pack_keys_dev.restype = i32
+    L.gm_unpack_keys_dev.argtypes = [vp, i64, i32, vp, vp, vp, vp]
+    L.gm_unpack_keys_dev.restype = i32
     L.gm_pam_count.argtypes = [c.c_char_p, i64, c.c_char_p, i32, i32, i32, i32, c.POINTER(vp), c.POINTER(i64),
                                c.POINTER(i64)]
     L.gm_pam_count.restype = i32
@@ -95,6 +99,7 @@ EXPORTS = [
     "gm_knn_query", "gm_knn_query_dev", "gm_nearest_dist", "gm_nearest_dist_dev", "gm_cfd_batch",
     "gm_cfd_batch_dev", "gm_last_kernel_ms", "gm_last_query_ms", "gm_last_kernel_name", "gm_last_kernel_pairs",
     "gm_set_variant", "gm_timing_reserve", "gm_timing_read", "gm_pam_count", "gm_pam_emit", "gm_pam_free",
+    "gm_pack_keys_dev", "gm_unpack_keys_dev",
 ]
 
 
@@ -261,6 +266,17 @@ def pam_scan(seq, pam, five_prime, guidelen, device=0):
     finally:
         lib().gm_pam_free(h)
     return packed, tstart, mstart, int(nf.value)
+
+
+def pack_keys_dev(ids_ptr, dists_ptr, n_q, k, keys_ptr, stream=None):
+    _check(lib().gm_pack_keys_dev(ctypes.c_void_p(ids_ptr), ctypes.c_void_p(dists_ptr), n_q, k,
+                                  ctypes.c_void_p(keys_ptr), ctypes.c_void_p(stream or 0)))
+
+
+def unpack_keys_dev(keys_ptr, n_q, k, ids_ptr, dists_ptr, counts_ptr, stream=None):
+    _check(lib().gm_unpack_keys_dev(ctypes.c_void_p(keys_ptr), n_q, k, ctypes.c_void_p(ids_ptr),
+                                    ctypes.c_void_p(dists_ptr), ctypes.c_void_p(counts_ptr),
+                                    ctypes.c_void_p(stream or 0)))
 
 
 def device_count():

@@ -422,4 +422,33 @@ static __global__ void k_cfd(const uint64_t* __restrict__ guides, const uint64_t
     out[idx] = score;
 }
 
+// ---------------------------------------------------------------------------------------------
+// neighbour lists <-> one 32-bit key per neighbour ((dist << 27) | id, 0xffffffff = no neighbour):
+// the form that crosses xGMI in the multi-GPU all-gather (one tensor, 4 B per neighbour instead of
+// ids + dists + counts)
+// ---------------------------------------------------------------------------------------------
+static __global__ void k_pack_keys(const int32_t* __restrict__ ids, const int32_t* __restrict__ dists, int64_t n,
+                                   uint32_t* __restrict__ keys) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t id = ids[i], d = dists[i];
+    keys[i] = id < 0 ? 0xffffffffu : (((uint32_t)d << ID_BITS) | (uint32_t)id);
+}
+
+static __global__ void k_unpack_keys(const uint32_t* __restrict__ keys, int64_t n_q, int k,
+                                     int32_t* __restrict__ ids, int32_t* __restrict__ dists,
+                                     int32_t* __restrict__ counts) {
+    int64_t qi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi >= n_q) return;
+    int cnt = 0;
+    for (int s = 0; s < k; ++s) {
+        const uint32_t key = keys[qi * k + s];
+        const bool ok = key != 0xffffffffu;
+        ids[qi * k + s] = ok ? (int32_t)(key & ID_MASK) : -1;
+        dists[qi * k + s] = ok ? (int32_t)(key >> ID_BITS) : -1;
+        cnt += ok ? 1 : 0;
+    }
+    counts[qi] = cnt;
+}
+
 }  // namespace gm

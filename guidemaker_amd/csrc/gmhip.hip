@@ -644,6 +644,30 @@ int gm_cfd_batch(const uint64_t* guides, const uint64_t* offs, int64_t n_pairs, 
     return GM_OK;
 }
 
+int gm_pack_keys_dev(const void* d_ids, const void* d_dists, int64_t n_q, int k, void* d_keys, void* stream) {
+    if (n_q < 0 || k < 1) return fail(GM_ERR_ARG, "gm_pack_keys: bad argument");
+    if (n_q == 0) return GM_OK;
+    if (!d_ids || !d_dists || !d_keys) return fail(GM_ERR_ARG, "gm_pack_keys: null buffer");
+    const int64_t n = n_q * k;
+    hipLaunchKernelGGL(gm::k_pack_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), static_cast<const int32_t*>(d_ids),
+                       static_cast<const int32_t*>(d_dists), n, static_cast<uint32_t*>(d_keys));
+    HIP_TRY(hipGetLastError());
+    return GM_OK;
+}
+
+int gm_unpack_keys_dev(const void* d_keys, int64_t n_q, int k, void* d_ids, void* d_dists, void* d_counts,
+                       void* stream) {
+    if (n_q < 0 || k < 1) return fail(GM_ERR_ARG, "gm_unpack_keys: bad argument");
+    if (n_q == 0) return GM_OK;
+    if (!d_keys || !d_ids || !d_dists || !d_counts) return fail(GM_ERR_ARG, "gm_unpack_keys: null buffer");
+    hipLaunchKernelGGL(gm::k_unpack_keys, dim3((unsigned)((n_q + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), static_cast<const uint32_t*>(d_keys), n_q, k,
+                       static_cast<int32_t*>(d_ids), static_cast<int32_t*>(d_dists), static_cast<int32_t*>(d_counts));
+    HIP_TRY(hipGetLastError());
+    return GM_OK;
+}
+
 double gm_last_kernel_ms(gm_index* idx) {
     if (!idx || !idx->timed) return -1.0;
     if (hipSetDevice(idx->device) != hipSuccess) return -1.0;

@@ -3,10 +3,16 @@
 
 The path shards embarrassingly by candidate guide: every rank holds the whole
 target pool (replicated index), scans a contiguous, equally sized (padded) shard of the candidates,
-and ONE all-gather per result tensor (ids, dists, counts) gives every rank the full neighbour lists.
-Nothing is reduced and there is no second exchange.
+and ONE all-gather gives every rank the full neighbour lists.  Nothing is reduced and there is no
+second exchange.  What crosses xGMI is one 32-bit key per neighbour, (dist << 27) | id with
+0xffffffff = "no neighbour" (the kernels' own list format): 4 bytes per neighbour in a single tensor
+instead of ids + dists + counts.
 """
 import numpy as np
+
+ID_BITS = 27
+ID_MASK = (1 << ID_BITS) - 1
+EMPTY = -1            # 0xffffffff seen as int32
 
 
 def shard_range(n, world, rank):
@@ -30,19 +36,51 @@ def is_distributed():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
+def pack_keys(ids, dists):
+    """[n, k] int32 ids / dists (-1 = none) -> [n, k] int32 keys (bit pattern of the uint32 key)."""
+    import torch
+    if ids.is_cuda:
+        from . import _lib
+        keys = torch.empty_like(ids)
+        _lib.pack_keys_dev(ids.data_ptr(), dists.data_ptr(), ids.shape[0], ids.shape[1], keys.data_ptr(),
+                           torch.cuda.current_stream().cuda_stream)
+        return keys
+    keys = (dists.to(torch.int64) << ID_BITS) | ids.to(torch.int64)
+    keys = torch.where(ids < 0, torch.full_like(keys, 0xFFFFFFFF), keys)
+    return (keys & 0xFFFFFFFF).to(torch.int64).sub(((keys >> 31) & 1) << 32).to(torch.int32)
+
+
+def unpack_keys(keys):
+    """[n, k] int32 keys -> (ids [n,k], dists [n,k], counts [n]) int32."""
+    import torch
+    n, k = keys.shape
+    if keys.is_cuda:
+        from . import _lib
+        ids = torch.empty_like(keys)
+        dists = torch.empty_like(keys)
+        counts = torch.empty((n,), dtype=torch.int32, device=keys.device)
+        _lib.unpack_keys_dev(keys.data_ptr(), n, k, ids.data_ptr(), dists.data_ptr(), counts.data_ptr(),
+                             torch.cuda.current_stream().cuda_stream)
+        return ids, dists, counts
+    u = keys.to(torch.int64) & 0xFFFFFFFF
+    ok = u != 0xFFFFFFFF
+    ids = torch.where(ok, u & ID_MASK, torch.full_like(u, -1)).to(torch.int32)
+    dists = torch.where(ok, u >> ID_BITS, torch.full_like(u, -1)).to(torch.int32)
+    return ids, dists, ok.sum(dim=1).to(torch.int32)
+
+
 def all_gather_neighbors(ids, dists, counts, n_total, group=None):
-    """ids/dists: [per, k] int32 tensors (rows past the shard's end are padding), counts: [per].
-    Returns the gathered tensors trimmed to n_total rows.  One all_gather_into_tensor per tensor."""
+    """ids/dists: [per, k] int32 tensors of this rank's shard (rows past the shard's end are padding with
+    -1 everywhere), counts: [per] (implied by the -1 padding, not transmitted).  Returns the gathered
+    (ids, dists, counts) trimmed to n_total rows.  ONE all_gather_into_tensor of packed keys."""
     import torch
     dist = _dist()
     world = dist.get_world_size(group)
     per, k = ids.shape
-    g_ids = torch.empty((world * per, k), dtype=ids.dtype, device=ids.device)
-    g_dists = torch.empty((world * per, k), dtype=dists.dtype, device=dists.device)
-    g_counts = torch.empty((world * per,), dtype=counts.dtype, device=counts.device)
-    dist.all_gather_into_tensor(g_ids, ids.contiguous(), group=group)
-    dist.all_gather_into_tensor(g_dists, dists.contiguous(), group=group)
-    dist.all_gather_into_tensor(g_counts, counts.contiguous(), group=group)
+    keys = pack_keys(ids.contiguous(), dists.contiguous())
+    gathered = torch.empty((world * per, k), dtype=torch.int32, device=keys.device)
+    dist.all_gather_into_tensor(gathered, keys, group=group)
+    g_ids, g_dists, g_counts = unpack_keys(gathered)
     return g_ids[:n_total], g_dists[:n_total], g_counts[:n_total]
 
 

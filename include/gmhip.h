@@ -93,6 +93,13 @@ int gm_cfd_batch(const uint64_t* guides, const uint64_t* offs, int64_t n_pairs, 
 int gm_cfd_batch_dev(const void* d_guides, const void* d_offs, int64_t n_pairs, int guidelen,
                      const void* d_mm, void* d_out, void* stream);
 
+/* Neighbour lists as ONE 32-bit key per neighbour, (dist << 27) | id, 0xffffffff = none: the form that
+ * crosses xGMI in the multi-GPU all-gather (4 B per neighbour instead of ids + dists + counts).
+ * keys: [n_q * k] uint32.  Device pointers; enqueued on `stream`. */
+int gm_pack_keys_dev(const void* d_ids, const void* d_dists, int64_t n_q, int k, void* d_keys, void* stream);
+int gm_unpack_keys_dev(const void* d_keys, int64_t n_q, int k, void* d_ids, void* d_dists, void* d_counts,
+                       void* stream);
+
 /* PAM scan + target extraction (replaces the regex loops of PamTarget.find_targets,
  * guidemaker/core.py:142-246).  seq: n upper-case ASCII bases of ONE record; pam: IUPAC string;
  * five_prime: 1 = 5'-[pam][target]-3', 0 = 5'-[target][pam]-3'.  gm_pam_count uploads the record, finds

@@ -72,3 +72,15 @@ def test_shard_range_covers_everything():
 
 def test_not_distributed_by_default():
     assert not distributed.is_distributed()
+
+
+def test_key_packing_roundtrip_cpu():
+    ids = torch.tensor([[0, 5, -1], [(1 << 27) - 1, 7, 9], [-1, -1, -1]], dtype=torch.int32)
+    dists = torch.tensor([[0, 3, -1], [27, 16, 20], [-1, -1, -1]], dtype=torch.int32)
+    keys = distributed.pack_keys(ids, dists)
+    assert keys.dtype == torch.int32
+    assert (keys.to(torch.int64) & 0xFFFFFFFF).tolist() == [
+        [0, (3 << 27) | 5, 0xFFFFFFFF], [(27 << 27) | ((1 << 27) - 1), (16 << 27) | 7, (20 << 27) | 9],
+        [0xFFFFFFFF] * 3]
+    i2, d2, c2 = distributed.unpack_keys(keys)
+    assert (i2 == ids).all() and (d2 == dists).all() and c2.tolist() == [2, 3, 0]

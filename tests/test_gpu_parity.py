@@ -370,3 +370,22 @@ def test_pam_scan_gpu_matches_host_scanner(pam, orient, L):
         d = core.scan_targets_gpu(short, pam, orient, L)
         h = core.scan_targets(short, pam, orient, L)
         assert d["packed"].shape[0] == h["codes"].shape[0] == 0
+
+
+def test_key_packing_device_matches_host():
+    import torch
+    from guidemaker_amd import distributed
+    rng = np.random.default_rng(3)
+    n, k = 1000, 10
+    ids = rng.integers(0, 1 << 27, size=(n, k)).astype(np.int32)
+    dists = rng.integers(0, 28, size=(n, k)).astype(np.int32)
+    cnt = rng.integers(0, k + 1, size=n)
+    for r in range(n):
+        ids[r, cnt[r]:] = -1
+        dists[r, cnt[r]:] = -1
+    ti, td = torch.from_numpy(ids), torch.from_numpy(dists)
+    want = distributed.pack_keys(ti, td)
+    got = distributed.pack_keys(ti.cuda(), td.cuda())
+    assert (got.cpu() == want).all()
+    gi, gd, gc = distributed.unpack_keys(got)
+    assert (gi.cpu() == ti).all() and (gd.cpu() == td).all() and (gc.cpu().numpy() == cnt).all()
