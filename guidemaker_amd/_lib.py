@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgmhip.so")
+LIB_PATH = os.environ.get("GMHIP_LIB", os.path.join(_HERE, "libgmhip.so"))   # override: A/B builds of the library
 
 METRIC_HAMMING = 0
 METRIC_LEVEN = 1

@@ -15,6 +15,9 @@
 // comparator `matches >= L + 1 - thr` (<=> distance < thr) -> hit word; same slow path / k-lists as K1v.
 // Per 64 pairs per lane: 20 ds_read_b64 + 2 x (36 + 5) v_bitop3 + 1 v_cmp at L=20 (1.3 VALU ops/pair).
 #pragma once
+#ifndef GM_LK_W10
+#define GM_LK_W10 6     /* waves per SIMD asked for with a 5/10-key register list at L <= 20 */
+#endif
 #include "gm_bitslice.hip.h"
 #include <type_traits>
 
@@ -228,7 +231,7 @@ __device__ __forceinline__ void lk_process_group(const LkGroupRegs<L>& r, int id
 //
 // register budget: for L <= 20 with a list of <= 10 keys the allocator lands 2 VGPRs above the 80 that allow
 // 6 waves/SIMD; asking for 6 costs no spills there (checked with -Rpass-analysis=kernel-resource-usage)
-__host__ __device__ constexpr int lk_min_waves(int L, int KCAP) { return (L <= 20 && KCAP <= 10) ? 6 : 1; }
+__host__ __device__ constexpr int lk_min_waves(int L, int KCAP) { return (L <= 20 && KCAP == 1) ? 8 : ((L <= 20 && KCAP > 0 && KCAP <= 10) ? GM_LK_W10 : 1); }
 
 template <int L, int KCAP, bool NEAREST, bool SEEDED>
 __global__ __launch_bounds__(WAVE, lk_min_waves(L, KCAP)) void k_hamming_knn_lk(
