@@ -74,7 +74,7 @@ GM_FOR_EACH_LEN(GM_DECL_LK)
 
 // K2L launchers, one per guide length (gm_inst_lv.hip)
 #define GM_DECL_LV(LEN)                                                                                        \
-    int gm_launch_lv_L##LEN(gm_index* idx, int kcap, int64_t n_q, int k, int n_seg, int tiles_per_seg,          \
+    int gm_launch_lv_L##LEN(gm_index* idx, int algo, int kcap, int64_t n_q, int k, int n_seg, int tiles_per_seg, \
                             const int32_t* seed_d, const int32_t* seed_c, int seed_k, uint32_t* keys, hipStream_t st);
 GM_FOR_EACH_LEN(GM_DECL_LV)
 #undef GM_DECL_LV

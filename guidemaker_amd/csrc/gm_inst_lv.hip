@@ -1,6 +1,6 @@
 // gm_inst_lv.hip -- instantiates the K2L Levenshtein scan kernels for ONE guide length (-DGM_LEN=<L>).
 #include "gm_host.h"
-#include "gm_leven.hip.h"
+#include "gm_leven_bs.hip.h"
 
 #ifndef GM_LEN
 #error "compile with -DGM_LEN=<guide length>"
@@ -20,14 +20,35 @@ int launch_lv_cfg(gm_index* idx, int64_t n_q, int k, int n_seg, int tiles_per_se
     return GM_OK;
 }
 
+template <int L, int KCAP>
+int launch_lvb_cfg(gm_index* idx, int64_t n_q, int k, int n_seg, int tiles_per_seg, const int32_t* seed_d,
+                   const int32_t* seed_c, int seed_k, uint32_t* keys, hipStream_t st) {
+    const int64_t chunks = (n_q + gm::WAVE - 1) / gm::WAVE;
+    const size_t lds = 2 * (size_t)gm::lk_tile_bytes(L);
+    hipLaunchKernelGGL((gm::k_leven_knn_bs<L, KCAP>), dim3((unsigned)chunks, (unsigned)n_seg), dim3(gm::WAVE), lds, st,
+                       idx->d_onehot, (int)idx->n_db, (int)idx->n_lk_tiles, tiles_per_seg, idx->d_q, n_q, k, seed_d,
+                       seed_c, seed_k, keys);
+    HIP_TRY(hipGetLastError());
+    return GM_OK;
+}
+
 }  // namespace
 
 #define GM_CAT2(a, b) a##b
 #define GM_CAT(a, b) GM_CAT2(a, b)
 
-int GM_CAT(gm_launch_lv_L, GM_LEN)(gm_index* idx, int kcap, int64_t n_q, int k, int n_seg, int tiles_per_seg,
+// algo 0 = K2L (Myers per pair, match masks from LDS), 1 = K2B (bit-sliced DP over 32 targets per word)
+int GM_CAT(gm_launch_lv_L, GM_LEN)(gm_index* idx, int algo, int kcap, int64_t n_q, int k, int n_seg, int tiles_per_seg,
                                    const int32_t* seed_d, const int32_t* seed_c, int seed_k, uint32_t* keys,
                                    hipStream_t st) {
+    if (algo == 1) {
+        switch (kcap) {
+            case 1: return launch_lvb_cfg<GM_LEN, 1>(idx, n_q, k, n_seg, tiles_per_seg, seed_d, seed_c, seed_k, keys, st);
+            case 10: return launch_lvb_cfg<GM_LEN, 10>(idx, n_q, k, n_seg, tiles_per_seg, seed_d, seed_c, seed_k, keys, st);
+            case 20: return launch_lvb_cfg<GM_LEN, 20>(idx, n_q, k, n_seg, tiles_per_seg, seed_d, seed_c, seed_k, keys, st);
+            default: return gm_fail(GM_ERR_ARG, "leven bit-sliced kernel: unsupported list capacity");
+        }
+    }
     switch (kcap) {
         case 1: return launch_lv_cfg<GM_LEN, 1>(idx, n_q, k, n_seg, tiles_per_seg, seed_d, seed_c, seed_k, keys, st);
         case 10: return launch_lv_cfg<GM_LEN, 10>(idx, n_q, k, n_seg, tiles_per_seg, seed_d, seed_c, seed_k, keys, st);

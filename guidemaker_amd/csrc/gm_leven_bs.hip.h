@@ -1,0 +1,137 @@
+// gm_leven_bs.hip.h -- bit-sliced Levenshtein k-NN scan for gfx950 (K2B).
+//
+// K2L (gm_leven.hip.h) runs Myers' bit-vector algorithm per (candidate, target) pair: bits = rows of the
+// DP column, ~12 VALU ops per text position per pair.  K2B turns the problem by 90 degrees, like K1L did
+// for Hamming: bits = 32 pool TARGETS, lane = one candidate, and the unit-cost DP is evaluated cell by
+// cell with Myers/Hyyro's delta logic on 32-target words:
+//
+//   cell (i, j): i = candidate position (row), j = target position (column), deltas in {-1, 0, +1}
+//   encoded as (P, M) bit pairs;  Eq = "target j-th base == candidate i-th base" for 32 targets = ONE
+//   ds_read_b32 from the one-hot table K1L already uses (table[G][j][base_i][half]), per-lane address.
+//       D0  = Eq | Mv | Mh                    (diagonal stays)          v_bitop3
+//       Ph' = Mv | ~(D0 | Pv);  Mh' = Pv & D0  (horizontal delta out)   v_bitop3, v_and
+//       Pv' = Mh | ~(D0 | Ph);  Mv' = Ph & D0  (vertical delta out)     v_bitop3, v_and
+//   5 full-rate ops per cell for 32 pairs: 5 L^2 / 32 ops per pair (83 at L=23) against ~290 for K2L.
+//   Vertical deltas live in 2L VGPRs, the horizontal delta runs down the column in 2 VGPRs.
+//   distance = L + #P - #M over the last column's vertical deltas; s = #M - #P = L - distance >= 0 is
+//   formed bit-sliced (two carry-save trees + a 5-bit ripple subtract) and then goes through exactly
+//   the K1L threshold comparator / hit walk / register k-lists (s plays the role of "matches").
+// Same tiles (LDS-DMA, double buffered), Hamming-seeded bounds, chunks x segments grid and merge as K2L.
+#pragma once
+#include "gm_leven.hip.h"
+
+namespace gm {
+
+constexpr int TT_OR3 = (0xF0 | 0xCC | 0xAA) & 0xFF;                               // a | b | c
+constexpr int TT_SUB_DIFF = (0xF0 ^ 0xCC ^ 0xAA) & 0xFF;                          // a ^ b ^ borrow
+constexpr int TT_SUB_BORROW = ((~0xF0 & 0xCC) | (~(0xF0 ^ 0xCC) & 0xAA)) & 0xFF;  // (~a & b) | (~(a ^ b) & borrow)
+
+// DP of one half group (32 targets) against this lane's candidate.  ptr[i] = LDS address of
+// (column 0, base of candidate position i, half 0) of the group; HOFF = half (word offset).  On return
+// ptr[] has advanced by one group (L columns x 8 words) and c[0..4] holds the bits of s = L - distance.
+template <int L, int HOFF>
+__device__ __forceinline__ void lvb_eval_half(const uint32_t* (&ptr)[L], uint32_t (&c)[5]) {
+    uint32_t Pv[L], Mv[L];
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        Pv[i] = 0xffffffffu;      // D(i, 0) = i
+        Mv[i] = 0u;
+    }
+#pragma unroll 1
+    for (int j = 0; j < L; ++j) {
+        uint32_t Ph = 0xffffffffu, Mh = 0u;      // D(0, j) = j
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            const uint32_t Eq = ptr[i][HOFF];                                    // ds_read_b32, per-lane address
+            const uint32_t D0 = GM_BITOP3(Eq, Mv[i], Mh, TT_OR3);
+            const uint32_t Pho = GM_BITOP3(Mv[i], D0, Pv[i], TT_A_OR_NOR_BC);
+            const uint32_t Mho = Pv[i] & D0;
+            Pv[i] = GM_BITOP3(Mh, D0, Ph, TT_A_OR_NOR_BC);
+            Mv[i] = Ph & D0;
+            Ph = Pho;
+            Mh = Mho;
+        }
+#pragma unroll
+        for (int i = 0; i < L; ++i) ptr[i] += 8;                                 // next column
+    }
+    // s = #M - #P over the last column (>= 0 because the distance never exceeds L)
+    uint32_t cm[5], cp[5];
+    bitslice_count<L>(Mv, cm);
+    bitslice_count<L>(Pv, cp);
+    uint32_t borrow = 0u;
+#pragma unroll
+    for (int b = 0; b < 5; ++b) {
+        c[b] = GM_BITOP3(cm[b], cp[b], borrow, TT_SUB_DIFF);
+        borrow = GM_BITOP3(cm[b], cp[b], borrow, TT_SUB_BORROW);
+    }
+}
+
+// K2B scan.  grid = (ceil(n_q / 64), n_seg); tiles = the K1L one-hot table tiles (LK_TG groups of 64).
+// Dynamic LDS: 2 tiles.  seed_*: Hamming k-NN of the same candidates (lev <= hamming).
+// keys: [n_seg][n_q][KCAP] raw RegList contents, folded by k_merge_lists.
+template <int L, int KCAP>
+__global__ __launch_bounds__(WAVE) void k_leven_knn_bs(const uint32_t* __restrict__ table, int n_db, int n_tiles,
+                                                       int tiles_per_seg, const uint2* __restrict__ q,
+                                                       int64_t n_q, int k, const int32_t* __restrict__ seed_dists,
+                                                       const int32_t* __restrict__ seed_counts, int seed_k,
+                                                       uint32_t* __restrict__ keys) {
+    extern __shared__ __align__(16) uint32_t smem[];
+    constexpr int TILE_W = lk_tile_bytes(L) / 4;
+    constexpr int GW = lk_group_words(L);
+    const int lane = threadIdx.x;
+    const int seg = blockIdx.y;
+    const int64_t qi = (int64_t)blockIdx.x * WAVE + lane;
+    const bool valid = qi < n_q;
+    const uint2 qv = valid ? q[qi] : make_uint2(0u, 0u);
+
+    RegList<KCAP> list;
+    list.init(k, nullptr, lane);
+    int thr_seed = L + 1;
+    if (valid && seed_dists != nullptr && (seed_counts == nullptr || seed_counts[qi] >= seed_k))
+        thr_seed = seed_dists[qi * seed_k + (seed_k - 1)] + 1;      // lev <= hamming
+    if (thr_seed > L + 1) thr_seed = L + 1;
+    int thr = valid ? thr_seed : 0;
+    uint32_t Tb[5];
+    lk_set_bound(Tb, L, thr);
+
+    const int t0 = seg * tiles_per_seg;
+    const int t1 = t0 + tiles_per_seg < n_tiles ? t0 + tiles_per_seg : n_tiles;
+    if (t0 < t1) lk_stage<L>(table, t0, smem, lane);
+    for (int t = t0; t < t1; ++t) {
+        const uint32_t* cur = smem + ((t - t0) & 1) * TILE_W;
+        lk_stage_wait();                                               // tile t has landed
+        if (t + 1 < t1) lk_stage<L>(table, t + 1, smem + ((t - t0 + 1) & 1) * TILE_W, lane);
+        // LDS address of (group 0, column 0, base of candidate position i, half 0)
+        const uint32_t* ptr[L];
+#pragma unroll
+        for (int i = 0; i < L; ++i) {
+            const uint32_t code = ((qv.x >> i) & 1u) | (((qv.y >> i) & 1u) << 1);
+            ptr[i] = cur + code * 2;
+        }
+        for (int gl = 0; gl < LK_TG; ++gl) {
+            uint32_t c0[5], c1[5];
+            lvb_eval_half<L, 0>(ptr, c0);                              // ptr: -> next group
+#pragma unroll
+            for (int i = 0; i < L; ++i) ptr[i] -= GW;                  // back to this group for the other half
+            lvb_eval_half<L, 1>(ptr, c1);
+            uint32_t h0 = GM_BITOP3(c0[0], Tb[0], Tb[0], TT_A_OR_NOTB), h1 = GM_BITOP3(c1[0], Tb[0], Tb[0], TT_A_OR_NOTB);
+#pragma unroll
+            for (int b = 1; b < 5; ++b) {
+                h0 = GM_BITOP3(c0[b], Tb[b], h0, TT_GE);
+                h1 = GM_BITOP3(c1[b], Tb[b], h1, TT_GE);
+            }
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64((h0 | h1) != 0u) != 0ull, 0)) {
+                const int id0 = (t * LK_TG + gl) * LK_GROUP;
+                lk_take_hits<L, RegList<KCAP>>(h0, c0, id0, n_db, list, thr, thr_seed, Tb);
+                lk_take_hits<L, RegList<KCAP>>(h1, c1, id0 + 32, n_db, list, thr, thr_seed, Tb);
+            }
+        }
+    }
+    if (valid) {
+        uint32_t* out = keys + ((int64_t)seg * n_q + qi) * KCAP;
+#pragma unroll
+        for (int s = 0; s < KCAP; ++s) out[s] = list.v[s];
+    }
+}
+
+}  // namespace gm

@@ -175,11 +175,11 @@ int run_hamming_lookup(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
     return launch_merge(a.kcap, idx->d_keys, (int)n_seg, n_q, a.k, ids, dists, counts, nearest, st);
 }
 
-int launch_lv_by_len(gm_index* idx, int kcap, int64_t n_q, int k, int n_seg, int tiles_per_seg,
+int launch_lv_by_len(gm_index* idx, int algo, int kcap, int64_t n_q, int k, int n_seg, int tiles_per_seg,
                      const int32_t* seed_d, const int32_t* seed_c, int seed_k, uint32_t* keys, hipStream_t st) {
     switch (idx->L) {
 #define GM_CASE(LEN) \
-    case LEN: return gm_launch_lv_L##LEN(idx, kcap, n_q, k, n_seg, tiles_per_seg, seed_d, seed_c, seed_k, keys, st);
+    case LEN: return gm_launch_lv_L##LEN(idx, algo, kcap, n_q, k, n_seg, tiles_per_seg, seed_d, seed_c, seed_k, keys, st);
         GM_FOR_EACH_LEN(GM_CASE)
 #undef GM_CASE
         default: return fail(GM_ERR_ARG, "leven look-up kernel: guidelen out of range");
@@ -191,7 +191,7 @@ int launch_lv_by_len(gm_index* idx, int kcap, int64_t n_q, int k, int n_seg, int
 // The query planes are already in idx->d_q.  d1 != nullptr: nearest-distance form (k = 1).
 bool use_leven_lookup(const gm_index* idx, int k) {
     return idx->metric == GM_METRIC_LEVEN && idx->d_peq != nullptr && idx->d_onehot != nullptr && k <= 20 &&
-           idx->variant == 0;
+           (idx->variant == 0 || idx->variant == 2);      // 0 = K2B bit-sliced DP, 2 = K2L (A/B baseline)
 }
 
 int run_leven_lookup(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* dists, int32_t* counts,
@@ -202,19 +202,22 @@ int run_leven_lookup(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* d
                      : run_hamming_lookup(idx, false, n_q, k, ids, dists, counts, false, st);
     if (rc) return rc;
     // enough (chunk, segment) workgroups to fill the chip several times over, segments of whole tiles
+    const int algo = idx->variant == 2 ? 0 : 1;
+    const int64_t n_tiles = algo == 1 ? idx->n_lk_tiles : idx->n_lv_tiles;
     const int64_t chunks = (n_q + gm::WAVE - 1) / gm::WAVE;
     int64_t want = ((int64_t)idx->n_simd * 8 + chunks - 1) / chunks;
     if (want < 1) want = 1;
-    if (want > idx->n_lv_tiles) want = idx->n_lv_tiles;
-    const int tiles_per_seg = (int)((idx->n_lv_tiles + want - 1) / want);
-    const int n_seg = (int)((idx->n_lv_tiles + tiles_per_seg - 1) / tiles_per_seg);
+    if (want > n_tiles) want = n_tiles;
+    const int tiles_per_seg = (int)((n_tiles + want - 1) / want);
+    const int n_seg = (int)((n_tiles + tiles_per_seg - 1) / tiles_per_seg);
     // own scratch: the Hamming seeder enqueued above may still be using idx->d_keys
     if ((rc = ensure_u32(&idx->d_keys2, &idx->keys2_cap, (int64_t)n_seg * n_q * kcap))) return rc;
     rc = timing_begin(idx, st);
     if (rc) return rc;
-    idx->last_kernel = nearest ? "k_leven_knn_lk(nearest)" : "k_leven_knn_lk";
-    rc = nearest ? launch_lv_by_len(idx, kcap, n_q, 1, n_seg, tiles_per_seg, d1, nullptr, 1, idx->d_keys2, st)
-                 : launch_lv_by_len(idx, kcap, n_q, k, n_seg, tiles_per_seg, dists, counts, k, idx->d_keys2, st);
+    idx->last_kernel = algo == 1 ? (nearest ? "k_leven_knn_bs(nearest)" : "k_leven_knn_bs")
+                                 : (nearest ? "k_leven_knn_lk(nearest)" : "k_leven_knn_lk");
+    rc = nearest ? launch_lv_by_len(idx, algo, kcap, n_q, 1, n_seg, tiles_per_seg, d1, nullptr, 1, idx->d_keys2, st)
+                 : launch_lv_by_len(idx, algo, kcap, n_q, k, n_seg, tiles_per_seg, dists, counts, k, idx->d_keys2, st);
     if (rc) return rc;
     rc = timing_end(idx, st, n_q * idx->n_db);
     if (rc) return rc;
