@@ -26,11 +26,50 @@ constexpr int TT_OR3 = (0xF0 | 0xCC | 0xAA) & 0xFF;                             
 constexpr int TT_SUB_DIFF = (0xF0 ^ 0xCC ^ 0xAA) & 0xFF;                          // a ^ b ^ borrow
 constexpr int TT_SUB_BORROW = ((~0xF0 & 0xCC) | (~(0xF0 ^ 0xCC) & 0xAA)) & 0xFF;  // (~a & b) | (~(a ^ b) & borrow)
 
-// DP of one half group (32 targets) against this lane's candidate.  ptr[i] = LDS address of
-// (column 0, base of candidate position i, half 0) of the group; HOFF = half (word offset).  On return
-// ptr[] has advanced by one group (L columns x 8 words) and c[0..4] holds the bits of s = L - distance.
-template <int L, int HOFF>
-__device__ __forceinline__ void lvb_eval_half(const uint32_t* (&ptr)[L], uint32_t (&c)[5]) {
+// The DP columns are written with inline-asm LDS reads on explicit per-lane byte addresses.  Left to
+// itself hipcc re-derives every address as base + loop offset (a half-rate SGPR-operand add per cell),
+// hoists the loads of several columns at once and ends at 256 VGPRs or ~1 KB of scratch per lane.  With
+// asm reads the address registers are bumped in place (also asm, so no copies), one column's L words
+// are in flight at a time, and the wait is ours.
+template <int BOFF>
+__device__ __forceinline__ uint32_t lvb_read(uint32_t adr) {
+    uint32_t v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(adr), "n"(BOFF));
+    return v;
+}
+// wait for every outstanding LDS read; the "+v" operands pin the consumers of those words behind the wait
+__device__ __forceinline__ void lvb_wait4(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+// one DP column for 32 targets: BOFF = constant byte offset (column within the unrolled block + half)
+template <int L, int BOFF>
+__device__ __forceinline__ void lvb_column(const uint32_t (&adr)[L], uint32_t (&Pv)[L], uint32_t (&Mv)[L]) {
+    constexpr int LP = (L + 3) / 4 * 4;      // rows padded to whole groups of four (dummies are never read)
+    uint32_t eq[LP];
+#pragma unroll
+    for (int i = 0; i < LP; ++i) eq[i] = i < L ? lvb_read<BOFF>(adr[i]) : 0u;
+#pragma unroll
+    for (int g = 0; g < LP / 4; ++g) lvb_wait4(eq[4 * g], eq[4 * g + 1], eq[4 * g + 2], eq[4 * g + 3]);
+    uint32_t Ph = 0xffffffffu, Mh = 0u;      // D(0, j) = j
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        const uint32_t D0 = GM_BITOP3(eq[i], Mv[i], Mh, TT_OR3);
+        const uint32_t Pho = GM_BITOP3(Mv[i], D0, Pv[i], TT_A_OR_NOR_BC);
+        const uint32_t Mho = Pv[i] & D0;
+        Pv[i] = GM_BITOP3(Mh, D0, Ph, TT_A_OR_NOR_BC);
+        Mv[i] = Ph & D0;
+        Ph = Pho;
+        Mh = Mho;
+    }
+}
+
+// DP of one half group (32 targets) against this lane's candidate.  adr[i] = LDS byte address of
+// (column 0, base of candidate position i, half 0) of the group; HB = byte offset of the half (0 / 4).
+// Columns are unrolled four at a time (offsets as instruction immediates; the addresses move once per
+// four columns).  On return adr[] has advanced by one group (L columns x 32 bytes) and c[0..4] holds the
+// bits of s = L - distance.
+template <int L, int HB>
+__device__ __forceinline__ void lvb_eval_half(uint32_t (&adr)[L], uint32_t (&c)[5]) {
     uint32_t Pv[L], Mv[L];
 #pragma unroll
     for (int i = 0; i < L; ++i) {
@@ -38,21 +77,20 @@ __device__ __forceinline__ void lvb_eval_half(const uint32_t* (&ptr)[L], uint32_
         Mv[i] = 0u;
     }
 #pragma unroll 1
-    for (int j = 0; j < L; ++j) {
-        uint32_t Ph = 0xffffffffu, Mh = 0u;      // D(0, j) = j
+    for (int j = 0; j + 4 <= L; j += 4) {
+        lvb_column<L, HB + 0>(adr, Pv, Mv);
+        lvb_column<L, HB + 32>(adr, Pv, Mv);
+        lvb_column<L, HB + 64>(adr, Pv, Mv);
+        lvb_column<L, HB + 96>(adr, Pv, Mv);
 #pragma unroll
-        for (int i = 0; i < L; ++i) {
-            const uint32_t Eq = ptr[i][HOFF];                                    // ds_read_b32, per-lane address
-            const uint32_t D0 = GM_BITOP3(Eq, Mv[i], Mh, TT_OR3);
-            const uint32_t Pho = GM_BITOP3(Mv[i], D0, Pv[i], TT_A_OR_NOR_BC);
-            const uint32_t Mho = Pv[i] & D0;
-            Pv[i] = GM_BITOP3(Mh, D0, Ph, TT_A_OR_NOR_BC);
-            Mv[i] = Ph & D0;
-            Ph = Pho;
-            Mh = Mho;
-        }
+        for (int i = 0; i < L; ++i) asm volatile("v_add_u32 %0, 0x80, %0" : "+v"(adr[i]));
+    }
+    if constexpr (L % 4 >= 1) lvb_column<L, HB + 0>(adr, Pv, Mv);
+    if constexpr (L % 4 >= 2) lvb_column<L, HB + 32>(adr, Pv, Mv);
+    if constexpr (L % 4 >= 3) lvb_column<L, HB + 64>(adr, Pv, Mv);
+    if constexpr (L % 4 != 0) {
 #pragma unroll
-        for (int i = 0; i < L; ++i) ptr[i] += 8;                                 // next column
+        for (int i = 0; i < L; ++i) asm volatile("v_add_u32 %0, %1, %0" : "+v"(adr[i]) : "n"(32 * (L % 4)));
     }
     // s = #M - #P over the last column (>= 0 because the distance never exceeds L)
     uint32_t cm[5], cp[5];
@@ -64,6 +102,9 @@ __device__ __forceinline__ void lvb_eval_half(const uint32_t* (&ptr)[L], uint32_
         c[b] = GM_BITOP3(cm[b], cp[b], borrow, TT_SUB_DIFF);
         borrow = GM_BITOP3(cm[b], cp[b], borrow, TT_SUB_BORROW);
     }
+    // finish the count HERE: without this the compiler sinks the trees below the next half's columns
+    // and keeps this half's 2L delta registers alive through them
+    asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]));
 }
 
 // K2B scan.  grid = (ceil(n_q / 64), n_seg); tiles = the K1L one-hot table tiles (LK_TG groups of 64).
@@ -101,19 +142,24 @@ __global__ __launch_bounds__(WAVE) void k_leven_knn_bs(const uint32_t* __restric
         const uint32_t* cur = smem + ((t - t0) & 1) * TILE_W;
         lk_stage_wait();                                               // tile t has landed
         if (t + 1 < t1) lk_stage<L>(table, t + 1, smem + ((t - t0 + 1) & 1) * TILE_W, lane);
-        // LDS address of (group 0, column 0, base of candidate position i, half 0)
-        const uint32_t* ptr[L];
+        // LDS byte address of (group 0, column 0, base of candidate position i, half 0)
+        // (re-derived from the packed candidate every tile: the opaque asm keeps the compiler from
+        // caching L base offsets in registers across the whole scan)
+        uint32_t adr[L];
+        const uint32_t cur_b = (uint32_t)(size_t)cur;
+        uint32_t qx = qv.x, qy = qv.y;
+        asm volatile("" : "+v"(qx), "+v"(qy));
 #pragma unroll
         for (int i = 0; i < L; ++i) {
-            const uint32_t code = ((qv.x >> i) & 1u) | (((qv.y >> i) & 1u) << 1);
-            ptr[i] = cur + code * 2;
+            const uint32_t code = ((qx >> i) & 1u) | (((qy >> i) & 1u) << 1);
+            adr[i] = cur_b + code * 8u;
         }
         for (int gl = 0; gl < LK_TG; ++gl) {
             uint32_t c0[5], c1[5];
-            lvb_eval_half<L, 0>(ptr, c0);                              // ptr: -> next group
+            lvb_eval_half<L, 0>(adr, c0);                              // adr: -> next group
 #pragma unroll
-            for (int i = 0; i < L; ++i) ptr[i] -= GW;                  // back to this group for the other half
-            lvb_eval_half<L, 1>(ptr, c1);
+            for (int i = 0; i < L; ++i) asm volatile("v_subrev_u32 %0, %1, %0" : "+v"(adr[i]) : "n"(GW * 4));
+            lvb_eval_half<L, 4>(adr, c1);
             uint32_t h0 = GM_BITOP3(c0[0], Tb[0], Tb[0], TT_A_OR_NOTB), h1 = GM_BITOP3(c1[0], Tb[0], Tb[0], TT_A_OR_NOTB);
 #pragma unroll
             for (int b = 1; b < 5; ++b) {
