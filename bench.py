@@ -53,6 +53,31 @@ def lookup_ops_per_pair(L):
     return (2 * (ops + 5) + 1) / 64.0
 
 
+def _tree_ops(L):
+    """Full/half-adder ops of one carry-save count of L one-bit words (gm_bitslice.hip.h)."""
+    def col(n):
+        if n <= 1:
+            return 0, 0
+        if n == 2:
+            return 2, 1
+        t, rem = divmod(n, 3)
+        ops, car = col(t + rem)
+        return 2 * t + ops, t + car
+    ops, n = 0, L
+    while n > 0:
+        o, n = col(n)
+        ops += o
+    return ops
+
+
+def bitsliced_leven_ops_per_pair(L):
+    """VALU lane-ops per guide pair of K2B (gm_leven_bs.hip.h): per 32-target word 5 ops per DP cell,
+    one address bump per row per 4 columns (+ one per row per group), two count trees, the 5-bit
+    subtract and the 5-op threshold compare."""
+    per_word = 5.0 * L * L + L * (L / 4.0) + L / 2.0 + 2 * _tree_ops(L) + 10 + 5
+    return per_word / 32.0
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -207,12 +232,15 @@ def main():
                         "VALU-bound, not HBM-bound, so frac > 1 means LDS/register reuse beats the "
                         "streaming model (SURVEY.md 8d)"}
         if pool["metric"] != "hamming" and 10 <= L <= 27:
-            opp = 11.0 * L + 12.0      # K2L: 11 VALU ops per text position + distance/threshold tail
+            if "knn_bs" in kname:      # K2B: 5 ops per DP cell per 32 pairs + counts, compare, address bumps
+                opp, reads = bitsliced_leven_ops_per_pair(L), L * L / 32.0
+            else:                      # K2L: 11 VALU ops per text position + distance/threshold tail
+                opp, reads = 11.0 * L + 12.0, float(L)
             ops = launch_pairs * opp / kern_s
             roof["valu"] = {"achieved": ops / 1e12, "peak": VALU_LANE_OPS_PER_S / 1e12,
                             "unit": "T lane-ops/s", "frac": ops / VALU_LANE_OPS_PER_S, "ops_per_pair": opp,
-                            "lds_reads_per_pair": float(L),
-                            "note": "the binding roof for the Myers scan: int32 VALU issue "
+                            "lds_reads_per_pair": reads,
+                            "note": "the binding roof for the Levenshtein scan: int32 VALU issue "
                                     "(256 CUs x 128 lanes/clk x 2.4 GHz); the HBM figure above is not meaningful "
                                     "for Levenshtein (SURVEY.md 8d)"}
         if pool["metric"] == "hamming" and 10 <= L <= 27:
