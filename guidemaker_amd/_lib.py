@@ -84,6 +84,10 @@ def lib():
     L.gm_pam_emit.restype = i32
     L.gm_pam_free.argtypes = [vp]
     L.gm_pam_free.restype = None
+    L.gm_site_flags.argtypes = [vp, i64, i32, c.POINTER(c.c_char_p), i32, vp, i32]
+    L.gm_site_flags.restype = i32
+    L.gm_seed_duplicated.argtypes = [vp, i64, i32, i32, i32, vp, i32]
+    L.gm_seed_duplicated.restype = i32
     for name in ("gm_pack", "gm_unpack", "gm_index_create", "gm_index_create_dev", "gm_index_guidelen",
                  "gm_index_metric", "gm_knn_query", "gm_knn_query_dev", "gm_nearest_dist",
                  "gm_nearest_dist_dev", "gm_cfd_batch", "gm_cfd_batch_dev", "gm_set_variant"):
@@ -99,7 +103,7 @@ EXPORTS = [
     "gm_knn_query", "gm_knn_query_dev", "gm_nearest_dist", "gm_nearest_dist_dev", "gm_cfd_batch",
     "gm_cfd_batch_dev", "gm_last_kernel_ms", "gm_last_query_ms", "gm_last_kernel_name", "gm_last_kernel_pairs",
     "gm_set_variant", "gm_timing_reserve", "gm_timing_read", "gm_pam_count", "gm_pam_emit", "gm_pam_free",
-    "gm_pack_keys_dev", "gm_unpack_keys_dev",
+    "gm_pack_keys_dev", "gm_unpack_keys_dev", "gm_site_flags", "gm_seed_duplicated",
 ]
 
 
@@ -266,6 +270,23 @@ def pam_scan(seq, pam, five_prime, guidelen, device=0):
     finally:
         lib().gm_pam_free(h)
     return packed, tstart, mstart, int(nf.value)
+
+
+def site_flags(packed, guidelen, sites, device=0):
+    """bool[n]: target i contains one of the IUPAC `sites` (list the reverse complements yourself)."""
+    packed = np.ascontiguousarray(packed, dtype=np.uint64)
+    flags = np.zeros(packed.shape, np.uint8)
+    arr = (ctypes.c_char_p * max(1, len(sites)))(*[s.encode("ascii") for s in sites])
+    _check(lib().gm_site_flags(_ptr(packed), packed.shape[0], guidelen, arr, len(sites), _ptr(flags), device))
+    return flags.astype(bool)
+
+
+def seed_duplicated(packed, guidelen, start, count, device=0):
+    """bool[n]: an earlier row has the same `count` bases from position `start` (duplicated(keep='first'))."""
+    packed = np.ascontiguousarray(packed, dtype=np.uint64)
+    flags = np.zeros(packed.shape, np.uint8)
+    _check(lib().gm_seed_duplicated(_ptr(packed), packed.shape[0], guidelen, start, count, _ptr(flags), device))
+    return flags.astype(bool)
 
 
 def pack_keys_dev(ids_ptr, dists_ptr, n_q, k, keys_ptr, stream=None):

@@ -319,18 +319,39 @@ class TargetProcessor:
         # anything but "hamming" selects Levenshtein (reference core.py:448,496,509)
         return self.targets['dtype'].iat[0] == "hamming"
 
+    def _packed_for_filters(self):
+        """(packed uint64, guide length) of the frame's targets when the GPU filters apply (a GPU is
+        visible, one common length <= 27, ACGT only), else None -> host (pandas) form of the same filter."""
+        t = self.targets['target']
+        if len(t) == 0 or _lib.device_count() <= 0:
+            return None
+        L = len(t.iat[0])
+        if L < 1 or L > _lib.MAX_GUIDELEN:
+            return None
+        try:
+            return _lib.pack(t.tolist(), L), L
+        except ValueError:
+            return None
+
     def check_restriction_enzymes(self, restriction_enzyme_list: list = []) -> None:
-        """Flag targets containing a restriction site or its reverse complement."""
-        sites = []
+        """Flag targets containing a restriction site or its reverse complement (reference
+        core.py:354-377).  On the GPU the IUPAC sites are matched on the packed words (gm_site_flags)."""
+        records = []
         for record in set(restriction_enzyme_list):
             for letter in record.upper():
                 assert letter in _IUPAC
-            sites += extend_ambiguous_dna(record.upper())
-            sites += extend_ambiguous_dna(reverse_complement(record.upper()))
-        if len(sites) > 0:
-            self.targets['hasrestrictionsite'] = self.targets['target'].str.contains('|'.join(sites))
-        else:
+            records += [record.upper(), reverse_complement(record.upper())]
+        if len(records) == 0:
             self.targets['hasrestrictionsite'] = False
+            return
+        pk = self._packed_for_filters() if len(records) <= 64 else None
+        if pk is not None:
+            self.targets['hasrestrictionsite'] = _lib.site_flags(pk[0], pk[1], records, self.device)
+            return
+        sites = []
+        for record in records:
+            sites += extend_ambiguous_dna(record)
+        self.targets['hasrestrictionsite'] = self.targets['target'].str.contains('|'.join(sites))
 
     def _one_hot_encode(self, seq_list: List[object]) -> np.ndarray:
         """Encoding step of the reference (core.py:379-386); here: 2-bit packing for the GPU."""
@@ -344,7 +365,8 @@ class TargetProcessor:
         return len(self.targets['target'].iat[0])
 
     def find_unique_near_pam(self) -> None:
-        """Flag targets whose PAM-proximal seed (length lsr) already occurred earlier in the frame."""
+        """Flag targets whose PAM-proximal seed (length lsr) already occurred earlier in the frame
+        (reference core.py:388-416).  On the GPU: gm_seed_duplicated on the packed words."""
         self.targets = deepcopy(self.targets)
         t = self.targets['target']
         if self.lsr == 0:
@@ -354,6 +376,20 @@ class TargetProcessor:
         else:
             seed = t.apply(lambda s: s[(len(s) - self.lsr):])
         self.targets['seedseq'] = seed
+        pk = self._packed_for_filters()
+        if pk is not None:
+            L = pk[1]
+            if self.lsr == 0:
+                start, count = 0, L
+            elif self.pam_orientation == True:
+                start, count = 0, min(self.lsr, L)
+            else:      # s[(len - lsr):] -- a negative start counts from the end, as Python slices do
+                start = L - self.lsr
+                if start < 0:
+                    start = max(L + start, 0)
+                count = L - start
+            self.targets['isseedduplicated'] = _lib.seed_duplicated(pk[0], L, start, count, self.device)
+            return
         self.targets['isseedduplicated'] = self.targets['seedseq'].duplicated()
 
     def create_index(self, configpath: str, num_threads=2):

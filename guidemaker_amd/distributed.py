@@ -29,9 +29,11 @@ def _dist():
 
 
 def is_distributed():
-    try:
-        dist = _dist()
-    except ImportError:
+    # a process group can only exist if the caller imported torch.distributed already: never pay the
+    # ~1 s `import torch` on the single-GPU path just to learn that there is none
+    import sys
+    dist = sys.modules.get("torch.distributed")
+    if dist is None:
         return False
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 

@@ -114,6 +114,20 @@ int gm_pam_count(const char* seq, int64_t n, const char* pam, int pam_len, int f
 int gm_pam_emit(gm_scan* scan, uint64_t* packed, int64_t* tstart, int64_t* mstart);
 void gm_pam_free(gm_scan* scan);
 
+/* Target filters on packed words.  Host pointers; blocking.
+ * gm_site_flags replaces TargetProcessor.check_restriction_enzymes (guidemaker/core.py:354-377):
+ * flags[i] = 1 iff target i contains an occurrence of any of the n_sites (<= 64) IUPAC strings in `sites`
+ * (NUL-terminated, upper case; the caller lists each enzyme AND its reverse complement, as the reference
+ * does before building its regex alternation).  A site longer than guidelen never matches; an empty site
+ * matches every target (the empty regex alternative).
+ * gm_seed_duplicated replaces TargetProcessor.find_unique_near_pam (core.py:388-416): the seed of a
+ * target is its `count` bases from position `start`; flags[i] = 1 iff an earlier row (smaller i) has the
+ * same seed -- pandas' duplicated(keep="first"). */
+int gm_site_flags(const uint64_t* packed, int64_t n, int guidelen, const char* const* sites, int n_sites,
+                  uint8_t* flags, int device);
+int gm_seed_duplicated(const uint64_t* packed, int64_t n, int guidelen, int start, int count, uint8_t* flags,
+                       int device);
+
 /* Measurement hooks: HIP-event duration (ms) of the dominant scan kernel of the last query on this
  * handle (blocks until that kernel has finished), its name, and the pairs it evaluated. */
 double gm_last_kernel_ms(gm_index* idx);

@@ -255,3 +255,51 @@ def cfd_score_rows(guides, similar_guides, mm):
         out.append([str(v) for v in vals])
         mx.append(sorted(float(x) for x in out[-1])[-1])
     return out, mx
+
+
+# ------------------------------------------------------------------------------------------------
+# N2 filters (test checker for gm_site_flags / gm_seed_duplicated)
+# ------------------------------------------------------------------------------------------------
+_IUPAC_VALUES = {
+    "A": "A", "C": "C", "G": "G", "T": "T", "M": "AC", "R": "AG", "W": "AT", "S": "CG", "Y": "CT",
+    "K": "GT", "V": "ACG", "H": "ACT", "D": "AGT", "B": "CGT", "X": "GATC", "N": "GATC",
+}
+_IUPAC_COMPLEMENT = str.maketrans("ACGTMRWSYKVHDBXN", "TGCAKYWSRMBDHVXN")
+
+
+def restriction_flags(targets, restriction_enzyme_list):
+    """check_restriction_enzymes restated (reference core.py:354-377): every enzyme and its reverse
+    complement is expanded to its concrete sequences (core.py:1093-1124), the alternation of all of them
+    is searched in each target.  -> list[bool]"""
+    import itertools
+    import re
+    alternatives = []
+    for record in set(restriction_enzyme_list):
+        record = record.upper()
+        for letter in record:
+            assert letter in _IUPAC_VALUES
+        for site in (record, record.translate(_IUPAC_COMPLEMENT)[::-1]):
+            alternatives += ["".join(p) for p in itertools.product(*[_IUPAC_VALUES[b] for b in site])]
+    if not alternatives:
+        return [False] * len(targets)
+    rx = re.compile("|".join(alternatives))
+    return [rx.search(t) is not None for t in targets]
+
+
+def seed_duplicated(targets, lsr, five_prime):
+    """find_unique_near_pam restated (reference core.py:388-416): seed = whole target (lsr == 0), the
+    first lsr bases (5prime: PAM in front) or s[(len(s) - lsr):] (3prime, with Python's negative-index
+    behaviour when lsr > len(s)); flag = the seed was seen at an earlier row (pandas duplicated()).
+    -> (seeds list[str], flags list[bool])"""
+    seeds, flags, seen = [], [], set()
+    for s in targets:
+        if lsr == 0:
+            seed = s
+        elif five_prime:
+            seed = s[0:lsr]
+        else:
+            seed = s[(len(s) - lsr):]
+        seeds.append(seed)
+        flags.append(seed in seen)
+        seen.add(seed)
+    return seeds, flags

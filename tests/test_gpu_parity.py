@@ -389,3 +389,74 @@ def test_key_packing_device_matches_host():
     assert (got.cpu() == want).all()
     gi, gd, gc = distributed.unpack_keys(got)
     assert (gi.cpu() == ti).all() and (gd.cpu() == td).all() and (gc.cpu().numpy() == cnt).all()
+
+
+# ------------------------------------------------------------------ N2: filters on packed words
+@pytest.mark.parametrize("tag,five_prime", [("NGG5p", True), ("NGG3p", False)])
+def test_filters_gpu_match_reference_flags(tag, five_prime):
+    """gm_site_flags / gm_seed_duplicated against the flags the reference produced on Carsonella."""
+    cols = load_carsonella(tag)
+    L = len(cols["target"][0])
+    packed = _lib.pack(cols["target"], L)
+    got = _lib.site_flags(packed, L, ["NRAGCA", core.reverse_complement("NRAGCA")])
+    assert got.tolist() == cols["hasrestrictionsite"]
+    start = 0 if five_prime else L - 10
+    assert _lib.seed_duplicated(packed, L, start, 10).tolist() == cols["isseedduplicated"]
+    # and through the mirrored TargetProcessor methods
+    tl = core.TargetProcessor(targets_frame(cols["target"], "hamming", five_prime),
+                              lsr=10, editdist=2, knum=2)
+    tl.check_restriction_enzymes(["NRAGCA"])
+    tl.find_unique_near_pam()
+    assert tl.targets["hasrestrictionsite"].tolist() == cols["hasrestrictionsite"]
+    assert tl.targets["isseedduplicated"].tolist() == cols["isseedduplicated"]
+
+
+@pytest.mark.parametrize("L", [10, 20, 27])
+def test_filters_gpu_match_oracle_edge_cases(oracle, L):
+    rng = random.Random(L)
+    base = ["".join(rng.choice("ACGT") for _ in range(L)) for _ in range(3000)]
+    targets = base + [rng.choice(base) for _ in range(1500)]            # many repeated seeds
+    targets += [t[:L // 2] + rng.choice(base)[L // 2:] for t in base[:500]]
+    rng.shuffle(targets)
+    packed = _lib.pack(targets, L)
+    for enzymes in (["GAATTC"], ["NRAGCA", "GGTCTC", "CACNNNGTG"], ["N"], ["A" * (L + 1)], ["XNNX"], ["BDHV"],
+                    [""], ["ACGT", "acgt"]):
+        sites = []
+        for e in set(enzymes):
+            sites += [e.upper(), core.reverse_complement(e.upper())]
+        assert _lib.site_flags(packed, L, sites).tolist() == oracle.restriction_flags(targets, enzymes), enzymes
+    for five_prime in (True, False):
+        for lsr in (0, 1, 5, L - 1, L, L + 3, 2 * L, 2 * L + 5):
+            tl = core.TargetProcessor(targets_frame(targets, "hamming", five_prime),
+                                      lsr=lsr, editdist=2, knum=2)
+            tl.find_unique_near_pam()
+            seeds, flags = oracle.seed_duplicated(targets, lsr, five_prime)
+            assert tl.targets["seedseq"].tolist() == seeds
+            assert tl.targets["isseedduplicated"].tolist() == flags, (five_prime, lsr)
+    assert _lib.site_flags(packed[:0], L, ["ACGT"]).shape == (0,)
+    assert _lib.seed_duplicated(packed[:0], L, 0, 5).shape == (0,)
+    with pytest.raises(ValueError):
+        _lib.site_flags(packed, L, ["ACGU"])
+
+
+def test_filters_full_size_properties():
+    """S1-sized frame: flags agree with numpy on the packed words (no oracle at this size)."""
+    L, n = 20, 600_000
+    rng = np.random.default_rng(5)
+    packed = core.pack_codes(rng.integers(0, 4, size=(n, L), dtype=np.uint8))
+    packed[rng.integers(0, n, size=50_000)] = packed[rng.integers(0, n, size=50_000)]
+    for start, count in ((0, 10), (10, 10), (0, 20), (3, 1)):
+        seeds = (packed >> np.uint64(2 * start)) & np.uint64((1 << (2 * count)) - 1)
+        first = np.ones(n, bool)
+        _, idx = np.unique(seeds, return_index=True)       # index of each seed's first occurrence
+        first[idx] = False
+        assert (_lib.seed_duplicated(packed, L, start, count) == first).all()
+    # GAATTC (its own reverse complement): compare with a direct scan of the 2-bit codes
+    site = np.array(["ACGT".index(c) for c in "GAATTC"], np.uint64)
+    want = np.zeros(n, bool)
+    for o in range(L - 6 + 1):
+        ok = np.ones(n, bool)
+        for j, c in enumerate(site):
+            ok &= ((packed >> np.uint64(2 * (o + j))) & np.uint64(3)) == c
+        want |= ok
+    assert (_lib.site_flags(packed, L, ["GAATTC"]) == want).all() and want.any()

@@ -121,3 +121,12 @@ def test_carsonella_summary(oracle):
         hist = np.bincount(dists[:, 1] // 2, minlength=10)[:10].tolist()
         assert hist == e["hist"]
         assert (dists[0] // 2).tolist() == e["first"]
+
+
+@pytest.mark.parametrize("tag,five_prime", [("NGG5p", True), ("NGG3p", False)])
+def test_filter_restatements_match_reference_flags(oracle, tag, five_prime):
+    """N2 oracle vs the flags the reference itself produced on Carsonella (lsr=10, NRAGCA)."""
+    cols = load_carsonella(tag)
+    assert oracle.restriction_flags(cols["target"], ["NRAGCA"]) == cols["hasrestrictionsite"]
+    assert oracle.seed_duplicated(cols["target"], 10, five_prime)[1] == cols["isseedduplicated"]
+    assert any(cols["hasrestrictionsite"]) and not all(cols["hasrestrictionsite"])
