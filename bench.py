@@ -107,10 +107,28 @@ def cpu_baseline(pool, seconds):
         if dt >= 0.6 * seconds or q_s == db.shape[0]:
             break
         q_s = int(min(db.shape[0], max(q_s + 1, q_s * seconds / dt)))
+    try:      # time the real NMSLib HNSW only if the timing box happens to have it
+        import nmslib  # noqa: F401
+        have_nmslib = "nmslib importable on this box but not timed (exact scan is the stated baseline)"
+    except ImportError:
+        have_nmslib = "nmslib unavailable on the timing box"
     return {"value": q_s * db.shape[0] / dt, "unit": "guide-pair comparisons/s", "cores": threads,
-            "kind": "port",
+            "kind": "port", "nmslib": have_nmslib,
             "sample": "%d candidates x %d targets (full pool), %s, k=%d, %.1f s, OpenMP exact scan "
                       "(oracle/gm_oracle.c: nmslib brute_force restated)" % (q_s, db.shape[0], metric, k, dt)}
+
+
+def wall_clock_knn(pool, metric_code, device):
+    """Wall clock of the genome-wide k-NN from host arrays: index build (H2D + table
+    kernels = create_index) + gm_knn_query with host pointers (H2D + kernels + D2H = get_neighbors'
+    search).  PCIe-inclusive, reported next to `value`, never as `value`."""
+    from guidemaker_amd import _lib
+    t0 = time.perf_counter()
+    idx = _lib.Index(pool["packed_db"], pool["guidelen"], metric_code, device)
+    idx.knn(pool["packed_all"], pool["k"])
+    dt = time.perf_counter() - t0
+    idx.close()
+    return dt
 
 
 def main():
@@ -252,6 +270,13 @@ def main():
                             "lds_reads_per_pair": L / 64.0,
                             "note": "the binding roofs: int32 VALU issue (256 CUs x 128 lanes/clk x 2.4 GHz) "
                                     "and LDS read issue (L ds_read_b64 per 64 pairs per lane)"}
+        # the ALGORITHMIC op model (4 int32 ops per Hamming pair for the popcount form,
+        # 17 L per Levenshtein pair for per-pair Myers) against 256 CUs x 64 lanes/clk x 2.4 GHz; > 1 means
+        # the bit-sliced kernels need fewer instructions than that model assumes
+        alg_ops = 4.0 if pool["metric"] == "hamming" else 17.0 * L
+        roof["alg_valu"] = {"ops_per_pair": alg_ops, "achieved": launch_pairs * alg_ops / kern_s / 1e12,
+                            "peak": 39.3216, "unit": "T int32 ops/s",
+                            "frac": launch_pairs * alg_ops / kern_s / 39.3216e12}
         out = {
             "metric": "guide-pair distance comparisons/sec (whole node)",
             "value": value, "unit": "guide-pair comparisons/s", "n_gpus": world, "steps": args.steps,
@@ -263,6 +288,8 @@ def main():
                        "parallelism": "candidate shards x%d, replicated pool, 1 RCCL all-gather" % world},
             "roofline": roof,
         }
+        if world == 1:
+            out["genome_wide_knn_wall_s"] = wall_clock_knn(pool, metric_code, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pool, args.cpu_seconds)
         print(json.dumps(out), flush=True)
