@@ -44,6 +44,27 @@ __device__ __forceinline__ unsigned valu_batch(unsigned x, unsigned y, unsigned 
     return a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
 }
 
+// mixed fetch: NL ds_read_b64 + NG global_load_dwordx2 gathers (4 distinct 8-byte addresses inside one
+// 32-byte span of an L1-resident table) -- does the vector-memory return path add to the LDS one?
+template <int NL, int NG>
+__device__ __forceinline__ unsigned mixed_batch(unsigned addr, const unsigned long long* gp) {
+    unsigned long long v[NL + NG];
+#pragma unroll
+    for (int i = 0; i < NG; ++i)
+        asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(v[NL + i]) : "v"(gp), "n"(i * 32));
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v[i]) : "v"(addr), "n"(i * 32));
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    unsigned long long x = 0;
+#pragma unroll
+    for (int i = 0; i < NL + NG; ++i) {
+        asm volatile("" : "+v"(v[i]));
+        x ^= v[i];
+    }
+    return (unsigned)(x ^ (x >> 32));
+}
+
 // 20 reads issued without waiting; the caller computes meanwhile and then calls lds_wait()
 struct Batch { unsigned long long v[20]; };
 __device__ __forceinline__ void lds_issue(Batch& b, unsigned addr) {
@@ -69,6 +90,44 @@ __device__ __forceinline__ unsigned batch_fold(Batch& b) {
         x ^= b.v[i];
     }
     return (unsigned)(x ^ (x >> 32));
+}
+
+template <int NL, int NG, bool VALU>
+__global__ __launch_bounds__(512) void k_mixed(unsigned* out, const unsigned long long* tbl, unsigned seed) {
+    __shared__ __align__(16) unsigned buf[8192];
+    for (int i = threadIdx.x; i < 8192; i += blockDim.x) buf[i] = i * seed;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned sel = (lane * 2654435761u >> 13) & 3;
+    unsigned addr = (unsigned)(size_t)buf + sel * 8 + wave * 1024;
+    const unsigned long long* gp = tbl + sel + wave * 128 + (blockIdx.x & 7) * 1024;
+    unsigned acc = seed + threadIdx.x;
+    for (int it = 0; it < ITERS; ++it) {
+        acc ^= mixed_batch<NL, NG>(addr, gp);
+        if (VALU) acc = valu_batch(acc, acc >> 3, seed);
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
+template <int NL, int NG, bool VALU>
+float run_mixed(unsigned* d_out, const unsigned long long* tbl, int cus, int wg_per_cu = 2, int threads = 512) {
+    dim3 grid(cus * wg_per_cu), block(threads);
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((k_mixed<NL, NG, VALU>), grid, block, 0, 0, d_out, tbl, 3u);
+    CHECK(hipDeviceSynchronize());
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL((k_mixed<NL, NG, VALU>), grid, block, 0, 0, d_out, tbl, 5u + rep);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    return best;
 }
 
 template <int MODE>
@@ -150,5 +209,18 @@ int main() {
     printf("12 waves/CU: alternate %.3f ms, pipelined %.3f ms  (x4/3: %.3f / %.3f)\n",
            run<4>(d_out, cus, 3, 256), run<5>(d_out, cus, 3, 256), run<4>(d_out, cus, 3, 256) * 4 / 3, run<5>(d_out, cus, 3, 256) * 4 / 3);
     printf("24 waves/CU: alternate %.3f ms  (x2/3: %.3f)\n", run<4>(d_out, cus, 3, 512), run<4>(d_out, cus, 3, 512) * 2 / 3);
+    // mixed LDS + global-gather fetch (16 and 24 waves/CU)
+    unsigned long long* tbl;
+    CHECK(hipMalloc(&tbl, 8 * 1024 * sizeof(unsigned long long) + 4096));
+    CHECK(hipMemset(tbl, 1, 8 * 1024 * sizeof(unsigned long long) + 4096));
+    printf("mixed fetch, 16 waves/CU, fetch only : 20 LDS %.3f | 16 LDS + 4 global %.3f | 12+8 %.3f | 0+20 %.3f ms\n",
+           run_mixed<20, 0, false>(d_out, tbl, cus), run_mixed<16, 4, false>(d_out, tbl, cus),
+           run_mixed<12, 8, false>(d_out, tbl, cus), run_mixed<0, 20, false>(d_out, tbl, cus));
+    printf("mixed fetch, 16 waves/CU, + 80 VALU  : 20 LDS %.3f | 18+2 %.3f | 16+4 %.3f | 12+8 %.3f ms\n",
+           run_mixed<20, 0, true>(d_out, tbl, cus), run_mixed<18, 2, true>(d_out, tbl, cus),
+           run_mixed<16, 4, true>(d_out, tbl, cus), run_mixed<12, 8, true>(d_out, tbl, cus));
+    printf("mixed fetch, 24 waves/CU, + 80 VALU  : 20 LDS %.3f | 18+2 %.3f | 16+4 %.3f | 12+8 %.3f ms\n",
+           run_mixed<20, 0, true>(d_out, tbl, cus, 3, 512), run_mixed<18, 2, true>(d_out, tbl, cus, 3, 512),
+           run_mixed<16, 4, true>(d_out, tbl, cus, 3, 512), run_mixed<12, 8, true>(d_out, tbl, cus, 3, 512));
     return 0;
 }
