@@ -226,6 +226,54 @@ def test_full_size_properties():
     idx.close()
 
 
+def test_full_size_properties_leven(oracle):
+    """B. subtilis-sized Levenshtein pool (BASELINE config 3 shape: L=23, k=5): size-independent
+    properties + a sampled comparison with the oracle over the FULL pool."""
+    L, k, n = 23, 5, 136_000
+    rng = np.random.default_rng(7)
+    codes = rng.integers(0, 4, size=(n, L), dtype=np.uint8)
+    # planted near-duplicates: substitutions and single-base shifts (indel pairs)
+    src = rng.integers(0, n, size=4000)
+    near = codes[src].copy()
+    near[np.arange(4000), rng.integers(0, L, size=4000)] = rng.integers(0, 4, size=4000)
+    shifted = np.concatenate([codes[src[:2000], 1:], rng.integers(0, 4, size=(2000, 1), dtype=np.uint8)], axis=1)
+    codes = np.concatenate([codes, near, shifted])
+    packed = np.unique(core.pack_codes(codes))
+    rng.shuffle(packed)
+    n = packed.shape[0]
+    idx = _lib.Index(packed, L, _lib.METRIC_LEVEN)
+    hidx = _lib.Index(packed, L, _lib.METRIC_HAMMING)
+    ids, dists, counts = idx.knn(packed, k)
+    assert (counts == k).all()
+    assert (dists[:, 0] == 0).all() and (ids[:, 0] == np.arange(n)).all()   # self is the nearest
+    assert (np.diff(dists, axis=1) >= 0).all()
+    same = np.diff(dists, axis=1) == 0
+    assert (np.diff(ids, axis=1)[same] > 0).all()                            # ties by id
+    # lev <= hamming, column by column of the two k-NN tables
+    _, hd, _ = hidx.knn(packed, k)
+    assert (dists <= hd).all()
+    assert (dists[:, 1] <= 1).sum() >= 3000                                  # the planted pairs are found
+    # nearest-distance kernel == first column of a 2-NN on probes that are not pool members
+    probe = core.pack_codes(rng.integers(0, 4, size=(3000, L), dtype=np.uint8))
+    assert (idx.nearest(probe) == idx.knn(probe, 2)[1][:, 0]).all()
+    # bit-sliced DP (default) == per-pair Myers kernel on a query sample
+    sel = rng.choice(n, size=20_000, replace=False)
+    idx.set_variant(2)
+    i2, d2, c2 = idx.knn(packed[sel], k)
+    idx.set_variant(0)
+    assert (i2 == ids[sel]).all() and (d2 == dists[sel]).all() and (c2 == counts[sel]).all()
+    # shard invariance
+    parts = [idx.knn(part, k) for part in np.array_split(packed[sel], 3)]
+    assert (np.concatenate([p[0] for p in parts]) == ids[sel]).all()
+    # oracle over the full pool for a few candidates
+    sample = rng.choice(n, size=64, replace=False)
+    db_str = _lib.unpack(packed, L)
+    oi, od, oc = _oracle_true_units(oracle, db_str, [db_str[i] for i in sample], L, "leven", k)
+    assert (oi == ids[sample]).all() and (od == dists[sample]).all() and (oc == counts[sample]).all()
+    idx.close()
+    hidx.close()
+
+
 # ------------------------------------------------------------------ controls
 def test_get_control_seqs(oracle):
     # reference tests/test_core.py:144-155 (shape), plus exact agreement with the oracle on the draw
