@@ -68,6 +68,10 @@ def lib():
     L.gm_last_kernel_name.restype = c.c_char_p
     L.gm_last_kernel_pairs.argtypes = [vp]
     L.gm_last_kernel_pairs.restype = i64
+    L.gm_last_kernel_evaluated.argtypes = [vp]
+    L.gm_last_kernel_evaluated.restype = i64
+    L.gm_last_incomplete.argtypes = [vp]
+    L.gm_last_incomplete.restype = i64
     L.gm_set_variant.argtypes = [vp, i32]
     L.gm_timing_reserve.argtypes = [vp, i32]
     L.gm_timing_reserve.restype = i32
@@ -104,6 +108,7 @@ EXPORTS = [
     "gm_cfd_batch_dev", "gm_last_kernel_ms", "gm_last_query_ms", "gm_last_kernel_name", "gm_last_kernel_pairs",
     "gm_set_variant", "gm_timing_reserve", "gm_timing_read", "gm_pam_count", "gm_pam_emit", "gm_pam_free",
     "gm_pack_keys_dev", "gm_unpack_keys_dev", "gm_site_flags", "gm_seed_duplicated",
+    "gm_last_kernel_evaluated", "gm_last_incomplete",
 ]
 
 
@@ -238,6 +243,12 @@ class Index:
         L = lib()
         return (L.gm_last_kernel_name(self._h).decode(), L.gm_last_kernel_ms(self._h),
                 L.gm_last_kernel_pairs(self._h))
+
+    def last_evaluated(self):
+        """(pairs the dominant launch really evaluated, candidates re-scanned afterwards): differs from
+        last_kernel()[2] only for the pigeonhole-partitioned scan."""
+        L = lib()
+        return int(L.gm_last_kernel_evaluated(self._h)), int(L.gm_last_incomplete(self._h))
 
 
 def cfd_batch(guides_packed, offs_packed, guidelen, mm, device=0):

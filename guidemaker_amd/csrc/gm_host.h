@@ -9,6 +9,9 @@
 #include <vector>
 
 #include "gmhip.h"
+#include "gm_pg_types.h"
+
+struct gm_pigeon;   // K1P state (gm_pigeon.hip)
 
 struct gm_index {
     int device = 0;
@@ -39,8 +42,11 @@ struct gm_index {
     int64_t hist_count = 0;
     const char* last_kernel = "";
     int64_t last_pairs = 0;
+    int64_t last_evaluated = 0;   // K1P: pairs the launch really evaluated (last_pairs = pairs it resolved)
+    int64_t last_incomplete = 0;  // K1P: candidates handed to the plain scan afterwards
     int variant = 0;
     int n_simd = 1024;            // CUs x 4
+    gm_pigeon* pg = nullptr;      // K1P: block-sorted pool copies + query workspaces (built on first use)
 };
 
 int gm_fail(int code, const std::string& msg);   // records the thread-local error message, returns code
@@ -67,10 +73,36 @@ struct gm_lk_args {
     const uint32_t* seed_keys = nullptr;
     uint32_t* out_keys = nullptr;
     int32_t *ids = nullptr, *dists = nullptr, *counts = nullptr;
+    const uint2* q = nullptr;     // candidate planes (nullptr: idx->d_q)
 };
 #define GM_DECL_LK(LEN) int gm_launch_lk_L##LEN(gm_index* idx, const gm_lk_args* a, hipStream_t st);
 GM_FOR_EACH_LEN(GM_DECL_LK)
 #undef GM_DECL_LK
+
+// K1P launchers, one per guide length (gm_inst_lk.hip): grid = upper bound of the chunk count
+#define GM_DECL_PG(LEN)                                                                                          \
+    int gm_launch_pg_L##LEN(gm_index* idx, int kcap, const gm_pg_blocks* blocks, const gm_pg_chunk* chunks,       \
+                            const int* n_chunks, int64_t grid, int64_t n_q, int k, int thr0, uint32_t* out_keys, \
+                            hipStream_t st);
+GM_FOR_EACH_LEN(GM_DECL_PG)
+#undef GM_DECL_PG
+
+// K1P host side (gm_pigeon.hip).  gm_pg_plan: number of blocks B (0 = the plain scan is the better choice);
+// gm_pg_prepare: block-sorted pool copies for B; gm_pg_candidates: group the candidates in idx->d_q;
+// gm_pg_scan: the K1P launch; gm_pg_incomplete: rows whose merged list is not full (device list + count,
+// synchronises the stream); gm_pg_gather / gm_pg_scatter: move those rows to / from a compact query.
+int gm_pg_plan(int64_t n_db, int L, int k);
+int gm_pg_prepare(gm_index* idx, int B, hipStream_t st);
+int gm_pg_candidates(gm_index* idx, int64_t n_q, hipStream_t st);
+int gm_pg_scan(gm_index* idx, int kcap, int64_t n_q, int k, uint32_t** keys_out, hipStream_t st);
+int gm_pg_incomplete(gm_index* idx, int64_t n_q, int need, const int32_t* counts, const int32_t* d1,
+                     int64_t* n_inc, int64_t* pairs_evaluated, hipStream_t st);
+int gm_pg_gather(gm_index* idx, int64_t n_inc, int k, bool nearest, const uint2** q2, int32_t** ids2,
+                 int32_t** dists2, int32_t** counts2, hipStream_t st);
+int gm_pg_scatter(gm_index* idx, int64_t n_inc, int k, bool nearest, int32_t* ids, int32_t* dists, int32_t* counts,
+                  hipStream_t st);
+int gm_pg_blocks_of(const gm_index* idx);
+void gm_pg_free(gm_index* idx);
 
 // K2L launchers, one per guide length (gm_inst_lv.hip)
 #define GM_DECL_LV(LEN)                                                                                        \

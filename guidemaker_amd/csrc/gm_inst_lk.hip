@@ -22,7 +22,7 @@ int launch_lk_cfg(gm_index* idx, const gm_lk_args& a, hipStream_t st) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)chunks, (unsigned)a.n_seg), dim3(gm::WAVE), lds, st, idx->d_onehot,
-                       (int)idx->n_db, (int)idx->n_lk_tiles, a.tiles_per_seg, a.seg_base, idx->d_q, a.n_q, a.k,
+                       (int)idx->n_db, (int)idx->n_lk_tiles, a.tiles_per_seg, a.seg_base, a.q ? a.q : idx->d_q, a.n_q, a.k,
                        a.seed_keys, a.out_keys, a.ids, a.dists, a.counts);
     HIP_TRY(hipGetLastError());
     return GM_OK;
@@ -47,6 +47,16 @@ int launch_lk(gm_index* idx, const gm_lk_args& a, hipStream_t st) {
     }
 }
 
+template <int L, int KCAP>
+int launch_pg_cfg(gm_index* idx, const gm_pg_blocks* blocks, const gm_pg_chunk* chunks, const int* n_chunks,
+                  int64_t grid, int64_t n_q, int k, int thr0, uint32_t* out_keys, hipStream_t st) {
+    const size_t lds = 2 * (size_t)gm::lk_tile_bytes(L);
+    hipLaunchKernelGGL((gm::k_hamming_knn_pg<L, KCAP>), dim3((unsigned)grid), dim3(gm::WAVE), lds, st, *blocks, chunks,
+                       n_chunks, (int)idx->n_db, (int)idx->n_lk_tiles, idx->d_q, n_q, k, thr0, out_keys);
+    HIP_TRY(hipGetLastError());
+    return GM_OK;
+}
+
 }  // namespace
 
 #define GM_CAT2(a, b) a##b
@@ -54,4 +64,16 @@ int launch_lk(gm_index* idx, const gm_lk_args& a, hipStream_t st) {
 
 int GM_CAT(gm_launch_lk_L, GM_LEN)(gm_index* idx, const gm_lk_args* a, hipStream_t st) {
     return launch_lk<GM_LEN>(idx, *a, st);
+}
+
+int GM_CAT(gm_launch_pg_L, GM_LEN)(gm_index* idx, int kcap, const gm_pg_blocks* blocks, const gm_pg_chunk* chunks,
+                                   const int* n_chunks, int64_t grid, int64_t n_q, int k, int thr0,
+                                   uint32_t* out_keys, hipStream_t st) {
+    switch (kcap) {
+        case 1: return launch_pg_cfg<GM_LEN, 1>(idx, blocks, chunks, n_chunks, grid, n_q, k, thr0, out_keys, st);
+        case 5: return launch_pg_cfg<GM_LEN, 5>(idx, blocks, chunks, n_chunks, grid, n_q, k, thr0, out_keys, st);
+        case 10: return launch_pg_cfg<GM_LEN, 10>(idx, blocks, chunks, n_chunks, grid, n_q, k, thr0, out_keys, st);
+        case 20: return launch_pg_cfg<GM_LEN, 20>(idx, blocks, chunks, n_chunks, grid, n_q, k, thr0, out_keys, st);
+        default: return gm_fail(GM_ERR_ARG, "pigeonhole kernel: unsupported list capacity");
+    }
 }

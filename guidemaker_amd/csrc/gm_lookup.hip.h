@@ -19,6 +19,7 @@
 #define GM_LK_W10 6     /* waves per SIMD asked for with a 5/10-key register list at L <= 20 */
 #endif
 #include "gm_bitslice.hip.h"
+#include "gm_pg_types.h"
 #include <type_traits>
 
 namespace gm {
@@ -93,6 +94,13 @@ struct RegList {
             v[s] = lo;
         }
     }
+    // insert unless the key is already in the list (merging lists that may share entries)
+    __device__ __forceinline__ void insert_unique(uint32_t key) {
+        bool dup = false;
+#pragma unroll
+        for (int s = 0; s < KCAP; ++s) dup = dup || v[s] == key + 1u;
+        if (!dup) insert(key);
+    }
     __device__ __forceinline__ void store(int k, int64_t qi, int32_t* __restrict__ ids,
                                           int32_t* __restrict__ dists, int32_t* __restrict__ counts,
                                           bool nearest) const {
@@ -151,9 +159,12 @@ __device__ __forceinline__ void lk_set_bound(uint32_t (&Tb)[5], int L, int thr) 
 }
 
 // slow path of one half group: walk this lane's hit bits in ascending id order
+// (id_lo: K1P scans a re-ordered copy of the pool and keeps only positions id_lo <= position < n_db = the
+// bucket's own range, where positions ascend with the pool ids; it translates positions to ids at the end)
 template <int L, class List>
 __device__ __forceinline__ void lk_take_hits(uint32_t hits, const uint32_t (&c)[5], int id0, int n_db,
-                                             List& list, int& thr, int thr_seed, uint32_t (&Tb)[5]) {
+                                             List& list, int& thr, int thr_seed, uint32_t (&Tb)[5],
+                                             int id_lo = 0) {
     while (hits != 0u) {
         int j = __builtin_ctz(hits);
         hits &= hits - 1u;
@@ -161,7 +172,7 @@ __device__ __forceinline__ void lk_take_hits(uint32_t hits, const uint32_t (&c)[
                             (((c[3] >> j) & 1u) << 3) | (((c[4] >> j) & 1u) << 4));
         int d = L - matches;
         int id = id0 + j;
-        if (d < thr && id < n_db) {
+        if (d < thr && id < n_db && id >= id_lo) {
             list.insert(((uint32_t)d << ID_BITS) | (uint32_t)id);
             int nt = list.threshold(L);
             nt = nt < thr_seed ? nt : thr_seed;      // a seeded bound never loosens while the list fills
@@ -207,13 +218,13 @@ __device__ __forceinline__ void lk_read_group(LkGroupRegs<L>& r, const uint32_t*
 }
 template <int L, class List>
 __device__ __forceinline__ void lk_process_group(const LkGroupRegs<L>& r, int id0, int n_db, List& list, int& thr,
-                                                 int thr_seed, uint32_t (&Tb)[5]) {
+                                                 int thr_seed, uint32_t (&Tb)[5], int id_lo = 0) {
     uint32_t c0[5], c1[5];
     uint32_t h0 = lk_eval_half<L>(r.m0, Tb, c0);
     uint32_t h1 = lk_eval_half<L>(r.m1, Tb, c1);
     if (__builtin_expect(__builtin_amdgcn_ballot_w64((h0 | h1) != 0u) != 0ull, 0)) {
-        lk_take_hits<L, List>(h0, c0, id0, n_db, list, thr, thr_seed, Tb);
-        lk_take_hits<L, List>(h1, c1, id0 + 32, n_db, list, thr, thr_seed, Tb);
+        lk_take_hits<L, List>(h0, c0, id0, n_db, list, thr, thr_seed, Tb, id_lo);
+        lk_take_hits<L, List>(h1, c1, id0 + 32, n_db, list, thr, thr_seed, Tb, id_lo);
     }
 }
 
@@ -316,21 +327,123 @@ __global__ __launch_bounds__(WAVE, lk_min_waves(L, KCAP)) void k_hamming_knn_lk(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// K1P -- pigeonhole-partitioned scan (exact for neighbours within r = B - 1 mismatches).
+// The guide is cut into B blocks of positions.  Two sequences with at most B - 1 mismatches agree
+// exactly on at least one block, so for block b it is enough to compare a candidate with the pool targets
+// that have the same bases on block b: the pool is stored B times, stable-sorted by the block's value
+// (ids ascend inside a bucket), with one one-hot table per copy; candidates are grouped by the same value
+// into chunks of <= 64 that never straddle a bucket.  Workgroup = one chunk: K1L's scan over the tiles
+// that cover the bucket (rounded outwards; hits outside the bucket's own range are ignored, they belong to
+// another workgroup), bound fixed at d < B, positions translated to ids through the copy's permutation.  Every candidate
+// gets one list per block; k_merge_lists folds them (a pair sharing several blocks appears in several).
+// A candidate whose merged list is full is exact (everything within r was enumerated); the others are
+// re-scanned by the plain kernel (host side, gmhip.hip).
+// ---------------------------------------------------------------------------------------------------
+template <int L, int KCAP>
+__global__ __launch_bounds__(WAVE, lk_min_waves(L, KCAP)) void k_hamming_knn_pg(
+    gm_pg_blocks P, const gm_pg_chunk* __restrict__ chunks, const int* __restrict__ n_chunks, int n_db, int n_tiles,
+    const uint2* __restrict__ q, int64_t n_q, int k, int thr0, uint32_t* __restrict__ out_keys) {
+    extern __shared__ __align__(16) uint32_t smem[];
+    constexpr int TILE_W = lk_tile_bytes(L) / 4;
+    constexpr int GW = lk_group_words(L);
+    constexpr int TILE_IDS = LK_TG * LK_GROUP;
+    if ((int)blockIdx.x >= *n_chunks) return;
+    const gm_pg_chunk ch = chunks[blockIdx.x];
+    const uint32_t* __restrict__ table = P.table[ch.b];
+    const int32_t* __restrict__ perm = P.perm[ch.b];
+    uint32_t* tiles = smem;
+    const int lane = threadIdx.x;
+    const bool valid = lane < ch.cn;
+    const int64_t qi = valid ? (int64_t)P.cperm[ch.b][ch.c0 + lane] : 0;
+    const uint2 qv = valid ? q[qi] : make_uint2(0u, 0u);
+
+    const uint32_t* ptr[L];
+#pragma unroll
+    for (int p = 0; p < L; ++p) {
+        uint32_t code = ((qv.x >> p) & 1u) | (((qv.y >> p) & 1u) << 1);
+        ptr[p] = tiles + p * 8 + (int)code * 2;
+    }
+    RegList<KCAP> list;
+    list.init(k, nullptr, lane);
+    const int thr_seed = thr0;
+    int thr = valid ? thr_seed : 0;
+    uint32_t Tb[5];
+    lk_set_bound(Tb, L, thr);
+
+    // tiles covering the bucket's targets [lo, hi) in this copy, widened to an even tile range
+    const int lo = P.toff[ch.b][ch.v], hi = P.toff[ch.b][ch.v + 1];
+    int t0 = (lo / TILE_IDS) & ~1;
+    int t1 = ((hi + TILE_IDS - 1) / TILE_IDS + 1) & ~1;
+    if (t1 > n_tiles) t1 = n_tiles;
+    if (hi <= lo) t1 = t0;
+
+    if (t0 < t1) lk_stage<L>(table, t0, tiles, lane);
+    for (int t = t0; t < t1; t += 2) {
+        lk_stage_wait();
+        lk_stage<L>(table, t + 1, tiles + TILE_W, lane);
+#pragma unroll
+        for (int gl = 0; gl < LK_TG; ++gl) {
+            LkGroupRegs<L> r;
+            if (gl == 0) lk_read_group<L, 0 * GW>(r, ptr);
+            if (gl == 1) lk_read_group<L, 1 * GW>(r, ptr);
+            if (gl == 2) lk_read_group<L, 2 * GW>(r, ptr);
+            if (gl == 3) lk_read_group<L, 3 * GW>(r, ptr);
+            lk_process_group<L, RegList<KCAP>>(r, (t * LK_TG + gl) * LK_GROUP, hi, list, thr, thr_seed, Tb, lo);
+        }
+        lk_stage_wait();
+        if (t + 2 < t1) lk_stage<L>(table, t + 2, tiles, lane);
+#pragma unroll
+        for (int gl = 0; gl < LK_TG; ++gl) {
+            LkGroupRegs<L> r;
+            if (gl == 0) lk_read_group<L, TILE_W + 0 * GW>(r, ptr);
+            if (gl == 1) lk_read_group<L, TILE_W + 1 * GW>(r, ptr);
+            if (gl == 2) lk_read_group<L, TILE_W + 2 * GW>(r, ptr);
+            if (gl == 3) lk_read_group<L, TILE_W + 3 * GW>(r, ptr);
+            lk_process_group<L, RegList<KCAP>>(r, ((t + 1) * LK_TG + gl) * LK_GROUP, hi, list, thr, thr_seed, Tb, lo);
+        }
+    }
+    if (valid) {      // positions -> pool ids; slot-major lists [b][slot][candidate]: the merge reads them coalesced
+#pragma unroll
+        for (int s = 0; s < KCAP; ++s) {
+            uint32_t v = list.v[s];
+            if (v != 0u && v != RegList<KCAP>::EMPTY) {
+                const uint32_t key = v - 1u;
+                v = ((key & ~ID_MASK) | (uint32_t)perm[key & ID_MASK]) + 1u;
+            }
+            out_keys[((int64_t)ch.b * KCAP + s) * n_q + qi] = v;
+        }
+    }
+}
+
 // fold per-segment raw RegList<KCAP> lists [n_seg][n_q][KCAP] into the final top-k.  One thread per candidate.
+// Keys occurring in more than one list (K1P: a pair that shares several blocks) are taken once.
+// slot_major = 0: lists [n_seg][n_q][KCAP] (the segmented scans); 1: [n_seg][KCAP][n_q] (K1P; the lists are
+// sorted with the unused slots at the end, so a list is left at its first empty slot).
 template <int KCAP>
 __global__ void k_merge_lists(const uint32_t* __restrict__ keys, int n_seg, int64_t n_q, int k,
                               int32_t* __restrict__ ids, int32_t* __restrict__ dists,
-                              int32_t* __restrict__ counts, int nearest) {
+                              int32_t* __restrict__ counts, int nearest, int slot_major) {
     const int64_t qi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (qi >= n_q) return;
     RegList<KCAP> list;
     list.init(k, nullptr, 0);
-    for (int s = 0; s < n_seg; ++s) {
-        const uint32_t* in = keys + ((int64_t)s * n_q + qi) * KCAP;
+    if (slot_major) {
+        for (int s = 0; s < n_seg; ++s) {
+            for (int i = 0; i < KCAP; ++i) {
+                const uint32_t v = keys[((int64_t)s * KCAP + i) * n_q + qi];
+                if (v == RegList<KCAP>::EMPTY) break;
+                if (v != 0u) list.insert_unique(v - 1u);
+            }
+        }
+    } else {
+        for (int s = 0; s < n_seg; ++s) {
+            const uint32_t* in = keys + ((int64_t)s * n_q + qi) * KCAP;
 #pragma unroll
-        for (int i = 0; i < KCAP; ++i) {
-            const uint32_t v = in[i];
-            if (v != 0u && v != RegList<KCAP>::EMPTY) list.insert(v - 1u);
+            for (int i = 0; i < KCAP; ++i) {
+                const uint32_t v = in[i];
+                if (v != 0u && v != RegList<KCAP>::EMPTY) list.insert_unique(v - 1u);
+            }
         }
     }
     list.store(k, qi, ids, dists, counts, nearest != 0);

@@ -1,0 +1,19 @@
+// gm_pg_types.h -- plain structs shared by the K1P kernel (gm_lookup.hip.h) and its host side (gm_pigeon.hip).
+#pragma once
+#include <stdint.h>
+
+constexpr int GM_PG_MAXB = 8;     // blocks per layout
+constexpr int GM_PG_MAXLEN = 6;   // bases per block (4^6 buckets)
+
+// per-block device pointers, passed to the kernel by value
+struct gm_pg_blocks {
+    const uint32_t* table[GM_PG_MAXB];   // one-hot table of the pool copy sorted by block b
+    const int32_t* perm[GM_PG_MAXB];     // position in that copy -> pool id
+    const int32_t* toff[GM_PG_MAXB];     // bucket v covers positions [toff[v], toff[v+1])
+    const uint32_t* cperm[GM_PG_MAXB];   // candidates sorted by block b: sorted position -> candidate row
+};
+
+// one workgroup's work: cn (<= 64) candidates starting at sorted position c0, all in bucket v of block b
+struct gm_pg_chunk {
+    int b, v, c0, cn;
+};

@@ -1,0 +1,576 @@
+// gm_pigeon.hip -- host side of K1P, the pigeonhole-partitioned Hamming scan (kernel: k_hamming_knn_pg in
+// gm_lookup.hip.h).  Exact k-NN without evaluating all pairs:
+//
+//   two sequences with at most r mismatches agree exactly on at least one of B = r + 1 disjoint blocks of
+//   positions, so the neighbours of a candidate within distance r all sit in the B buckets "same bases on
+//   block b".  Pool side (once per index and layout): for every block a stable sort of the pool by the
+//   block's value (ids ascend inside a bucket -> the kernels' strict test keeps the canonical (distance, id)
+//   order), the permutation, the bucket offsets and a one-hot table of the sorted copy.  Query side: the
+//   candidates are sorted by the same value and cut into chunks of <= 64 that do not straddle buckets; one
+//   workgroup scans one chunk against its bucket; B lists per candidate are merged (duplicates dropped).
+//   Work: sum_b 4^-len(b) of all pairs (15.6 % for L = 20, B = 7).
+//   A candidate whose merged list is full is exact: every target within r was enumerated.  The rest (the
+//   layout is chosen so that they are few) are re-scanned by the plain two-phase kernel (gmhip.hip).
+//
+// Everything here is integer bookkeeping on the device: block keys, a stable rocPRIM sort per pool copy, one
+// counting sort of the candidates for all blocks, a chunk table built by a count / scan / fill triple.  No host round trip except the one
+// read-back of the incomplete-row count.
+#include "gm_host.h"
+
+#include <cmath>
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "gm_lookup.hip.h"      // k_to_onehot, tile geometry
+
+namespace {
+
+struct PgLayoutArg {              // per-block geometry + offsets, by value
+    int B;
+    int ebase[GM_PG_MAXB + 1];    // first entry of block b in the flattened (block, bucket) list
+    const int32_t* coff[GM_PG_MAXB];
+    const int32_t* toff[GM_PG_MAXB];
+};
+
+struct PgCounters {               // device-resident
+    int n_chunks;
+    int n_inc;
+    unsigned long long pairs;     // pairs the last K1P launch evaluates (chunks x 64 x scanned targets)
+};
+
+__global__ __launch_bounds__(256) void k_block_keys(const uint2* __restrict__ planes, int64_t n, int start, int len,
+                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ rows) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint2 e = planes[i];
+    uint32_t key = 0;
+    for (int j = 0; j < len; ++j) {
+        const int p = start + j;
+        key |= (((e.x >> p) & 1u) | (((e.y >> p) & 1u) << 1)) << (2 * j);
+    }
+    keys[i] = key;
+    rows[i] = (uint32_t)i;
+}
+
+// off[v] = first position whose key is >= v (v = 0 .. nb); keys ascending
+__global__ __launch_bounds__(256) void k_bucket_offsets(const uint32_t* __restrict__ keys, int64_t n, int nb,
+                                                        int32_t* __restrict__ off) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v > nb) return;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < (uint32_t)v) lo = mid + 1; else hi = mid;
+    }
+    off[v] = (int32_t)lo;
+}
+
+// ---- candidate grouping: one counting sort for ALL blocks (order inside a bucket is irrelevant) ----
+struct PgKeyArg {
+    int B;
+    int bstart[GM_PG_MAXB], blen[GM_PG_MAXB];
+    int ebase[GM_PG_MAXB + 1];
+    int32_t* coff[GM_PG_MAXB];
+    uint32_t* cperm[GM_PG_MAXB];
+};
+
+__device__ __forceinline__ int pg_key(const uint2 e, int start, int len) {
+    int key = 0;
+    for (int j = 0; j < len; ++j) {
+        const int p = start + j;
+        key |= (int)(((e.x >> p) & 1u) | (((e.y >> p) & 1u) << 1)) << (2 * j);
+    }
+    return key;
+}
+
+// hist[entry] += candidates with that (block, value); LDS-privatised per workgroup when the table fits
+__global__ __launch_bounds__(1024) void k_cand_hist(const uint2* __restrict__ planes, int64_t n, PgKeyArg K,
+                                                    int* __restrict__ hist, int use_lds) {
+    extern __shared__ int s_hist[];
+    const int n_entries = K.ebase[K.B];
+    if (use_lds) {
+        for (int e = threadIdx.x; e < n_entries; e += blockDim.x) s_hist[e] = 0;
+        __syncthreads();
+    }
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const uint2 e = planes[i];
+        for (int b = 0; b < K.B; ++b) {
+            const int ent = K.ebase[b] + pg_key(e, K.bstart[b], K.blen[b]);
+            if (use_lds) atomicAdd(&s_hist[ent], 1); else atomicAdd(&hist[ent], 1);
+        }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < n_entries; e += blockDim.x)
+            if (s_hist[e] != 0) atomicAdd(&hist[e], s_hist[e]);
+    }
+}
+
+// per block (blockIdx.x = b): exclusive scan of its buckets -> coff[b][0..nb], cursor[entry] = bucket start
+__global__ __launch_bounds__(1024) void k_cand_offsets(PgKeyArg K, const int* __restrict__ hist, int* __restrict__ cursor) {
+    __shared__ int s[1024];
+    const int b = blockIdx.x;
+    const int e0 = K.ebase[b], nb = K.ebase[b + 1] - e0;
+    const int per = (nb + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = lo + per < nb ? lo + per : nb;
+    int sum = 0;
+    for (int v = lo; v < hi; ++v) sum += hist[e0 + v];
+    s[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int t = threadIdx.x >= d ? s[threadIdx.x - d] : 0;
+        __syncthreads();
+        s[threadIdx.x] += t;
+        __syncthreads();
+    }
+    int run = threadIdx.x ? s[threadIdx.x - 1] : 0;
+    for (int v = lo; v < hi; ++v) {
+        K.coff[b][v] = run;
+        cursor[e0 + v] = run;
+        run += hist[e0 + v];
+    }
+    if (threadIdx.x == 1023) K.coff[b][nb] = s[1023];
+}
+
+// cperm[b][position] = candidate row; positions handed out per bucket: rank inside the workgroup from an
+// LDS counter, one global atomic per (workgroup, non-empty bucket) for the workgroup's base
+__global__ __launch_bounds__(1024) void k_cand_scatter(const uint2* __restrict__ planes, int64_t n, PgKeyArg K,
+                                                       int* __restrict__ cursor, int use_lds) {
+    extern __shared__ int s_cnt[];      // [n_entries] counts, then reused as bases
+    const int n_entries = K.ebase[K.B];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int ent[GM_PG_MAXB], rank[GM_PG_MAXB];
+    if (use_lds) {
+        for (int e = threadIdx.x; e < n_entries; e += blockDim.x) s_cnt[e] = 0;
+        __syncthreads();
+    }
+    if (i < n) {
+        const uint2 e = planes[i];
+#pragma unroll
+        for (int b = 0; b < GM_PG_MAXB; ++b) {
+            if (b < K.B) {
+                ent[b] = K.ebase[b] + pg_key(e, K.bstart[b], K.blen[b]);
+                rank[b] = use_lds ? atomicAdd(&s_cnt[ent[b]], 1) : atomicAdd(&cursor[ent[b]], 1);
+            }
+        }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < n_entries; e += blockDim.x) {
+            const int c = s_cnt[e];
+            s_cnt[e] = c != 0 ? atomicAdd(&cursor[e], c) : 0;
+        }
+        __syncthreads();
+    }
+    if (i < n) {
+#pragma unroll
+        for (int b = 0; b < GM_PG_MAXB; ++b) {
+            if (b < K.B) {
+                const int pos = use_lds ? s_cnt[ent[b]] + rank[b] : rank[b];
+                K.cperm[b][pos] = (uint32_t)i;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gather_planes(const uint2* __restrict__ planes, const uint32_t* __restrict__ perm,
+                                                       int64_t n, uint2* __restrict__ out, int32_t* __restrict__ perm_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = planes[perm[i]];
+    perm_out[i] = (int32_t)perm[i];
+}
+
+__device__ __forceinline__ void pg_entry(const PgLayoutArg& A, int e, int& b, int& v) {
+    b = 0;
+    while (b + 1 < A.B && e >= A.ebase[b + 1]) ++b;
+    v = e - A.ebase[b];
+}
+
+// chunks per (block, bucket) entry
+__global__ __launch_bounds__(256) void k_chunk_count(PgLayoutArg A, int* __restrict__ nch) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= A.ebase[A.B]) return;
+    int b, v;
+    pg_entry(A, e, b, v);
+    const int cnt = A.coff[b][v + 1] - A.coff[b][v];
+    nch[e] = (cnt + 63) / 64;
+}
+
+// exclusive scan of n ints by ONE workgroup; total -> *total
+__global__ __launch_bounds__(1024) void k_scan_excl(const int* __restrict__ in, int n, int* __restrict__ out,
+                                                    int* __restrict__ total) {
+    __shared__ int s[1024];
+    const int per = (n + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += in[i];
+    s[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = threadIdx.x >= d ? s[threadIdx.x - d] : 0;
+        __syncthreads();
+        s[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = threadIdx.x ? s[threadIdx.x - 1] : 0;
+    for (int i = lo; i < hi; ++i) {
+        out[i] = run;
+        run += in[i];
+    }
+    if (threadIdx.x == 1023) *total = s[1023];
+}
+
+__global__ __launch_bounds__(256) void k_fill_chunks(PgLayoutArg A, const int* __restrict__ cbase, int n_tiles,
+                                                     gm_pg_chunk* __restrict__ chunks, PgCounters* __restrict__ ctr) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= A.ebase[A.B]) return;
+    int b, v;
+    pg_entry(A, e, b, v);
+    const int c0 = A.coff[b][v], c1 = A.coff[b][v + 1];
+    if (c1 <= c0) return;
+    int w = cbase[e];
+    for (int c = c0; c < c1; c += 64, ++w) chunks[w] = gm_pg_chunk{b, v, c, c1 - c < 64 ? c1 - c : 64};
+    // the tiles the kernel will scan for this bucket (same rounding as k_hamming_knn_pg)
+    constexpr int TILE_IDS = gm::LK_TG * gm::LK_GROUP;
+    const int lo = A.toff[b][v], hi = A.toff[b][v + 1];
+    int t0 = (lo / TILE_IDS) & ~1, t1 = ((hi + TILE_IDS - 1) / TILE_IDS + 1) & ~1;
+    if (t1 > n_tiles) t1 = n_tiles;
+    if (hi <= lo) t1 = t0;
+    const unsigned long long pairs = (unsigned long long)((c1 - c0 + 63) / 64) * 64ull * (unsigned long long)(t1 - t0) * TILE_IDS;
+    atomicAdd(&ctr->pairs, pairs);
+}
+
+__global__ __launch_bounds__(256) void k_collect_incomplete(const int32_t* __restrict__ counts, const int32_t* __restrict__ d1,
+                                                            int64_t n_q, int need, int32_t* __restrict__ inc,
+                                                            PgCounters* __restrict__ ctr) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_q) return;
+    const bool incomplete = counts != nullptr ? counts[i] < need : d1[i] < 0;
+    if (incomplete) inc[atomicAdd(&ctr->n_inc, 1)] = (int32_t)i;
+}
+
+__global__ __launch_bounds__(256) void k_gather_rows(const uint2* __restrict__ q, const int32_t* __restrict__ inc, int64_t n,
+                                                     uint2* __restrict__ q2) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) q2[j] = q[inc[j]];
+}
+
+__global__ __launch_bounds__(256) void k_scatter_rows(const int32_t* __restrict__ inc, int64_t n, int k,
+                                                      const int32_t* __restrict__ ids2, const int32_t* __restrict__ dists2,
+                                                      const int32_t* __restrict__ counts2, int32_t* __restrict__ ids,
+                                                      int32_t* __restrict__ dists, int32_t* __restrict__ counts) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * k) return;
+    const int64_t j = t / k;
+    const int s = (int)(t % k);
+    const int64_t row = inc[j];
+    if (ids != nullptr) ids[row * k + s] = ids2[t];
+    dists[row * k + s] = dists2[t];
+    if (counts != nullptr && s == 0) counts[row] = counts2[j];
+}
+
+template <class T>
+int ensure(T** p, int64_t* cap, int64_t need, const char* what) {
+    if (need <= *cap && *p != nullptr) return GM_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    if (need < 1) need = 1;
+    if (hipMalloc(reinterpret_cast<void**>(p), sizeof(T) * (size_t)need) != hipSuccess)
+        return gm_fail(GM_ERR_ALLOC, std::string("hipMalloc(") + what + ") failed");
+    *cap = need;
+    return GM_OK;
+}
+
+inline dim3 grid_for(int64_t n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
+
+}  // namespace
+
+struct gm_pigeon {
+    int B = 0;
+    int bstart[GM_PG_MAXB]{}, blen[GM_PG_MAXB]{};
+    int ebase[GM_PG_MAXB + 1]{};
+    // pool side
+    uint32_t* table[GM_PG_MAXB]{};
+    int32_t* perm[GM_PG_MAXB]{};
+    int32_t* toff[GM_PG_MAXB]{};
+    // query side (grow-only)
+    uint32_t* cperm[GM_PG_MAXB]{};
+    int64_t cperm_cap[GM_PG_MAXB]{};
+    int32_t* coff[GM_PG_MAXB]{};
+    uint32_t *k0 = nullptr, *k1 = nullptr, *r0 = nullptr, *r1 = nullptr;
+    int64_t k0_cap = 0, k1_cap = 0, r0_cap = 0, r1_cap = 0;
+    void* sort_tmp = nullptr;
+    size_t sort_tmp_cap = 0;
+    int *nch = nullptr, *cbase = nullptr, *hist = nullptr, *cursor = nullptr;
+    int64_t nch_cap = 0, cbase_cap = 0, hist_cap = 0, cursor_cap = 0;
+    gm_pg_chunk* chunks = nullptr;
+    int64_t chunks_cap = 0;
+    PgCounters* ctr = nullptr;
+    int64_t grid = 0;
+    uint32_t* keys = nullptr;
+    int64_t keys_cap = 0;
+    int32_t* inc = nullptr;
+    int64_t inc_cap = 0;
+    uint2* q2 = nullptr;
+    int64_t q2_cap = 0;
+    int32_t *ids2 = nullptr, *dists2 = nullptr, *counts2 = nullptr;
+    int64_t ids2_cap = 0, dists2_cap = 0, counts2_cap = 0;
+};
+
+namespace {
+
+int sort_pairs(gm_pigeon* pg, int64_t n, int bits, hipStream_t st) {
+    size_t bytes = 0;
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, bytes, pg->k0, pg->k1, pg->r0, pg->r1, (size_t)n, 0u, (unsigned)bits, st));
+    if (bytes > pg->sort_tmp_cap || pg->sort_tmp == nullptr) {
+        if (pg->sort_tmp) (void)hipFree(pg->sort_tmp);
+        pg->sort_tmp = nullptr;
+        pg->sort_tmp_cap = 0;
+        if (hipMalloc(&pg->sort_tmp, bytes ? bytes : 1) != hipSuccess)
+            return gm_fail(GM_ERR_ALLOC, "hipMalloc(radix sort workspace) failed");
+        pg->sort_tmp_cap = bytes;
+    }
+    HIP_TRY(rocprim::radix_sort_pairs(pg->sort_tmp, bytes, pg->k0, pg->k1, pg->r0, pg->r1, (size_t)n, 0u, (unsigned)bits, st));
+    return GM_OK;
+}
+
+int ensure_sort_buffers(gm_pigeon* pg, int64_t n) {
+    int rc;
+    if ((rc = ensure(&pg->k0, &pg->k0_cap, n, "sort keys"))) return rc;
+    if ((rc = ensure(&pg->k1, &pg->k1_cap, n, "sort keys"))) return rc;
+    if ((rc = ensure(&pg->r0, &pg->r0_cap, n, "sort rows"))) return rc;
+    return ensure(&pg->r1, &pg->r1_cap, n, "sort rows");
+}
+
+void free_pool_side(gm_pigeon* pg) {
+    for (int b = 0; b < GM_PG_MAXB; ++b) {
+        if (pg->table[b]) (void)hipFree(pg->table[b]);
+        if (pg->perm[b]) (void)hipFree(pg->perm[b]);
+        if (pg->toff[b]) (void)hipFree(pg->toff[b]);
+        if (pg->coff[b]) (void)hipFree(pg->coff[b]);
+        pg->table[b] = nullptr;
+        pg->perm[b] = nullptr;
+        pg->toff[b] = nullptr;
+        pg->coff[b] = nullptr;
+    }
+    pg->B = 0;
+}
+
+double log_choose(int n, int r) { return std::lgamma(n + 1.0) - std::lgamma(r + 1.0) - std::lgamma(n - r + 1.0); }
+
+}  // namespace
+
+// Layout choice under the uniform-base model: E(r) = expected pool targets within r mismatches of a
+// candidate; a candidate is incomplete when fewer than k of them exist (Poisson), and costs a plain scan.
+// Minimise  sum_b 4^-len(b)  +  P(incomplete)  over B = r + 1; 0 when the plain scan is at least as good.
+int gm_pg_plan(int64_t n_db, int L, int k) {
+    if (L < 12 || L > GM_MAX_GUIDELEN || n_db < 32768 || k < 1 || k > 20) return 0;
+    double best = 0.45;      // K1P has to be clearly cheaper than scanning everything
+    int best_B = 0;
+    double cum = 0.0;
+    for (int r = 0; r < GM_PG_MAXB; ++r) {
+        cum += std::exp(log_choose(L, r) + r * std::log(3.0) - L * std::log(4.0));
+        const int B = r + 1;
+        if (B < 2) continue;
+        const int base = L / B, extra = L % B;
+        if (base < 2 || base + (extra ? 1 : 0) > GM_PG_MAXLEN) continue;
+        double work = 0.0;
+        for (int b = 0; b < B; ++b) work += std::pow(4.0, -(double)(base + (b < extra ? 1 : 0)));
+        const double mean = (double)n_db * cum;
+        double p_inc = 0.0, term = std::exp(-mean);      // P(Poisson(mean) < k)
+        for (int j = 0; j < k; ++j) {
+            p_inc += term;
+            term *= mean / (j + 1);
+        }
+        if (mean > 700.0) p_inc = 0.0;
+        const double cost = work + (p_inc < 1.0 ? p_inc : 1.0);
+        if (cost < best) {
+            best = cost;
+            best_B = B;
+        }
+    }
+    return best_B;
+}
+
+int gm_pg_blocks_of(const gm_index* idx) { return idx->pg ? idx->pg->B : 0; }
+
+void gm_pg_free(gm_index* idx) {
+    gm_pigeon* pg = idx->pg;
+    if (!pg) return;
+    free_pool_side(pg);
+    for (int b = 0; b < GM_PG_MAXB; ++b)
+        if (pg->cperm[b]) (void)hipFree(pg->cperm[b]);
+    void* bufs[] = {pg->k0, pg->k1, pg->r0, pg->r1, pg->sort_tmp, pg->nch, pg->cbase, pg->hist, pg->cursor, pg->chunks, pg->ctr, pg->keys,
+                    pg->inc, pg->q2, pg->ids2, pg->dists2, pg->counts2};
+    for (void* p : bufs)
+        if (p) (void)hipFree(p);
+    delete pg;
+    idx->pg = nullptr;
+}
+
+int gm_pg_prepare(gm_index* idx, int B, hipStream_t st) {
+    if (B < 2 || B > GM_PG_MAXB) return gm_fail(GM_ERR_ARG, "gm_pg_prepare: bad block count");
+    if (!idx->pg) idx->pg = new gm_pigeon();
+    gm_pigeon* pg = idx->pg;
+    if (pg->B == B) return GM_OK;
+    free_pool_side(pg);
+    const int L = idx->L;
+    const int64_t n = idx->n_db;
+    const int base = L / B, extra = L % B;
+    int pos = 0;
+    pg->ebase[0] = 0;
+    for (int b = 0; b < B; ++b) {
+        pg->bstart[b] = pos;
+        pg->blen[b] = base + (b < extra ? 1 : 0);
+        pos += pg->blen[b];
+        pg->ebase[b + 1] = pg->ebase[b] + (1 << (2 * pg->blen[b]));
+    }
+    int rc;
+    if ((rc = ensure_sort_buffers(pg, n))) return rc;
+    if (!pg->ctr && hipMalloc(reinterpret_cast<void**>(&pg->ctr), sizeof(PgCounters)) != hipSuccess)
+        return gm_fail(GM_ERR_ALLOC, "hipMalloc(K1P counters) failed");
+    const int64_t n_groups = idx->n_lk_tiles * gm::LK_TG;
+    const int64_t words = n_groups * gm::lk_group_words(L);
+    uint2* sorted_planes = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&sorted_planes), sizeof(uint2) * (size_t)n) != hipSuccess)
+        return gm_fail(GM_ERR_ALLOC, "hipMalloc(sorted planes) failed");
+    for (int b = 0; b < B && rc == GM_OK; ++b) {
+        const int nb = 1 << (2 * pg->blen[b]);
+        if (hipMalloc(reinterpret_cast<void**>(&pg->table[b]), sizeof(uint32_t) * (size_t)words) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&pg->perm[b]), sizeof(int32_t) * (size_t)n) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&pg->toff[b]), sizeof(int32_t) * (size_t)(nb + 1)) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&pg->coff[b]), sizeof(int32_t) * (size_t)(nb + 1)) != hipSuccess) {
+            rc = gm_fail(GM_ERR_ALLOC, "hipMalloc(K1P pool copy) failed");
+            break;
+        }
+        hipLaunchKernelGGL(k_block_keys, grid_for(n), dim3(256), 0, st, idx->d_db, n, pg->bstart[b], pg->blen[b], pg->k0,
+                           pg->r0);
+        if ((rc = sort_pairs(pg, n, 2 * pg->blen[b], st))) break;
+        hipLaunchKernelGGL(k_bucket_offsets, grid_for(nb + 1), dim3(256), 0, st, pg->k1, n, nb, pg->toff[b]);
+        hipLaunchKernelGGL(k_gather_planes, grid_for(n), dim3(256), 0, st, idx->d_db, pg->r1, n, sorted_planes, pg->perm[b]);
+        hipLaunchKernelGGL(gm::k_to_onehot, grid_for(words), dim3(256), 0, st, sorted_planes, n, pg->table[b], n_groups, L);
+        if (hipGetLastError() != hipSuccess) rc = gm_fail(GM_ERR_DEVICE, "K1P pool-copy kernels failed to launch");
+    }
+    if (hipStreamSynchronize(st) != hipSuccess && rc == GM_OK) rc = gm_fail(GM_ERR_DEVICE, "K1P pool-copy build failed");
+    (void)hipFree(sorted_planes);
+    if (rc != GM_OK) {
+        free_pool_side(pg);
+        return rc;
+    }
+    pg->B = B;
+    return GM_OK;
+}
+
+// group the candidates in idx->d_q by every block's value and build the chunk table
+int gm_pg_candidates(gm_index* idx, int64_t n_q, hipStream_t st) {
+    gm_pigeon* pg = idx->pg;
+    if (!pg || pg->B < 2) return gm_fail(GM_ERR_ARG, "gm_pg_candidates: no layout prepared");
+    if (n_q >= (int64_t)1 << 31) return gm_fail(GM_ERR_ARG, "gm_pg_candidates: too many candidates");
+    int rc;
+    const int n_entries = pg->ebase[pg->B];
+    if ((rc = ensure(&pg->hist, &pg->hist_cap, n_entries, "bucket histogram"))) return rc;
+    if ((rc = ensure(&pg->cursor, &pg->cursor_cap, n_entries, "bucket cursors"))) return rc;
+    PgLayoutArg A{};
+    A.B = pg->B;
+    PgKeyArg K{};
+    K.B = pg->B;
+    int64_t grid = 0;
+    for (int b = 0; b <= pg->B; ++b) A.ebase[b] = K.ebase[b] = pg->ebase[b];
+    for (int b = 0; b < pg->B; ++b) {
+        if ((rc = ensure(&pg->cperm[b], &pg->cperm_cap[b], n_q, "candidate order"))) return rc;
+        K.bstart[b] = pg->bstart[b];
+        K.blen[b] = pg->blen[b];
+        K.coff[b] = pg->coff[b];
+        K.cperm[b] = pg->cperm[b];
+        A.coff[b] = pg->coff[b];
+        A.toff[b] = pg->toff[b];
+        grid += (n_q + 63) / 64 + (1 << (2 * pg->blen[b]));
+    }
+    // counting sort of the candidates by every block's value: histogram, per-block scan, scatter
+    const int use_lds = n_entries <= 8192 ? 1 : 0;
+    const size_t lds = use_lds ? sizeof(int) * (size_t)n_entries : 0;
+    HIP_TRY(hipMemsetAsync(pg->hist, 0, sizeof(int) * (size_t)n_entries, st));
+    hipLaunchKernelGGL(k_cand_hist, grid_for(n_q, 1024), dim3(1024), lds, st, idx->d_q, n_q, K, pg->hist, use_lds);
+    hipLaunchKernelGGL(k_cand_offsets, dim3(pg->B), dim3(1024), 0, st, K, pg->hist, pg->cursor);
+    hipLaunchKernelGGL(k_cand_scatter, grid_for(n_q, 1024), dim3(1024), lds, st, idx->d_q, n_q, K, pg->cursor, use_lds);
+    HIP_TRY(hipGetLastError());
+    if ((rc = ensure(&pg->nch, &pg->nch_cap, n_entries, "chunk counts"))) return rc;
+    if ((rc = ensure(&pg->cbase, &pg->cbase_cap, n_entries, "chunk offsets"))) return rc;
+    if ((rc = ensure(&pg->chunks, &pg->chunks_cap, grid, "chunk table"))) return rc;
+    HIP_TRY(hipMemsetAsync(pg->ctr, 0, sizeof(PgCounters), st));
+    hipLaunchKernelGGL(k_chunk_count, grid_for(n_entries), dim3(256), 0, st, A, pg->nch);
+    hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, st, pg->nch, n_entries, pg->cbase, &pg->ctr->n_chunks);
+    hipLaunchKernelGGL(k_fill_chunks, grid_for(n_entries), dim3(256), 0, st, A, pg->cbase, (int)idx->n_lk_tiles, pg->chunks,
+                       pg->ctr);
+    HIP_TRY(hipGetLastError());
+    pg->grid = grid;
+    return GM_OK;
+}
+
+int gm_pg_scan(gm_index* idx, int kcap, int64_t n_q, int k, uint32_t** keys_out, hipStream_t st) {
+    gm_pigeon* pg = idx->pg;
+    int rc;
+    if ((rc = ensure(&pg->keys, &pg->keys_cap, (int64_t)pg->B * n_q * kcap, "K1P lists"))) return rc;
+    gm_pg_blocks blocks{};
+    for (int b = 0; b < pg->B; ++b) {
+        blocks.table[b] = pg->table[b];
+        blocks.perm[b] = pg->perm[b];
+        blocks.toff[b] = pg->toff[b];
+        blocks.cperm[b] = pg->cperm[b];
+    }
+    const int thr0 = pg->B;      // accept d < B, i.e. d <= r
+    *keys_out = pg->keys;
+    switch (idx->L) {
+#define GM_CASE(LEN) \
+    case LEN: return gm_launch_pg_L##LEN(idx, kcap, &blocks, pg->chunks, &pg->ctr->n_chunks, pg->grid, n_q, k, thr0, pg->keys, st);
+        GM_FOR_EACH_LEN(GM_CASE)
+#undef GM_CASE
+        default: return gm_fail(GM_ERR_ARG, "pigeonhole kernel: guidelen out of range");
+    }
+}
+
+int gm_pg_incomplete(gm_index* idx, int64_t n_q, int need, const int32_t* counts, const int32_t* d1, int64_t* n_inc,
+                     int64_t* pairs_evaluated, hipStream_t st) {
+    gm_pigeon* pg = idx->pg;
+    int rc;
+    if ((rc = ensure(&pg->inc, &pg->inc_cap, n_q, "incomplete rows"))) return rc;
+    hipLaunchKernelGGL(k_collect_incomplete, grid_for(n_q), dim3(256), 0, st, counts, d1, n_q, need, pg->inc, pg->ctr);
+    HIP_TRY(hipGetLastError());
+    PgCounters h{};
+    HIP_TRY(hipMemcpyAsync(&h, pg->ctr, sizeof(PgCounters), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *n_inc = h.n_inc;
+    *pairs_evaluated = (int64_t)h.pairs;
+    return GM_OK;
+}
+
+int gm_pg_gather(gm_index* idx, int64_t n_inc, int k, bool nearest, const uint2** q2, int32_t** ids2, int32_t** dists2,
+                 int32_t** counts2, hipStream_t st) {
+    gm_pigeon* pg = idx->pg;
+    int rc;
+    if ((rc = ensure(&pg->q2, &pg->q2_cap, n_inc, "compact query"))) return rc;
+    if ((rc = ensure(&pg->ids2, &pg->ids2_cap, n_inc * k, "compact ids"))) return rc;
+    if ((rc = ensure(&pg->dists2, &pg->dists2_cap, n_inc * k, "compact distances"))) return rc;
+    if ((rc = ensure(&pg->counts2, &pg->counts2_cap, n_inc, "compact counts"))) return rc;
+    hipLaunchKernelGGL(k_gather_rows, grid_for(n_inc), dim3(256), 0, st, idx->d_q, pg->inc, n_inc, pg->q2);
+    HIP_TRY(hipGetLastError());
+    *q2 = pg->q2;
+    *ids2 = nearest ? nullptr : pg->ids2;
+    *dists2 = pg->dists2;
+    *counts2 = nearest ? nullptr : pg->counts2;
+    return GM_OK;
+}
+
+int gm_pg_scatter(gm_index* idx, int64_t n_inc, int k, bool nearest, int32_t* ids, int32_t* dists, int32_t* counts,
+                  hipStream_t st) {
+    gm_pigeon* pg = idx->pg;
+    hipLaunchKernelGGL(k_scatter_rows, grid_for(n_inc * k), dim3(256), 0, st, pg->inc, n_inc, k,
+                       nearest ? nullptr : pg->ids2, pg->dists2, nearest ? nullptr : pg->counts2, nearest ? nullptr : ids,
+                       dists, nearest ? nullptr : counts);
+    HIP_TRY(hipGetLastError());
+    return GM_OK;
+}

@@ -109,14 +109,14 @@ int ensure_u32(uint32_t** buf, int64_t* cap, int64_t need) {
 }
 
 int launch_merge(int kcap, const uint32_t* keys, int n_seg, int64_t n_q, int k, int32_t* ids, int32_t* dists,
-                 int32_t* counts, bool nearest, hipStream_t st) {
+                 int32_t* counts, bool nearest, hipStream_t st, bool slot_major = false) {
     const dim3 grid((unsigned)((n_q + 255) / 256)), block(256);
-    const int nr = nearest ? 1 : 0;
+    const int nr = nearest ? 1 : 0, sm = slot_major ? 1 : 0;
     switch (kcap) {
-        case 1: hipLaunchKernelGGL(gm::k_merge_lists<1>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
-        case 5: hipLaunchKernelGGL(gm::k_merge_lists<5>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
-        case 10: hipLaunchKernelGGL(gm::k_merge_lists<10>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
-        default: hipLaunchKernelGGL(gm::k_merge_lists<20>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
+        case 1: hipLaunchKernelGGL(gm::k_merge_lists<1>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr, sm); break;
+        case 5: hipLaunchKernelGGL(gm::k_merge_lists<5>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr, sm); break;
+        case 10: hipLaunchKernelGGL(gm::k_merge_lists<10>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr, sm); break;
+        default: hipLaunchKernelGGL(gm::k_merge_lists<20>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr, sm); break;
     }
     HIP_TRY(hipGetLastError());
     return GM_OK;
@@ -125,8 +125,9 @@ int launch_merge(int kcap, const uint32_t* keys, int n_seg, int64_t n_q, int k, 
 // K1L Hamming scan of the candidates in idx->d_q.  nearest: k = 1, distances only (into dists).
 // timed: record the HIP events around the dominant launch (false when used as the Levenshtein seeder).
 int run_hamming_lookup(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t* ids, int32_t* dists,
-                       int32_t* counts, bool timed, hipStream_t st) {
+                       int32_t* counts, bool timed, hipStream_t st, const uint2* qplanes = nullptr) {
     gm_lk_args a;
+    a.q = qplanes;
     a.kcap = nearest ? 1 : (idx->variant == 7 || k > 20 ? 0 : (k <= 5 ? 5 : (k <= 10 ? 10 : 20)));
     a.n_q = n_q;
     a.k = nearest ? 1 : k;
@@ -142,14 +143,17 @@ int run_hamming_lookup(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
     const int64_t want_items = (int64_t)idx->n_simd * 5 * per_slot;
     int64_t n_seg = (want_items + chunks - 1) / chunks;
     if (n_seg > n_tiles / 2) n_seg = n_tiles / 2;
-    if (n_seg > 512) n_seg = 512;
+    // the merge is one thread per candidate walking n_seg lists: with few candidates it is the serial part,
+    // so long lists get fewer segments (5 000 candidates, k = 10: 512 segments merged in 1.2 ms, 64 in 0.1 ms)
+    const int64_t seg_cap = a.kcap == 1 ? 512 : (a.kcap == 5 ? 128 : 64);
+    if (n_seg > seg_cap) n_seg = seg_cap;
     if (idx->variant >= 50 && idx->variant < 100) n_seg = idx->variant - 50;     // A/B knob: force the segment count
     int rc;
     if (a.kcap == 0 || n_seg < 2 || idx->variant == 9) {           // single pass over the whole pool
         a.n_seg = 1;
         a.tiles_per_seg = (int)n_tiles;
         if (timed && (rc = timing_begin(idx, st))) return rc;
-        idx->last_kernel = nearest ? "k_hamming_knn_lk(nearest)" : "k_hamming_knn_lk";
+        if (timed) idx->last_kernel = nearest ? "k_hamming_knn_lk(nearest)" : "k_hamming_knn_lk";
         if ((rc = launch_lk_len(idx, a, st))) return rc;
         return timed ? timing_end(idx, st, n_q * idx->n_db) : GM_OK;
     }
@@ -167,7 +171,7 @@ int run_hamming_lookup(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
     a.seg_base = 1;
     a.seed_keys = idx->d_keys;
     if (timed && (rc = timing_begin(idx, st))) return rc;
-    idx->last_kernel = nearest ? "k_hamming_knn_lk(nearest,seeded)" : "k_hamming_knn_lk(seeded)";
+    if (timed) idx->last_kernel = nearest ? "k_hamming_knn_lk(nearest,seeded)" : "k_hamming_knn_lk(seeded)";
     if ((rc = launch_lk_len(idx, a, st))) return rc;               // phase B: the dominant launch
     const int64_t seg0 = tps * gm::LK_TG * gm::LK_GROUP;          // pool targets covered by segment 0
     const int64_t in_b = idx->n_db > seg0 ? idx->n_db - seg0 : 0;
@@ -225,9 +229,52 @@ int run_leven_lookup(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* d
                    : launch_merge(kcap, idx->d_keys2, n_seg, n_q, k, ids, dists, counts, false, st);
 }
 
+// K1P (gm_pigeon.hip): exact Hamming k-NN from B block-sorted pool copies, then the plain scan for the few
+// candidates whose merged list did not fill.  Returns through *used whether K1P ran (the layout planner
+// may decide that the plain scan is the better choice for this pool / k).
+int run_hamming_pigeon(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t* ids, int32_t* dists,
+                       int32_t* counts, hipStream_t st, bool* used) {
+    *used = false;
+    const int keff = nearest ? 1 : k;
+    if (keff > 20 || idx->n_db < keff || n_q < 1) return GM_OK;
+    // variants 102..108 force a layout of 2..8 blocks (tests, A/B); the result is exact for any layout
+    const bool forced = idx->variant >= 102 && idx->variant <= 100 + GM_PG_MAXB;
+    const int B = forced ? idx->variant - 100 : gm_pg_plan(idx->n_db, idx->L, keff);
+    if (B == 0 || idx->L / B < 1) return GM_OK;
+    const int max_len = (idx->L + B - 1) / B;
+    if (max_len > GM_PG_MAXLEN) return GM_OK;
+    // enough candidates per bucket to fill the 64-lane chunks (measured break-even on a 600k pool: ~10k)
+    if (!forced && n_q < (int64_t)160 << (2 * max_len)) return GM_OK;
+    int rc;
+    if ((rc = gm_pg_prepare(idx, B, st))) return rc;
+    if ((rc = gm_pg_candidates(idx, n_q, st))) return rc;
+    const int kcap = nearest ? 1 : (k <= 5 ? 5 : (k <= 10 ? 10 : 20));
+    uint32_t* keys = nullptr;
+    if ((rc = timing_begin(idx, st))) return rc;
+    idx->last_kernel = nearest ? "k_hamming_knn_pg(nearest)" : "k_hamming_knn_pg";
+    if ((rc = gm_pg_scan(idx, kcap, n_q, keff, &keys, st))) return rc;
+    if ((rc = timing_end(idx, st, n_q * idx->n_db))) return rc;
+    if ((rc = launch_merge(kcap, keys, B, n_q, keff, ids, dists, counts, nearest, st, true))) return rc;
+    int64_t n_inc = 0, pairs = 0;
+    if ((rc = gm_pg_incomplete(idx, n_q, keff, nearest ? nullptr : counts, nearest ? dists : nullptr, &n_inc, &pairs,
+                               st)))
+        return rc;
+    idx->last_evaluated = pairs;
+    idx->last_incomplete = n_inc;
+    if (n_inc > 0) {
+        const uint2* q2 = nullptr;
+        int32_t *ids2 = nullptr, *dists2 = nullptr, *counts2 = nullptr;
+        if ((rc = gm_pg_gather(idx, n_inc, keff, nearest, &q2, &ids2, &dists2, &counts2, st))) return rc;
+        if ((rc = run_hamming_lookup(idx, nearest, n_inc, keff, ids2, dists2, counts2, false, st, q2))) return rc;
+        if ((rc = gm_pg_scatter(idx, n_inc, keff, nearest, ids, dists, counts, st))) return rc;
+    }
+    *used = true;
+    return GM_OK;
+}
+
 // variant 0 = default (K1L look-up kernel), 1 = popcount kernel K1, 5 and 2x/3x = K1v knobs
 bool use_lookup(const gm_index* idx) {
-    return idx->metric == GM_METRIC_HAMMING && idx->d_onehot != nullptr && (idx->variant == 0 || idx->variant == 7 || idx->variant == 9 || (idx->variant >= 40 && idx->variant < 100));
+    return idx->metric == GM_METRIC_HAMMING && idx->d_onehot != nullptr && (idx->variant == 0 || idx->variant == 7 || idx->variant == 8 || idx->variant == 9 || (idx->variant >= 40 && idx->variant < 100) || (idx->variant >= 102 && idx->variant <= 100 + GM_PG_MAXB));
 }
 
 bool use_bitslice(const gm_index* idx) {
@@ -248,6 +295,8 @@ int timing_end(gm_index* idx, hipStream_t st, int64_t pairs) {
     }
     idx->timed = true;
     idx->last_pairs = pairs;
+    idx->last_evaluated = pairs;
+    idx->last_incomplete = 0;
     return GM_OK;
 }
 
@@ -429,6 +478,7 @@ void gm_index_free(gm_index* idx) {
     (void)hipSetDevice(idx->device);
     if (idx->d_db) (void)hipFree(idx->d_db);
     if (idx->d_vert) (void)hipFree(idx->d_vert);
+    gm_pg_free(idx);
     if (idx->d_onehot) (void)hipFree(idx->d_onehot);
     if (idx->d_peq) (void)hipFree(idx->d_peq);
     if (idx->d_keys) (void)hipFree(idx->d_keys);
@@ -489,7 +539,14 @@ static int knn_query_dev_impl(gm_index* idx, const void* d_q, int64_t n_q, int k
     rc = planes_launch(static_cast<const uint64_t*>(d_q), idx->d_q, n_q, n_q, st);
     if (rc) return rc;
     if (use_leven_lookup(idx, k)) return run_leven_lookup(idx, n_q, k, ids, dists, counts, nullptr, st);
-    if (use_lookup(idx)) return run_hamming_lookup(idx, false, n_q, k, ids, dists, counts, true, st);
+    if (use_lookup(idx)) {
+        if (idx->variant == 0 || idx->variant > 100) {      // (variant 8 = plain two-phase scan, the A/B baseline of K1P)
+            bool used = false;
+            int rc = run_hamming_pigeon(idx, false, n_q, k, ids, dists, counts, st, &used);
+            if (rc || used) return rc;
+        }
+        return run_hamming_lookup(idx, false, n_q, k, ids, dists, counts, true, st);
+    }
     rc = timing_begin(idx, st);
     if (rc) return rc;
     const int R = pick_r(k);
@@ -562,7 +619,14 @@ static int nearest_dist_dev_impl(gm_index* idx, const void* d_q, int64_t n_q, vo
     rc = planes_launch(static_cast<const uint64_t*>(d_q), idx->d_q, n_q, n_q, st);
     if (rc) return rc;
     if (use_leven_lookup(idx, 1)) return run_leven_lookup(idx, n_q, 1, nullptr, nullptr, nullptr, d1, st);
-    if (use_lookup(idx)) return run_hamming_lookup(idx, true, n_q, 1, nullptr, d1, nullptr, true, st);
+    if (use_lookup(idx)) {
+        if (idx->variant == 0 || idx->variant > 100) {
+            bool used = false;
+            int rc = run_hamming_pigeon(idx, true, n_q, 1, nullptr, d1, nullptr, st, &used);
+            if (rc || used) return rc;
+        }
+        return run_hamming_lookup(idx, true, n_q, 1, nullptr, d1, nullptr, true, st);
+    }
     int n_tiles = (int)(idx->n_db_pad / gm::TILE);
     rc = timing_begin(idx, st);
     if (rc) return rc;
@@ -725,5 +789,7 @@ double gm_last_query_ms(gm_index* idx) {
 
 const char* gm_last_kernel_name(gm_index* idx) { return idx ? idx->last_kernel : ""; }
 int64_t gm_last_kernel_pairs(gm_index* idx) { return idx ? idx->last_pairs : 0; }
+int64_t gm_last_kernel_evaluated(gm_index* idx) { return idx ? idx->last_evaluated : 0; }
+int64_t gm_last_incomplete(gm_index* idx) { return idx ? idx->last_incomplete : 0; }
 
 }  // extern "C"

@@ -136,6 +136,11 @@ double gm_last_kernel_ms(gm_index* idx);
 double gm_last_query_ms(gm_index* idx);
 const char* gm_last_kernel_name(gm_index* idx);
 int64_t gm_last_kernel_pairs(gm_index* idx);
+/* The pigeonhole-partitioned Hamming scan (K1P) resolves n_q * n_db pairs but evaluates only those that
+ * share a block: the pairs its launch really computed, and the number of candidates it handed to the plain
+ * scan afterwards (both equal the plain figures / 0 for the other kernels). */
+int64_t gm_last_kernel_evaluated(gm_index* idx);
+int64_t gm_last_incomplete(gm_index* idx);
 
 /* Per-launch timing history: gm_timing_reserve(idx, n) arms n HIP-event pairs (and resets the
  * history); every later scan-kernel launch on this handle records into the next pair (wrapping);

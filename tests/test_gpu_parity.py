@@ -368,6 +368,66 @@ def test_kernel_variants_agree(oracle):
     idx.close()
 
 
+@pytest.mark.parametrize("L,B", [(12, 4), (16, 8), (20, 4), (20, 7), (23, 5), (27, 8)])
+def test_pigeonhole_layouts_match_oracle(oracle, L, B):
+    """K1P, the pigeonhole-partitioned scan, with a forced layout (variant 100 + B).  It must be exact for
+    any block count: candidates whose merged lists do not fill are re-scanned by the plain kernel, so a
+    small pool with planted near-duplicates exercises the bucket scan, the duplicate-dropping merge and the
+    re-scan.  The skewed base composition gives crowded and empty buckets."""
+    rng = random.Random(1000 * L + B)
+    skew = "AAAAACCGT"
+    db = ["".join(rng.choice(skew) for _ in range(L)) for _ in range(5000)]
+    for _ in range(2500):      # near-duplicates: 1-4 substitutions
+        src = list(db[rng.randrange(len(db))])
+        for p in rng.sample(range(L), rng.randint(1, 4)):
+            src[p] = rng.choice("ACGT")
+        db.append("".join(src))
+    db = list(dict.fromkeys(db))
+    rng.shuffle(db)
+    q = db[::2] + ["".join(rng.choice("ACGT") for _ in range(L)) for _ in range(700)] + db[:5]
+    idx = _lib.Index(_lib.pack(db, L), L, _lib.METRIC_HAMMING)
+    idx.set_variant(100 + B)
+    qp = _lib.pack(q, L)
+    for k in (2, 5, 10, 20):
+        ids, dists, counts = idx.knn(qp, k)
+        assert idx.last_kernel()[0].startswith("k_hamming_knn_pg"), "the forced layout was not used"
+        oi, od, oc = _oracle_true_units(oracle, db, q, L, "hamming", k)
+        assert (counts == oc).all() and (dists == od).all() and (ids == oi).all(), (L, B, k)
+    d1 = idx.nearest(qp)
+    assert idx.last_kernel()[0].startswith("k_hamming_knn_pg")
+    assert (d1 == _oracle_true_units(oracle, db, q, L, "hamming", 1)[1][:, 0]).all()
+    evaluated, rescanned = idx.last_evaluated()
+    assert evaluated > 0      # (no saving expected here: tile and chunk padding dominate a 7k pool)
+    idx.close()
+
+
+def test_pigeonhole_default_path_sampled_oracle(oracle):
+    """Pool large enough for the planner to choose K1P on its own: compare a sample with the oracle over
+    the full pool, and the whole result with the plain two-phase scan (variant 8)."""
+    L, k, n = 20, 10, 300_000
+    rng = np.random.default_rng(11)
+    packed = np.unique(core.pack_codes(rng.integers(0, 4, size=(n, L), dtype=np.uint8)))
+    rng.shuffle(packed)
+    idx = _lib.Index(packed, L, _lib.METRIC_HAMMING)
+    q = np.concatenate([packed[:60_000], core.pack_codes(rng.integers(0, 4, size=(20_000, L), dtype=np.uint8))])
+    ids, dists, counts = idx.knn(q, k)
+    assert idx.last_kernel()[0] == "k_hamming_knn_pg"
+    evaluated, rescanned = idx.last_evaluated()
+    assert evaluated < 0.5 * q.shape[0] * packed.shape[0]
+    idx.set_variant(8)
+    i8, d8, c8 = idx.knn(q, k)
+    assert idx.last_kernel()[0].startswith("k_hamming_knn_lk")
+    assert (i8 == ids).all() and (d8 == dists).all() and (c8 == counts).all()
+    idx.set_variant(0)
+    d1 = idx.nearest(q)
+    assert idx.last_kernel()[0] == "k_hamming_knn_pg(nearest)" and (d1 == dists[:, 0]).all()
+    sample = rng.choice(q.shape[0], size=48, replace=False)
+    db_str = _lib.unpack(packed, L)
+    oi, od, oc = _oracle_true_units(oracle, db_str, _lib.unpack(q[sample], L), L, "hamming", k)
+    assert (oi == ids[sample]).all() and (od == dists[sample]).all() and (oc == counts[sample]).all()
+    idx.close()
+
+
 def test_many_segments_leven(oracle):
     # few candidates x larger pool -> the Levenshtein scan splits the pool into many segments + merge
     L = 23

@@ -43,7 +43,8 @@ def main():
             else:
                 out = idx.knn(q, a.k)
             name, ms, pairs = idx.last_kernel()
-            names[v] = name
+            ev, inc = idx.last_evaluated()
+            names[v] = name if ev == pairs else "%s[eval %.1f%%, %d re-scanned]" % (name, 100.0 * ev / max(pairs, 1), inc)
             if r > 0:
                 times[v].append(idx.last_query_ms())     # whole query: all phases + merge, device time
                 ktimes[v].append(ms)
@@ -54,7 +55,7 @@ def main():
                     assert all((x == y).all() for x, y in zip(ref, out)), "variant %d differs" % v
     for v in variants:
         t = np.array(times[v])
-        print("variant %3d %-32s n_db=%d n_q=%d k=%d: query median %.3f ms min %.3f ms (dominant kernel %.3f ms)"
+        print("variant %3d %-40s n_db=%d n_q=%d k=%d: query median %.3f ms min %.3f ms (dominant kernel %.3f ms)"
               "  -> %.3e pairs/s"
               % (v, names[v], len(db), len(q), a.k, np.median(t), t.min(), np.median(ktimes[v]),
                  len(db) * len(q) / (np.median(t) * 1e-3)))
