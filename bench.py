@@ -235,6 +235,9 @@ def main():
         # pairs evaluated by ONE launch of the dominant kernel (the seeded phase of the two-phase scan
         # covers all pool segments but the first), as counted by the library
         launch_pairs = float(idx.last_kernel()[2])
+        # K1P resolves launch_pairs (all candidate x target pairs) but evaluates only those sharing a block
+        evaluated_pairs, rescanned = idx.last_evaluated()
+        evaluated_pairs = float(evaluated_pairs)
         achieved = launch_pairs * B_ALG[pool["metric"]] / kern_s / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -263,13 +266,17 @@ def main():
                                     "for Levenshtein (SURVEY.md 8d)"}
         if pool["metric"] == "hamming" and 10 <= L <= 27:
             opp = lookup_ops_per_pair(L)
-            ops = launch_pairs * opp / kern_s
+            ops = evaluated_pairs * opp / kern_s
+            roof["pairs_evaluated"] = evaluated_pairs
+            roof["candidates_rescanned"] = int(rescanned)
             roof["valu"] = {"achieved": ops / 1e12, "peak": VALU_LANE_OPS_PER_S / 1e12,
                             "unit": "T lane-ops/s", "frac": ops / VALU_LANE_OPS_PER_S,
                             "ops_per_pair": opp,
                             "lds_reads_per_pair": L / 64.0,
                             "note": "the binding roofs: int32 VALU issue (256 CUs x 128 lanes/clk x 2.4 GHz) "
-                                    "and LDS read issue (L ds_read_b64 per 64 pairs per lane)"}
+                                    "and LDS read issue (L ds_read_b64 per 64 pairs per lane); computed on the "
+                                    "pairs the launch EVALUATED (pairs_evaluated; the pigeonhole-partitioned "
+                                    "scan resolves pairs_per_launch pairs by evaluating a fraction of them)"}
         # the ALGORITHMIC op model (4 int32 ops per Hamming pair for the popcount form,
         # 17 L per Levenshtein pair for per-pair Myers) against 256 CUs x 64 lanes/clk x 2.4 GHz; > 1 means
         # the bit-sliced kernels need fewer instructions than that model assumes

@@ -80,21 +80,23 @@ GM_FOR_EACH_LEN(GM_DECL_LK)
 #undef GM_DECL_LK
 
 // K1P launchers, one per guide length (gm_inst_lk.hip): grid = upper bound of the chunk count
-#define GM_DECL_PG(LEN)                                                                                          \
-    int gm_launch_pg_L##LEN(gm_index* idx, int kcap, const gm_pg_blocks* blocks, const gm_pg_chunk* chunks,       \
-                            const int* n_chunks, int64_t grid, int64_t n_q, int k, int thr0, uint32_t* out_keys, \
-                            hipStream_t st);
+#define GM_DECL_PG(LEN)                                                                                      \
+    int gm_launch_pg_L##LEN(gm_index* idx, const gm_pg_blocks* blocks, const gm_pg_chunk* chunks,             \
+                            const int* n_chunks, int64_t grid, int64_t n_q, int thr0, int cap, uint32_t* hits, \
+                            int32_t* n_hits, hipStream_t st);
 GM_FOR_EACH_LEN(GM_DECL_PG)
 #undef GM_DECL_PG
 
 // K1P host side (gm_pigeon.hip).  gm_pg_plan: number of blocks B (0 = the plain scan is the better choice);
 // gm_pg_prepare: block-sorted pool copies for B; gm_pg_candidates: group the candidates in idx->d_q;
-// gm_pg_scan: the K1P launch; gm_pg_incomplete: rows whose merged list is not full (device list + count,
+// gm_pg_scan: the K1P launch; gm_pg_merge: slot lists -> top k; gm_pg_incomplete: rows whose merged list is not full (device list + count,
 // synchronises the stream); gm_pg_gather / gm_pg_scatter: move those rows to / from a compact query.
 int gm_pg_plan(int64_t n_db, int L, int k);
 int gm_pg_prepare(gm_index* idx, int B, hipStream_t st);
 int gm_pg_candidates(gm_index* idx, int64_t n_q, hipStream_t st);
-int gm_pg_scan(gm_index* idx, int kcap, int64_t n_q, int k, uint32_t** keys_out, hipStream_t st);
+int gm_pg_scan(gm_index* idx, int64_t n_q, int k, hipStream_t st);
+int gm_pg_merge(gm_index* idx, int kcap, int64_t n_q, int k, int32_t* ids, int32_t* dists, int32_t* counts,
+                bool nearest, hipStream_t st);
 int gm_pg_incomplete(gm_index* idx, int64_t n_q, int need, const int32_t* counts, const int32_t* d1,
                      int64_t* n_inc, int64_t* pairs_evaluated, hipStream_t st);
 int gm_pg_gather(gm_index* idx, int64_t n_inc, int k, bool nearest, const uint2** q2, int32_t** ids2,

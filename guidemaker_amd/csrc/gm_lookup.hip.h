@@ -333,17 +333,53 @@ __global__ __launch_bounds__(WAVE, lk_min_waves(L, KCAP)) void k_hamming_knn_lk(
 // exactly on at least one block, so for block b it is enough to compare a candidate with the pool targets
 // that have the same bases on block b: the pool is stored B times, stable-sorted by the block's value
 // (ids ascend inside a bucket), with one one-hot table per copy; candidates are grouped by the same value
-// into chunks of <= 64 that never straddle a bucket.  Workgroup = one chunk: K1L's scan over the tiles
-// that cover the bucket (rounded outwards; hits outside the bucket's own range are ignored, they belong to
-// another workgroup), bound fixed at d < B, positions translated to ids through the copy's permutation.  Every candidate
-// gets one list per block; k_merge_lists folds them (a pair sharing several blocks appears in several).
-// A candidate whose merged list is full is exact (everything within r was enumerated); the others are
-// re-scanned by the plain kernel (host side, gmhip.hip).
+// into chunks of <= 64 that never straddle a bucket.  Workgroup = one chunk: K1L's look-ups, adder trees
+// and comparator over the tiles that cover the bucket (rounded outwards; hits outside the bucket's own
+// range are ignored, they belong to another workgroup) with the bound fixed at d < B.
+// Inside a bucket hits are frequent (the pairs already share a block) and only one to three lanes of a wave
+// take part in each visit of the slow path, so it does the minimum: APPEND (distance << 27 | position) to the
+// lane's slot list hits[b][slot][candidate] in HBM -- no sorted register list, no bound updates, and the
+// kernel does not depend on k.  k_merge_hits (one thread per candidate, all lanes busy) translates positions
+// to pool ids, drops the pairs that were found under several blocks and selects the top k.  A candidate
+// whose merged list is full is exact (everything within r was enumerated); the others, and those whose slot
+// list overflowed, are re-scanned by the plain kernel (host side, gmhip.hip).
 // ---------------------------------------------------------------------------------------------------
-template <int L, int KCAP>
-__global__ __launch_bounds__(WAVE, lk_min_waves(L, KCAP)) void k_hamming_knn_pg(
-    gm_pg_blocks P, const gm_pg_chunk* __restrict__ chunks, const int* __restrict__ n_chunks, int n_db, int n_tiles,
-    const uint2* __restrict__ q, int64_t n_q, int k, int thr0, uint32_t* __restrict__ out_keys) {
+template <int L>
+__device__ __forceinline__ void pg_append_hits(uint32_t hits, const uint32_t (&c)[5], int id0, int lo, int hi, int thr,
+                                               int cap, int64_t n_q, uint32_t* __restrict__ slot0, int& cnt) {
+    while (hits != 0u) {
+        const int j = __builtin_ctz(hits);
+        hits &= hits - 1u;
+        const int matches = (int)(((c[0] >> j) & 1u) | (((c[1] >> j) & 1u) << 1) | (((c[2] >> j) & 1u) << 2) |
+                                  (((c[3] >> j) & 1u) << 3) | (((c[4] >> j) & 1u) << 4));
+        const int d = L - matches;
+        const int pos = id0 + j;
+        if (d < thr && pos >= lo && pos < hi) {
+            if (cnt < cap) slot0[(int64_t)cnt * n_q] = ((uint32_t)d << ID_BITS) | (uint32_t)pos;
+            ++cnt;
+        }
+    }
+}
+
+template <int L>
+__device__ __forceinline__ void pg_process_group(const LkGroupRegs<L>& r, int id0, int lo, int hi, int thr,
+                                                 const uint32_t (&Tb)[5], int cap, int64_t n_q,
+                                                 uint32_t* __restrict__ slot0, int& cnt) {
+    uint32_t c0[5], c1[5];
+    const uint32_t h0 = lk_eval_half<L>(r.m0, Tb, c0);
+    const uint32_t h1 = lk_eval_half<L>(r.m1, Tb, c1);
+    if (__builtin_amdgcn_ballot_w64((h0 | h1) != 0u) != 0ull) {
+        pg_append_hits<L>(h0, c0, id0, lo, hi, thr, cap, n_q, slot0, cnt);
+        pg_append_hits<L>(h1, c1, id0 + 32, lo, hi, thr, cap, n_q, slot0, cnt);
+    }
+}
+
+// hits: [B][cap][n_q] keys (distance << 27 | position in copy b), n_hits: [B][n_q] (> cap: overflow)
+template <int L>
+__global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
+    gm_pg_blocks P, const gm_pg_chunk* __restrict__ chunks, const int* __restrict__ n_chunks, int n_tiles,
+    const uint2* __restrict__ q, int64_t n_q, int thr0, int cap, uint32_t* __restrict__ hits,
+    int32_t* __restrict__ n_hits) {
     extern __shared__ __align__(16) uint32_t smem[];
     constexpr int TILE_W = lk_tile_bytes(L) / 4;
     constexpr int GW = lk_group_words(L);
@@ -351,7 +387,6 @@ __global__ __launch_bounds__(WAVE, lk_min_waves(L, KCAP)) void k_hamming_knn_pg(
     if ((int)blockIdx.x >= *n_chunks) return;
     const gm_pg_chunk ch = chunks[blockIdx.x];
     const uint32_t* __restrict__ table = P.table[ch.b];
-    const int32_t* __restrict__ perm = P.perm[ch.b];
     uint32_t* tiles = smem;
     const int lane = threadIdx.x;
     const bool valid = lane < ch.cn;
@@ -364,12 +399,11 @@ __global__ __launch_bounds__(WAVE, lk_min_waves(L, KCAP)) void k_hamming_knn_pg(
         uint32_t code = ((qv.x >> p) & 1u) | (((qv.y >> p) & 1u) << 1);
         ptr[p] = tiles + p * 8 + (int)code * 2;
     }
-    RegList<KCAP> list;
-    list.init(k, nullptr, lane);
-    const int thr_seed = thr0;
-    int thr = valid ? thr_seed : 0;
+    const int thr = valid ? thr0 : 0;
     uint32_t Tb[5];
     lk_set_bound(Tb, L, thr);
+    uint32_t* slot0 = hits + (int64_t)ch.b * cap * n_q + qi;      // slot s of this lane: slot0[s * n_q]
+    int cnt = 0;
 
     // tiles covering the bucket's targets [lo, hi) in this copy, widened to an even tile range
     const int lo = P.toff[ch.b][ch.v], hi = P.toff[ch.b][ch.v + 1];
@@ -389,7 +423,7 @@ __global__ __launch_bounds__(WAVE, lk_min_waves(L, KCAP)) void k_hamming_knn_pg(
             if (gl == 1) lk_read_group<L, 1 * GW>(r, ptr);
             if (gl == 2) lk_read_group<L, 2 * GW>(r, ptr);
             if (gl == 3) lk_read_group<L, 3 * GW>(r, ptr);
-            lk_process_group<L, RegList<KCAP>>(r, (t * LK_TG + gl) * LK_GROUP, hi, list, thr, thr_seed, Tb, lo);
+            pg_process_group<L>(r, (t * LK_TG + gl) * LK_GROUP, lo, hi, thr, Tb, cap, n_q, slot0, cnt);
         }
         lk_stage_wait();
         if (t + 2 < t1) lk_stage<L>(table, t + 2, tiles, lane);
@@ -400,50 +434,55 @@ __global__ __launch_bounds__(WAVE, lk_min_waves(L, KCAP)) void k_hamming_knn_pg(
             if (gl == 1) lk_read_group<L, TILE_W + 1 * GW>(r, ptr);
             if (gl == 2) lk_read_group<L, TILE_W + 2 * GW>(r, ptr);
             if (gl == 3) lk_read_group<L, TILE_W + 3 * GW>(r, ptr);
-            lk_process_group<L, RegList<KCAP>>(r, ((t + 1) * LK_TG + gl) * LK_GROUP, hi, list, thr, thr_seed, Tb, lo);
+            pg_process_group<L>(r, ((t + 1) * LK_TG + gl) * LK_GROUP, lo, hi, thr, Tb, cap, n_q, slot0, cnt);
         }
     }
-    if (valid) {      // positions -> pool ids; slot-major lists [b][slot][candidate]: the merge reads them coalesced
-#pragma unroll
-        for (int s = 0; s < KCAP; ++s) {
-            uint32_t v = list.v[s];
-            if (v != 0u && v != RegList<KCAP>::EMPTY) {
-                const uint32_t key = v - 1u;
-                v = ((key & ~ID_MASK) | (uint32_t)perm[key & ID_MASK]) + 1u;
-            }
-            out_keys[((int64_t)ch.b * KCAP + s) * n_q + qi] = v;
-        }
-    }
+    if (valid) n_hits[(int64_t)ch.b * n_q + qi] = cnt;
 }
 
-// fold per-segment raw RegList<KCAP> lists [n_seg][n_q][KCAP] into the final top-k.  One thread per candidate.
-// Keys occurring in more than one list (K1P: a pair that shares several blocks) are taken once.
-// slot_major = 0: lists [n_seg][n_q][KCAP] (the segmented scans); 1: [n_seg][KCAP][n_q] (K1P; the lists are
-// sorted with the unused slots at the end, so a list is left at its first empty slot).
+// K1P merge: one thread per candidate folds its B slot lists into the top k (duplicates taken once).
+// A slot list that overflowed makes the row incomplete (count 0 / distance -1): the host re-scans it.
 template <int KCAP>
-__global__ void k_merge_lists(const uint32_t* __restrict__ keys, int n_seg, int64_t n_q, int k,
-                              int32_t* __restrict__ ids, int32_t* __restrict__ dists,
-                              int32_t* __restrict__ counts, int nearest, int slot_major) {
+__global__ void k_merge_hits(gm_pg_blocks P, int B, int cap, const uint32_t* __restrict__ hits,
+                             const int32_t* __restrict__ n_hits, int64_t n_q, int k, int32_t* __restrict__ ids,
+                             int32_t* __restrict__ dists, int32_t* __restrict__ counts, int nearest) {
     const int64_t qi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (qi >= n_q) return;
     RegList<KCAP> list;
     list.init(k, nullptr, 0);
-    if (slot_major) {
-        for (int s = 0; s < n_seg; ++s) {
-            for (int i = 0; i < KCAP; ++i) {
-                const uint32_t v = keys[((int64_t)s * KCAP + i) * n_q + qi];
-                if (v == RegList<KCAP>::EMPTY) break;
-                if (v != 0u) list.insert_unique(v - 1u);
-            }
+    bool overflow = false;
+    for (int b = 0; b < B; ++b) {
+        int c = n_hits[(int64_t)b * n_q + qi];
+        if (c > cap) {
+            overflow = true;
+            c = cap;
         }
-    } else {
-        for (int s = 0; s < n_seg; ++s) {
-            const uint32_t* in = keys + ((int64_t)s * n_q + qi) * KCAP;
+        const int32_t* __restrict__ perm = P.perm[b];
+        const uint32_t* slot0 = hits + (int64_t)b * cap * n_q + qi;
+        for (int i = 0; i < c; ++i) {
+            const uint32_t key = slot0[(int64_t)i * n_q];
+            list.insert_unique((key & ~ID_MASK) | (uint32_t)perm[key & ID_MASK]);
+        }
+    }
+    if (overflow) list.init(k, nullptr, 0);
+    list.store(k, qi, ids, dists, counts, nearest != 0);
+}
+
+// fold per-segment raw RegList<KCAP> lists [n_seg][n_q][KCAP] into the final top-k.  One thread per candidate.
+template <int KCAP>
+__global__ void k_merge_lists(const uint32_t* __restrict__ keys, int n_seg, int64_t n_q, int k,
+                              int32_t* __restrict__ ids, int32_t* __restrict__ dists,
+                              int32_t* __restrict__ counts, int nearest) {
+    const int64_t qi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi >= n_q) return;
+    RegList<KCAP> list;
+    list.init(k, nullptr, 0);
+    for (int s = 0; s < n_seg; ++s) {
+        const uint32_t* in = keys + ((int64_t)s * n_q + qi) * KCAP;
 #pragma unroll
-            for (int i = 0; i < KCAP; ++i) {
-                const uint32_t v = in[i];
-                if (v != 0u && v != RegList<KCAP>::EMPTY) list.insert_unique(v - 1u);
-            }
+        for (int i = 0; i < KCAP; ++i) {
+            const uint32_t v = in[i];
+            if (v != 0u && v != RegList<KCAP>::EMPTY) list.insert(v - 1u);
         }
     }
     list.store(k, qi, ids, dists, counts, nearest != 0);

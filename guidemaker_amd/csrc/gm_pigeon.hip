@@ -311,8 +311,12 @@ struct gm_pigeon {
     int64_t chunks_cap = 0;
     PgCounters* ctr = nullptr;
     int64_t grid = 0;
-    uint32_t* keys = nullptr;
+    uint32_t* keys = nullptr;     // slot lists [B][cap][n_q]
     int64_t keys_cap = 0;
+    int32_t* n_hits = nullptr;    // [B][n_q]
+    int64_t n_hits_cap = 0;
+    int cap = 0;
+    gm_pg_blocks blocks{};
     int32_t* inc = nullptr;
     int64_t inc_cap = 0;
     uint2* q2 = nullptr;
@@ -405,7 +409,7 @@ void gm_pg_free(gm_index* idx) {
     for (int b = 0; b < GM_PG_MAXB; ++b)
         if (pg->cperm[b]) (void)hipFree(pg->cperm[b]);
     void* bufs[] = {pg->k0, pg->k1, pg->r0, pg->r1, pg->sort_tmp, pg->nch, pg->cbase, pg->hist, pg->cursor, pg->chunks, pg->ctr, pg->keys,
-                    pg->inc, pg->q2, pg->ids2, pg->dists2, pg->counts2};
+                    pg->n_hits, pg->inc, pg->q2, pg->ids2, pg->dists2, pg->counts2};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     delete pg;
@@ -511,11 +515,36 @@ int gm_pg_candidates(gm_index* idx, int64_t n_q, hipStream_t st) {
     return GM_OK;
 }
 
-int gm_pg_scan(gm_index* idx, int kcap, int64_t n_q, int k, uint32_t** keys_out, hipStream_t st) {
+// slots per (candidate, block): mean + 6 sigma of the hits expected under the uniform-base model
+// (pool targets in the bucket x P(at most r mismatches on the other positions)), at least 16
+static int pg_slot_capacity(const gm_index* idx, const gm_pigeon* pg, int64_t n_q) {
+    const int L = idx->L, r = pg->B - 1;
+    double worst = 0.0;
+    for (int b = 0; b < pg->B; ++b) {
+        const int rest = L - pg->blen[b];
+        double cum = 0.0;
+        for (int i = 0; i <= r && i <= rest; ++i)
+            cum += std::exp(log_choose(rest, i) + i * std::log(3.0) - rest * std::log(4.0));
+        const double h = (double)idx->n_db * std::pow(4.0, -(double)pg->blen[b]) * cum + 1.0;
+        if (h > worst) worst = h;
+    }
+    double cap = std::ceil(worst + 6.0 * std::sqrt(worst) + 8.0);
+    if (cap < 16.0) cap = 16.0;
+    if (cap > 512.0) cap = 512.0;
+    // keep the slot lists below 8 GiB; rows that overflow are simply re-scanned
+    const double per_slot = (double)pg->B * (double)n_q * 4.0;
+    while (cap > 16.0 && cap * per_slot > 8.0 * 1024 * 1024 * 1024) cap = std::floor(cap / 2.0);
+    return (int)cap;
+}
+
+int gm_pg_scan(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
+    (void)k;
     gm_pigeon* pg = idx->pg;
     int rc;
-    if ((rc = ensure(&pg->keys, &pg->keys_cap, (int64_t)pg->B * n_q * kcap, "K1P lists"))) return rc;
-    gm_pg_blocks blocks{};
+    pg->cap = pg_slot_capacity(idx, pg, n_q);
+    if ((rc = ensure(&pg->keys, &pg->keys_cap, (int64_t)pg->B * pg->cap * n_q, "K1P slot lists"))) return rc;
+    if ((rc = ensure(&pg->n_hits, &pg->n_hits_cap, (int64_t)pg->B * n_q, "K1P hit counts"))) return rc;
+    gm_pg_blocks& blocks = pg->blocks;
     for (int b = 0; b < pg->B; ++b) {
         blocks.table[b] = pg->table[b];
         blocks.perm[b] = pg->perm[b];
@@ -523,14 +552,28 @@ int gm_pg_scan(gm_index* idx, int kcap, int64_t n_q, int k, uint32_t** keys_out,
         blocks.cperm[b] = pg->cperm[b];
     }
     const int thr0 = pg->B;      // accept d < B, i.e. d <= r
-    *keys_out = pg->keys;
     switch (idx->L) {
 #define GM_CASE(LEN) \
-    case LEN: return gm_launch_pg_L##LEN(idx, kcap, &blocks, pg->chunks, &pg->ctr->n_chunks, pg->grid, n_q, k, thr0, pg->keys, st);
+    case LEN: return gm_launch_pg_L##LEN(idx, &blocks, pg->chunks, &pg->ctr->n_chunks, pg->grid, n_q, thr0, pg->cap, pg->keys, pg->n_hits, st);
         GM_FOR_EACH_LEN(GM_CASE)
 #undef GM_CASE
         default: return gm_fail(GM_ERR_ARG, "pigeonhole kernel: guidelen out of range");
     }
+}
+
+int gm_pg_merge(gm_index* idx, int kcap, int64_t n_q, int k, int32_t* ids, int32_t* dists, int32_t* counts,
+                bool nearest, hipStream_t st) {
+    gm_pigeon* pg = idx->pg;
+    const dim3 grid = grid_for(n_q), block(256);
+    const int nr = nearest ? 1 : 0;
+    switch (kcap) {
+        case 1: hipLaunchKernelGGL(gm::k_merge_hits<1>, grid, block, 0, st, pg->blocks, pg->B, pg->cap, pg->keys, pg->n_hits, n_q, k, ids, dists, counts, nr); break;
+        case 5: hipLaunchKernelGGL(gm::k_merge_hits<5>, grid, block, 0, st, pg->blocks, pg->B, pg->cap, pg->keys, pg->n_hits, n_q, k, ids, dists, counts, nr); break;
+        case 10: hipLaunchKernelGGL(gm::k_merge_hits<10>, grid, block, 0, st, pg->blocks, pg->B, pg->cap, pg->keys, pg->n_hits, n_q, k, ids, dists, counts, nr); break;
+        default: hipLaunchKernelGGL(gm::k_merge_hits<20>, grid, block, 0, st, pg->blocks, pg->B, pg->cap, pg->keys, pg->n_hits, n_q, k, ids, dists, counts, nr); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return GM_OK;
 }
 
 int gm_pg_incomplete(gm_index* idx, int64_t n_q, int need, const int32_t* counts, const int32_t* d1, int64_t* n_inc,

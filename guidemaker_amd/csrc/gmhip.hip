@@ -109,14 +109,14 @@ int ensure_u32(uint32_t** buf, int64_t* cap, int64_t need) {
 }
 
 int launch_merge(int kcap, const uint32_t* keys, int n_seg, int64_t n_q, int k, int32_t* ids, int32_t* dists,
-                 int32_t* counts, bool nearest, hipStream_t st, bool slot_major = false) {
+                 int32_t* counts, bool nearest, hipStream_t st) {
     const dim3 grid((unsigned)((n_q + 255) / 256)), block(256);
-    const int nr = nearest ? 1 : 0, sm = slot_major ? 1 : 0;
+    const int nr = nearest ? 1 : 0;
     switch (kcap) {
-        case 1: hipLaunchKernelGGL(gm::k_merge_lists<1>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr, sm); break;
-        case 5: hipLaunchKernelGGL(gm::k_merge_lists<5>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr, sm); break;
-        case 10: hipLaunchKernelGGL(gm::k_merge_lists<10>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr, sm); break;
-        default: hipLaunchKernelGGL(gm::k_merge_lists<20>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr, sm); break;
+        case 1: hipLaunchKernelGGL(gm::k_merge_lists<1>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
+        case 5: hipLaunchKernelGGL(gm::k_merge_lists<5>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
+        case 10: hipLaunchKernelGGL(gm::k_merge_lists<10>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
+        default: hipLaunchKernelGGL(gm::k_merge_lists<20>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
     }
     HIP_TRY(hipGetLastError());
     return GM_OK;
@@ -249,12 +249,11 @@ int run_hamming_pigeon(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
     if ((rc = gm_pg_prepare(idx, B, st))) return rc;
     if ((rc = gm_pg_candidates(idx, n_q, st))) return rc;
     const int kcap = nearest ? 1 : (k <= 5 ? 5 : (k <= 10 ? 10 : 20));
-    uint32_t* keys = nullptr;
     if ((rc = timing_begin(idx, st))) return rc;
-    idx->last_kernel = nearest ? "k_hamming_knn_pg(nearest)" : "k_hamming_knn_pg";
-    if ((rc = gm_pg_scan(idx, kcap, n_q, keff, &keys, st))) return rc;
+    idx->last_kernel = "k_hamming_scan_pg";
+    if ((rc = gm_pg_scan(idx, n_q, keff, st))) return rc;
     if ((rc = timing_end(idx, st, n_q * idx->n_db))) return rc;
-    if ((rc = launch_merge(kcap, keys, B, n_q, keff, ids, dists, counts, nearest, st, true))) return rc;
+    if ((rc = gm_pg_merge(idx, kcap, n_q, keff, ids, dists, counts, nearest, st))) return rc;
     int64_t n_inc = 0, pairs = 0;
     if ((rc = gm_pg_incomplete(idx, n_q, keff, nearest ? nullptr : counts, nearest ? dists : nullptr, &n_inc, &pairs,
                                st)))

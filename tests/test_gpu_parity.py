@@ -390,11 +390,11 @@ def test_pigeonhole_layouts_match_oracle(oracle, L, B):
     qp = _lib.pack(q, L)
     for k in (2, 5, 10, 20):
         ids, dists, counts = idx.knn(qp, k)
-        assert idx.last_kernel()[0].startswith("k_hamming_knn_pg"), "the forced layout was not used"
+        assert idx.last_kernel()[0].startswith("k_hamming_scan_pg"), "the forced layout was not used"
         oi, od, oc = _oracle_true_units(oracle, db, q, L, "hamming", k)
         assert (counts == oc).all() and (dists == od).all() and (ids == oi).all(), (L, B, k)
     d1 = idx.nearest(qp)
-    assert idx.last_kernel()[0].startswith("k_hamming_knn_pg")
+    assert idx.last_kernel()[0].startswith("k_hamming_scan_pg")
     assert (d1 == _oracle_true_units(oracle, db, q, L, "hamming", 1)[1][:, 0]).all()
     evaluated, rescanned = idx.last_evaluated()
     assert evaluated > 0      # (no saving expected here: tile and chunk padding dominate a 7k pool)
@@ -411,7 +411,7 @@ def test_pigeonhole_default_path_sampled_oracle(oracle):
     idx = _lib.Index(packed, L, _lib.METRIC_HAMMING)
     q = np.concatenate([packed[:60_000], core.pack_codes(rng.integers(0, 4, size=(20_000, L), dtype=np.uint8))])
     ids, dists, counts = idx.knn(q, k)
-    assert idx.last_kernel()[0] == "k_hamming_knn_pg"
+    assert idx.last_kernel()[0] == "k_hamming_scan_pg"
     evaluated, rescanned = idx.last_evaluated()
     assert evaluated < 0.5 * q.shape[0] * packed.shape[0]
     idx.set_variant(8)
@@ -420,7 +420,7 @@ def test_pigeonhole_default_path_sampled_oracle(oracle):
     assert (i8 == ids).all() and (d8 == dists).all() and (c8 == counts).all()
     idx.set_variant(0)
     d1 = idx.nearest(q)
-    assert idx.last_kernel()[0] == "k_hamming_knn_pg(nearest)" and (d1 == dists[:, 0]).all()
+    assert idx.last_kernel()[0] == "k_hamming_scan_pg" and (d1 == dists[:, 0]).all()
     sample = rng.choice(q.shape[0], size=48, replace=False)
     db_str = _lib.unpack(packed, L)
     oi, od, oc = _oracle_true_units(oracle, db_str, _lib.unpack(q[sample], L), L, "hamming", k)
