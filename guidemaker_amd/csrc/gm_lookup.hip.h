@@ -338,15 +338,20 @@ __global__ __launch_bounds__(WAVE, lk_min_waves(L, KCAP)) void k_hamming_knn_lk(
 // range are ignored, they belong to another workgroup) with the bound fixed at d < B.
 // Inside a bucket hits are frequent (the pairs already share a block) and only one to three lanes of a wave
 // take part in each visit of the slow path, so it does the minimum: APPEND (distance << 27 | position) to the
-// lane's slot list hits[b][slot][candidate] in HBM -- no sorted register list, no bound updates, and the
-// kernel does not depend on k.  k_merge_hits (one thread per candidate, all lanes busy) translates positions
+// lane's slot list hits[b][slot][candidate] in HBM -- no sorted register list, two counters instead of a
+// list for the bound, and one instantiation per guide length serves every k.  k_merge_hits (one thread per candidate, all lanes busy) translates positions
 // to pool ids, drops the pairs that were found under several blocks and selects the top k.  A candidate
 // whose merged list is full is exact (everything within r was enumerated); the others, and those whose slot
 // list overflowed, are re-scanned by the plain kernel (host side, gmhip.hip).
 // ---------------------------------------------------------------------------------------------------
+// Bound tightening without a sorted list (positions ascend with the pool ids inside a bucket, so a later
+// target never wins a tie): once k hits were appended (all with d < thr0) nothing at distance thr0 - 1 can
+// enter the top k any more -> d < thr0 - 1; once k of them had d < thr0 - 1 -> d < thr0 - 2.  k == 1: the
+// bound simply follows the best distance so far.
 template <int L>
-__device__ __forceinline__ void pg_append_hits(uint32_t hits, const uint32_t (&c)[5], int id0, int lo, int hi, int thr,
-                                               int cap, int64_t n_q, uint32_t* __restrict__ slot0, int& cnt) {
+__device__ __forceinline__ void pg_append_hits(uint32_t hits, const uint32_t (&c)[5], int id0, int lo, int hi, int k,
+                                               int thr0, int cap, int64_t n_q, uint32_t* __restrict__ slot0, int& cnt,
+                                               int& cnt_lt, int& thr, uint32_t (&Tb)[5]) {
     while (hits != 0u) {
         const int j = __builtin_ctz(hits);
         hits &= hits - 1u;
@@ -357,20 +362,27 @@ __device__ __forceinline__ void pg_append_hits(uint32_t hits, const uint32_t (&c
         if (d < thr && pos >= lo && pos < hi) {
             if (cnt < cap) slot0[(int64_t)cnt * n_q] = ((uint32_t)d << ID_BITS) | (uint32_t)pos;
             ++cnt;
+            cnt_lt += d < thr0 - 1 ? 1 : 0;
+            int nt = k == 1 ? d : (cnt_lt >= k ? thr0 - 2 : (cnt >= k ? thr0 - 1 : thr0));
+            nt = nt < thr ? nt : thr;
+            if (nt != thr) {
+                thr = nt;
+                lk_set_bound(Tb, L, thr);
+            }
         }
     }
 }
 
 template <int L>
-__device__ __forceinline__ void pg_process_group(const LkGroupRegs<L>& r, int id0, int lo, int hi, int thr,
-                                                 const uint32_t (&Tb)[5], int cap, int64_t n_q,
-                                                 uint32_t* __restrict__ slot0, int& cnt) {
+__device__ __forceinline__ void pg_process_group(const LkGroupRegs<L>& r, int id0, int lo, int hi, int k, int thr0,
+                                                 int cap, int64_t n_q, uint32_t* __restrict__ slot0, int& cnt,
+                                                 int& cnt_lt, int& thr, uint32_t (&Tb)[5]) {
     uint32_t c0[5], c1[5];
     const uint32_t h0 = lk_eval_half<L>(r.m0, Tb, c0);
     const uint32_t h1 = lk_eval_half<L>(r.m1, Tb, c1);
     if (__builtin_amdgcn_ballot_w64((h0 | h1) != 0u) != 0ull) {
-        pg_append_hits<L>(h0, c0, id0, lo, hi, thr, cap, n_q, slot0, cnt);
-        pg_append_hits<L>(h1, c1, id0 + 32, lo, hi, thr, cap, n_q, slot0, cnt);
+        pg_append_hits<L>(h0, c0, id0, lo, hi, k, thr0, cap, n_q, slot0, cnt, cnt_lt, thr, Tb);
+        pg_append_hits<L>(h1, c1, id0 + 32, lo, hi, k, thr0, cap, n_q, slot0, cnt, cnt_lt, thr, Tb);
     }
 }
 
@@ -378,7 +390,7 @@ __device__ __forceinline__ void pg_process_group(const LkGroupRegs<L>& r, int id
 template <int L>
 __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
     gm_pg_blocks P, const gm_pg_chunk* __restrict__ chunks, const int* __restrict__ n_chunks, int n_tiles,
-    const uint2* __restrict__ q, int64_t n_q, int thr0, int cap, uint32_t* __restrict__ hits,
+    const uint2* __restrict__ q, int64_t n_q, int k, int thr0, int cap, uint32_t* __restrict__ hits,
     int32_t* __restrict__ n_hits) {
     extern __shared__ __align__(16) uint32_t smem[];
     constexpr int TILE_W = lk_tile_bytes(L) / 4;
@@ -399,11 +411,11 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
         uint32_t code = ((qv.x >> p) & 1u) | (((qv.y >> p) & 1u) << 1);
         ptr[p] = tiles + p * 8 + (int)code * 2;
     }
-    const int thr = valid ? thr0 : 0;
+    int thr = valid ? thr0 : 0;
     uint32_t Tb[5];
     lk_set_bound(Tb, L, thr);
     uint32_t* slot0 = hits + (int64_t)ch.b * cap * n_q + qi;      // slot s of this lane: slot0[s * n_q]
-    int cnt = 0;
+    int cnt = 0, cnt_lt = 0;
 
     // tiles covering the bucket's targets [lo, hi) in this copy, widened to an even tile range
     const int lo = P.toff[ch.b][ch.v], hi = P.toff[ch.b][ch.v + 1];
@@ -423,7 +435,7 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
             if (gl == 1) lk_read_group<L, 1 * GW>(r, ptr);
             if (gl == 2) lk_read_group<L, 2 * GW>(r, ptr);
             if (gl == 3) lk_read_group<L, 3 * GW>(r, ptr);
-            pg_process_group<L>(r, (t * LK_TG + gl) * LK_GROUP, lo, hi, thr, Tb, cap, n_q, slot0, cnt);
+            pg_process_group<L>(r, (t * LK_TG + gl) * LK_GROUP, lo, hi, k, thr0, cap, n_q, slot0, cnt, cnt_lt, thr, Tb);
         }
         lk_stage_wait();
         if (t + 2 < t1) lk_stage<L>(table, t + 2, tiles, lane);
@@ -434,7 +446,8 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
             if (gl == 1) lk_read_group<L, TILE_W + 1 * GW>(r, ptr);
             if (gl == 2) lk_read_group<L, TILE_W + 2 * GW>(r, ptr);
             if (gl == 3) lk_read_group<L, TILE_W + 3 * GW>(r, ptr);
-            pg_process_group<L>(r, ((t + 1) * LK_TG + gl) * LK_GROUP, lo, hi, thr, Tb, cap, n_q, slot0, cnt);
+            pg_process_group<L>(r, ((t + 1) * LK_TG + gl) * LK_GROUP, lo, hi, k, thr0, cap, n_q, slot0, cnt, cnt_lt, thr,
+                                Tb);
         }
     }
     if (valid) n_hits[(int64_t)ch.b * n_q + qi] = cnt;

@@ -66,6 +66,26 @@ __global__ __launch_bounds__(256) void k_bucket_offsets(const uint32_t* __restri
     off[v] = (int32_t)lo;
 }
 
+// base composition of the pool: counts[c] = occurrences of base code c over all positions
+__global__ __launch_bounds__(256) void k_base_counts(const uint2* __restrict__ planes, int64_t n, int L,
+                                                     unsigned long long* __restrict__ counts) {
+    __shared__ unsigned s[4];
+    if (threadIdx.x < 4) s[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t mask = L >= 32 ? 0xffffffffu : ((1u << L) - 1u);
+    unsigned c[4] = {0, 0, 0, 0};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint2 e = planes[i];
+        c[0] += __popc(~e.x & ~e.y & mask);
+        c[1] += __popc(e.x & ~e.y & mask);
+        c[2] += __popc(~e.x & e.y & mask);
+        c[3] += __popc(e.x & e.y & mask);
+    }
+    for (int b = 0; b < 4; ++b) atomicAdd(&s[b], c[b]);
+    __syncthreads();
+    if (threadIdx.x < 4) atomicAdd(&counts[threadIdx.x], (unsigned long long)s[threadIdx.x]);
+}
+
 // ---- candidate grouping: one counting sort for ALL blocks (order inside a bucket is irrelevant) ----
 struct PgKeyArg {
     int B;
@@ -291,6 +311,8 @@ inline dim3 grid_for(int64_t n, int block = 256) { return dim3((unsigned)((n + b
 
 struct gm_pigeon {
     int B = 0;
+    double p_match = 0.0;              // P(two pool sequences carry the same base at a position); 0 = not measured
+    int max_bucket[GM_PG_MAXB]{};      // largest bucket of every pool copy
     int bstart[GM_PG_MAXB]{}, blen[GM_PG_MAXB]{};
     int ebase[GM_PG_MAXB + 1]{};
     // pool side
@@ -368,23 +390,30 @@ double log_choose(int n, int r) { return std::lgamma(n + 1.0) - std::lgamma(r + 
 
 }  // namespace
 
-// Layout choice under the uniform-base model: E(r) = expected pool targets within r mismatches of a
-// candidate; a candidate is incomplete when fewer than k of them exist (Poisson), and costs a plain scan.
-// Minimise  sum_b 4^-len(b)  +  P(incomplete)  over B = r + 1; 0 when the plain scan is at least as good.
-int gm_pg_plan(int64_t n_db, int L, int k) {
+// P(at most r mismatches over n positions) when a position matches with probability pm
+static double tail_within(int n, int r, double pm) {
+    double cum = 0.0;
+    for (int i = 0; i <= r && i <= n; ++i)
+        cum += std::exp(log_choose(n, i) + i * std::log(1.0 - pm) + (n - i) * std::log(pm));
+    return cum;
+}
+
+// Layout choice under an independent-base model with the pool's own composition (p_match = sum_b f_b^2):
+// E(r) = expected pool targets within r mismatches of a candidate; a candidate is incomplete when fewer
+// than k of them exist (Poisson), and costs a plain scan.  Minimise  sum_b p_match^len(b)  (fraction of the
+// pairs that share block b)  +  P(incomplete)  over B = r + 1; 0 when the plain scan is at least as good.
+int gm_pg_plan(int64_t n_db, int L, int k, double p_match) {
     if (L < 12 || L > GM_MAX_GUIDELEN || n_db < 32768 || k < 1 || k > 20) return 0;
+    if (!(p_match >= 0.25 && p_match < 0.9)) p_match = 0.25;
     double best = 0.45;      // K1P has to be clearly cheaper than scanning everything
     int best_B = 0;
-    double cum = 0.0;
-    for (int r = 0; r < GM_PG_MAXB; ++r) {
-        cum += std::exp(log_choose(L, r) + r * std::log(3.0) - L * std::log(4.0));
+    for (int r = 1; r < GM_PG_MAXB; ++r) {
         const int B = r + 1;
-        if (B < 2) continue;
         const int base = L / B, extra = L % B;
         if (base < 2 || base + (extra ? 1 : 0) > GM_PG_MAXLEN) continue;
         double work = 0.0;
-        for (int b = 0; b < B; ++b) work += std::pow(4.0, -(double)(base + (b < extra ? 1 : 0)));
-        const double mean = (double)n_db * cum;
+        for (int b = 0; b < B; ++b) work += std::pow(p_match, (double)(base + (b < extra ? 1 : 0)));
+        const double mean = (double)n_db * tail_within(L, r, p_match);
         double p_inc = 0.0, term = std::exp(-mean);      // P(Poisson(mean) < k)
         for (int j = 0; j < k; ++j) {
             p_inc += term;
@@ -398,6 +427,32 @@ int gm_pg_plan(int64_t n_db, int L, int k) {
         }
     }
     return best_B;
+}
+
+// measures the pool's base composition once per index (one small kernel + a 32-byte read-back)
+int gm_pg_pool_stats(gm_index* idx, hipStream_t st, double* p_match) {
+    if (!idx->pg) idx->pg = new gm_pigeon();
+    gm_pigeon* pg = idx->pg;
+    if (pg->p_match == 0.0) {
+        unsigned long long* d_counts = nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&d_counts), 4 * sizeof(unsigned long long)) != hipSuccess)
+            return gm_fail(GM_ERR_ALLOC, "hipMalloc(base counts) failed");
+        unsigned long long h[4] = {0, 0, 0, 0};
+        hipError_t e = hipMemsetAsync(d_counts, 0, sizeof(h), st);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_base_counts, dim3(1024), dim3(256), 0, st, idx->d_db, idx->n_db, idx->L, d_counts);
+            e = hipMemcpyAsync(h, d_counts, sizeof(h), hipMemcpyDeviceToHost, st);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        (void)hipFree(d_counts);
+        if (e != hipSuccess) return gm_fail(GM_ERR_DEVICE, std::string("pool composition: ") + hipGetErrorString(e));
+        const double total = (double)(h[0] + h[1] + h[2] + h[3]);
+        double pm = 0.0;
+        for (int b = 0; b < 4; ++b) pm += (h[b] / total) * (h[b] / total);
+        pg->p_match = pm;
+    }
+    *p_match = pg->p_match;
+    return GM_OK;
 }
 
 int gm_pg_blocks_of(const gm_index* idx) { return idx->pg ? idx->pg->B : 0; }
@@ -461,6 +516,17 @@ int gm_pg_prepare(gm_index* idx, int B, hipStream_t st) {
     }
     if (hipStreamSynchronize(st) != hipSuccess && rc == GM_OK) rc = gm_fail(GM_ERR_DEVICE, "K1P pool-copy build failed");
     (void)hipFree(sorted_planes);
+    for (int b = 0; b < B && rc == GM_OK; ++b) {      // largest bucket per copy: sizes the slot lists
+        const int nb = 1 << (2 * pg->blen[b]);
+        std::vector<int32_t> off((size_t)nb + 1);
+        if (hipMemcpy(off.data(), pg->toff[b], sizeof(int32_t) * off.size(), hipMemcpyDeviceToHost) != hipSuccess) {
+            rc = gm_fail(GM_ERR_DEVICE, "K1P bucket offsets read-back failed");
+            break;
+        }
+        int mx = 0;
+        for (int v = 0; v < nb; ++v) mx = off[v + 1] - off[v] > mx ? off[v + 1] - off[v] : mx;
+        pg->max_bucket[b] = mx;
+    }
     if (rc != GM_OK) {
         free_pool_side(pg);
         return rc;
@@ -515,30 +581,30 @@ int gm_pg_candidates(gm_index* idx, int64_t n_q, hipStream_t st) {
     return GM_OK;
 }
 
-// slots per (candidate, block): mean + 6 sigma of the hits expected under the uniform-base model
-// (pool targets in the bucket x P(at most r mismatches on the other positions)), at least 16
+// slots per (candidate, block): 1.25 x (mean + 6 sigma) of the hits expected in the LARGEST bucket of any copy
+// under the independent-base model with the pool's own composition, at least 16.  A list that still
+// overflows (repeat families) only makes its row incomplete: the row is re-scanned by the plain kernel.
 static int pg_slot_capacity(const gm_index* idx, const gm_pigeon* pg, int64_t n_q) {
     const int L = idx->L, r = pg->B - 1;
+    const double pm = pg->p_match >= 0.25 ? pg->p_match : 0.25;
     double worst = 0.0;
     for (int b = 0; b < pg->B; ++b) {
-        const int rest = L - pg->blen[b];
-        double cum = 0.0;
-        for (int i = 0; i <= r && i <= rest; ++i)
-            cum += std::exp(log_choose(rest, i) + i * std::log(3.0) - rest * std::log(4.0));
-        const double h = (double)idx->n_db * std::pow(4.0, -(double)pg->blen[b]) * cum + 1.0;
+        const double h = (double)pg->max_bucket[b] * tail_within(L - pg->blen[b], r, pm) + 1.0;
         if (h > worst) worst = h;
     }
-    double cap = std::ceil(worst + 6.0 * std::sqrt(worst) + 8.0);
+    double cap = std::ceil(1.25 * (worst + 6.0 * std::sqrt(worst)) + 8.0);
     if (cap < 16.0) cap = 16.0;
-    if (cap > 512.0) cap = 512.0;
-    // keep the slot lists below 8 GiB; rows that overflow are simply re-scanned
+    if (cap > 1024.0) cap = 1024.0;
+    // keep the slot lists within a quarter of the free device memory (at least 2 GiB)
+    size_t free_b = 0, total_b = 0;
+    double limit = 2.0 * 1024 * 1024 * 1024;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)free_b / 4.0 > limit) limit = (double)free_b / 4.0;
     const double per_slot = (double)pg->B * (double)n_q * 4.0;
-    while (cap > 16.0 && cap * per_slot > 8.0 * 1024 * 1024 * 1024) cap = std::floor(cap / 2.0);
+    while (cap > 16.0 && cap * per_slot > limit) cap = std::floor(cap * 0.75);
     return (int)cap;
 }
 
 int gm_pg_scan(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
-    (void)k;
     gm_pigeon* pg = idx->pg;
     int rc;
     pg->cap = pg_slot_capacity(idx, pg, n_q);
@@ -554,7 +620,7 @@ int gm_pg_scan(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
     const int thr0 = pg->B;      // accept d < B, i.e. d <= r
     switch (idx->L) {
 #define GM_CASE(LEN) \
-    case LEN: return gm_launch_pg_L##LEN(idx, &blocks, pg->chunks, &pg->ctr->n_chunks, pg->grid, n_q, thr0, pg->cap, pg->keys, pg->n_hits, st);
+    case LEN: return gm_launch_pg_L##LEN(idx, &blocks, pg->chunks, &pg->ctr->n_chunks, pg->grid, n_q, k, thr0, pg->cap, pg->keys, pg->n_hits, st);
         GM_FOR_EACH_LEN(GM_CASE)
 #undef GM_CASE
         default: return gm_fail(GM_ERR_ARG, "pigeonhole kernel: guidelen out of range");

@@ -239,13 +239,17 @@ int run_hamming_pigeon(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
     if (keff > 20 || idx->n_db < keff || n_q < 1) return GM_OK;
     // variants 102..108 force a layout of 2..8 blocks (tests, A/B); the result is exact for any layout
     const bool forced = idx->variant >= 102 && idx->variant <= 100 + GM_PG_MAXB;
-    const int B = forced ? idx->variant - 100 : gm_pg_plan(idx->n_db, idx->L, keff);
+    int rc;
+    double p_match = 0.25;
+    if (idx->n_db >= 32768 || forced) {
+        if ((rc = gm_pg_pool_stats(idx, st, &p_match))) return rc;
+    }
+    const int B = forced ? idx->variant - 100 : gm_pg_plan(idx->n_db, idx->L, keff, p_match);
     if (B == 0 || idx->L / B < 1) return GM_OK;
     const int max_len = (idx->L + B - 1) / B;
     if (max_len > GM_PG_MAXLEN) return GM_OK;
     // enough candidates per bucket to fill the 64-lane chunks (measured break-even on a 600k pool: ~10k)
     if (!forced && n_q < (int64_t)160 << (2 * max_len)) return GM_OK;
-    int rc;
     if ((rc = gm_pg_prepare(idx, B, st))) return rc;
     if ((rc = gm_pg_candidates(idx, n_q, st))) return rc;
     const int kcap = nearest ? 1 : (k <= 5 ? 5 : (k <= 10 ? 10 : 20));
