@@ -255,7 +255,10 @@ int run_hamming_pigeon(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
     const int kcap = nearest ? 1 : (k <= 5 ? 5 : (k <= 10 ? 10 : 20));
     if ((rc = timing_begin(idx, st))) return rc;
     idx->last_kernel = "k_hamming_scan_pg";
-    if ((rc = gm_pg_scan(idx, n_q, keff, st))) return rc;
+    if ((rc = gm_pg_scan(idx, n_q, keff, st))) {
+        if (rc == GM_ERR_ALLOC) return GM_OK;      // no room for the slot lists: the plain scan takes over
+        return rc;
+    }
     if ((rc = timing_end(idx, st, n_q * idx->n_db))) return rc;
     if ((rc = gm_pg_merge(idx, kcap, n_q, keff, ids, dists, counts, nearest, st))) return rc;
     int64_t n_inc = 0, pairs = 0;

@@ -401,6 +401,32 @@ def test_pigeonhole_layouts_match_oracle(oracle, L, B):
     idx.close()
 
 
+def test_pigeonhole_repeat_family_overflows_to_rescan(oracle):
+    """A family of near-identical targets (a repeat) floods the slot lists of its members: those rows must
+    come back exact through the re-scan, the rest through the merge."""
+    L, k = 20, 20
+    rng = random.Random(77)
+    db = ["".join(rng.choice("ACGT") for _ in range(L)) for _ in range(9000)]
+    root = db[0]
+    for _ in range(700):
+        s = list(root)
+        for p in rng.sample(range(L), rng.randint(1, 2)):
+            s[p] = rng.choice("ACGT")
+        db.append("".join(s))
+    db = list(dict.fromkeys(db))
+    rng.shuffle(db)
+    fam = [t for t in db if sum(a != b for a, b in zip(t, root)) <= 2]
+    q = fam[:150] + db[:600]
+    idx = _lib.Index(_lib.pack(db, L), L, _lib.METRIC_HAMMING)
+    idx.set_variant(107)
+    ids, dists, counts = idx.knn(_lib.pack(q, L), k)
+    assert idx.last_kernel()[0] == "k_hamming_scan_pg"
+    assert idx.last_evaluated()[1] >= 100          # the family rows were re-scanned
+    oi, od, oc = _oracle_true_units(oracle, db, q, L, "hamming", k)
+    assert (counts == oc).all() and (dists == od).all() and (ids == oi).all()
+    idx.close()
+
+
 def test_pigeonhole_default_path_sampled_oracle(oracle):
     """Pool large enough for the planner to choose K1P on its own: compare a sample with the oracle over
     the full pool, and the whole result with the plain two-phase scan (variant 8)."""
