@@ -34,15 +34,18 @@ constexpr int TT_GE = 0xB2;          // (a & ~b) | (~(a ^ b) & c)   a = count bi
 static_assert(((0xF0 | ~0xCC) & 0xFF) == TT_A_OR_NOTB, "a | ~b");
 static_assert((((0xF0 & ~0xCC) | (~(0xF0 ^ 0xCC) & 0xAA)) & 0xFF) == TT_GE, "ge stage");
 
-// planes -> one-hot bit-sliced table.  One thread per output word; ids past n_db replicate the last.
+// planes -> one-hot bit-sliced table of L positions.  One thread per output word; ids past n_db replicate
+// the last.  skip_len > 0: the table leaves out the sequence positions [skip_start, skip_start + skip_len)
+// (K1P: positions on which every pair of a bucket agrees anyway), L = positions kept.
 static __global__ void k_to_onehot(const uint2* __restrict__ planes, int64_t n_db, uint32_t* __restrict__ table,
-                            int64_t n_groups, int L) {
+                            int64_t n_groups, int L, int skip_start = 0, int skip_len = 0) {
     const int gw = lk_group_words(L);
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_groups * gw) return;
     int64_t G = t / gw;
     int w = (int)(t % gw);
     int p = w >> 3, b = (w >> 1) & 3, h = w & 1;
+    if (p >= skip_start) p += skip_len;
     uint32_t out = 0;
     for (int j = 0; j < 32; ++j) {
         int64_t id = G * LK_GROUP + 32 * h + j;
@@ -405,10 +408,14 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
     const int64_t qi = valid ? (int64_t)P.cperm[ch.b][ch.c0 + lane] : 0;
     const uint2 qv = valid ? q[qi] : make_uint2(0u, 0u);
 
+    // L = positions evaluated: the copy's table leaves out P.skip_len positions of its own block (all pairs
+    // of the bucket agree there), so table position p is sequence position p (+ skip_len behind the gap)
+    const int skip_start = P.skip[ch.b], skip_len = P.skip_len;
     const uint32_t* ptr[L];
 #pragma unroll
     for (int p = 0; p < L; ++p) {
-        uint32_t code = ((qv.x >> p) & 1u) | (((qv.y >> p) & 1u) << 1);
+        const int sp = p >= skip_start ? p + skip_len : p;
+        uint32_t code = ((qv.x >> sp) & 1u) | (((qv.y >> sp) & 1u) << 1);
         ptr[p] = tiles + p * 8 + (int)code * 2;
     }
     int thr = valid ? thr0 : 0;

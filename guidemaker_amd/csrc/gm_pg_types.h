@@ -11,6 +11,8 @@ struct gm_pg_blocks {
     const int32_t* perm[GM_PG_MAXB];     // position in that copy -> pool id
     const int32_t* toff[GM_PG_MAXB];     // bucket v covers positions [toff[v], toff[v+1])
     const uint32_t* cperm[GM_PG_MAXB];   // candidates sorted by block b: sorted position -> candidate row
+    int skip[GM_PG_MAXB];                // copy b's table leaves out sequence positions [skip[b], skip[b] + skip_len)
+    int skip_len;
 };
 
 // one workgroup's work: cn (<= 64) candidates starting at sorted position c0, all in bucket v of block b

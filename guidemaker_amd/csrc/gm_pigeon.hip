@@ -313,6 +313,8 @@ struct gm_pigeon {
     int B = 0;
     double p_match = 0.0;              // P(two pool sequences carry the same base at a position); 0 = not measured
     int max_bucket[GM_PG_MAXB]{};      // largest bucket of every pool copy
+    int skip_len = 0;                  // positions of its own block each copy's table leaves out
+    int Lp = 0;                        // positions the scan evaluates = L - skip_len (>= 10)
     int bstart[GM_PG_MAXB]{}, blen[GM_PG_MAXB]{};
     int ebase[GM_PG_MAXB + 1]{};
     // pool side
@@ -492,8 +494,13 @@ int gm_pg_prepare(gm_index* idx, int B, hipStream_t st) {
     if ((rc = ensure_sort_buffers(pg, n))) return rc;
     if (!pg->ctr && hipMalloc(reinterpret_cast<void**>(&pg->ctr), sizeof(PgCounters)) != hipSuccess)
         return gm_fail(GM_ERR_ALLOC, "hipMalloc(K1P counters) failed");
+    // every pair of a bucket agrees on the copy's own block: leave the first `base` (= shortest block length)
+    // positions of the block out of the table and run the scan for L - base positions
+    pg->skip_len = base;
+    if (L - pg->skip_len < 10) pg->skip_len = L - 10;
+    pg->Lp = L - pg->skip_len;
     const int64_t n_groups = idx->n_lk_tiles * gm::LK_TG;
-    const int64_t words = n_groups * gm::lk_group_words(L);
+    const int64_t words = n_groups * gm::lk_group_words(pg->Lp);
     uint2* sorted_planes = nullptr;
     if (hipMalloc(reinterpret_cast<void**>(&sorted_planes), sizeof(uint2) * (size_t)n) != hipSuccess)
         return gm_fail(GM_ERR_ALLOC, "hipMalloc(sorted planes) failed");
@@ -511,7 +518,8 @@ int gm_pg_prepare(gm_index* idx, int B, hipStream_t st) {
         if ((rc = sort_pairs(pg, n, 2 * pg->blen[b], st))) break;
         hipLaunchKernelGGL(k_bucket_offsets, grid_for(nb + 1), dim3(256), 0, st, pg->k1, n, nb, pg->toff[b]);
         hipLaunchKernelGGL(k_gather_planes, grid_for(n), dim3(256), 0, st, idx->d_db, pg->r1, n, sorted_planes, pg->perm[b]);
-        hipLaunchKernelGGL(gm::k_to_onehot, grid_for(words), dim3(256), 0, st, sorted_planes, n, pg->table[b], n_groups, L);
+        hipLaunchKernelGGL(gm::k_to_onehot, grid_for(words), dim3(256), 0, st, sorted_planes, n, pg->table[b], n_groups,
+                           pg->Lp, pg->bstart[b], pg->skip_len);
         if (hipGetLastError() != hipSuccess) rc = gm_fail(GM_ERR_DEVICE, "K1P pool-copy kernels failed to launch");
     }
     if (hipStreamSynchronize(st) != hipSuccess && rc == GM_OK) rc = gm_fail(GM_ERR_DEVICE, "K1P pool-copy build failed");
@@ -616,9 +624,11 @@ int gm_pg_scan(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
         blocks.perm[b] = pg->perm[b];
         blocks.toff[b] = pg->toff[b];
         blocks.cperm[b] = pg->cperm[b];
+        blocks.skip[b] = pg->bstart[b];
     }
+    blocks.skip_len = pg->skip_len;
     const int thr0 = pg->B;      // accept d < B, i.e. d <= r
-    switch (idx->L) {
+    switch (pg->Lp) {            // the kernel instantiated for the positions actually evaluated
 #define GM_CASE(LEN) \
     case LEN: return gm_launch_pg_L##LEN(idx, &blocks, pg->chunks, &pg->ctr->n_chunks, pg->grid, n_q, k, thr0, pg->cap, pg->keys, pg->n_hits, st);
         GM_FOR_EACH_LEN(GM_CASE)

@@ -418,7 +418,7 @@ int gm_index_create_dev(const void* d_packed, int64_t n_db, int guidelen, int me
                 return fail(GM_ERR_ALLOC, "hipMalloc(db one-hot table) failed");
             }
             hipLaunchKernelGGL(gm::k_to_onehot, dim3((unsigned)((lk_words + 255) / 256)), dim3(256), 0, st,
-                               idx->d_db, n_db, idx->d_onehot, lk_groups, guidelen);
+                               idx->d_db, n_db, idx->d_onehot, lk_groups, guidelen, 0, 0);
             if (hipGetLastError() != hipSuccess) {
                 gm_index_free(idx);
                 return fail(GM_ERR_DEVICE, "k_to_onehot launch failed");
