@@ -265,14 +265,18 @@ def main():
                                     "(256 CUs x 128 lanes/clk x 2.4 GHz); the HBM figure above is not meaningful "
                                     "for Levenshtein (SURVEY.md 8d)"}
         if pool["metric"] == "hamming" and 10 <= L <= 27:
-            opp = lookup_ops_per_pair(L)
+            L_eval = L
+            if "scan_pg" in kname and idx.pigeon_blocks() > 0:      # K1P evaluates L - L // B positions
+                roof["pigeon_blocks"] = idx.pigeon_blocks()
+                L_eval = max(10, L - L // idx.pigeon_blocks())
+            opp = lookup_ops_per_pair(L_eval)
             ops = evaluated_pairs * opp / kern_s
             roof["pairs_evaluated"] = evaluated_pairs
             roof["candidates_rescanned"] = int(rescanned)
             roof["valu"] = {"achieved": ops / 1e12, "peak": VALU_LANE_OPS_PER_S / 1e12,
                             "unit": "T lane-ops/s", "frac": ops / VALU_LANE_OPS_PER_S,
                             "ops_per_pair": opp,
-                            "lds_reads_per_pair": L / 64.0,
+                            "lds_reads_per_pair": L_eval / 64.0,
                             "note": "the binding roofs: int32 VALU issue (256 CUs x 128 lanes/clk x 2.4 GHz) "
                                     "and LDS read issue (L ds_read_b64 per 64 pairs per lane); computed on the "
                                     "pairs the launch EVALUATED (pairs_evaluated; the pigeonhole-partitioned "

@@ -72,6 +72,8 @@ def lib():
     L.gm_last_kernel_evaluated.restype = i64
     L.gm_last_incomplete.argtypes = [vp]
     L.gm_last_incomplete.restype = i64
+    L.gm_pigeon_blocks.argtypes = [vp]
+    L.gm_pigeon_blocks.restype = i32
     L.gm_set_variant.argtypes = [vp, i32]
     L.gm_timing_reserve.argtypes = [vp, i32]
     L.gm_timing_reserve.restype = i32
@@ -108,7 +110,7 @@ EXPORTS = [
     "gm_cfd_batch_dev", "gm_last_kernel_ms", "gm_last_query_ms", "gm_last_kernel_name", "gm_last_kernel_pairs",
     "gm_set_variant", "gm_timing_reserve", "gm_timing_read", "gm_pam_count", "gm_pam_emit", "gm_pam_free",
     "gm_pack_keys_dev", "gm_unpack_keys_dev", "gm_site_flags", "gm_seed_duplicated",
-    "gm_last_kernel_evaluated", "gm_last_incomplete",
+    "gm_last_kernel_evaluated", "gm_last_incomplete", "gm_pigeon_blocks",
 ]
 
 
@@ -249,6 +251,10 @@ class Index:
         last_kernel()[2] only for the pigeonhole-partitioned scan."""
         L = lib()
         return int(L.gm_last_kernel_evaluated(self._h)), int(L.gm_last_incomplete(self._h))
+
+    def pigeon_blocks(self):
+        """Blocks of the pigeonhole layout built for this index (0: the plain scan is in use)."""
+        return int(lib().gm_pigeon_blocks(self._h))
 
 
 def cfd_batch(guides_packed, offs_packed, guidelen, mm, device=0):

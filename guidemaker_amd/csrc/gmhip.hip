@@ -797,5 +797,6 @@ const char* gm_last_kernel_name(gm_index* idx) { return idx ? idx->last_kernel :
 int64_t gm_last_kernel_pairs(gm_index* idx) { return idx ? idx->last_pairs : 0; }
 int64_t gm_last_kernel_evaluated(gm_index* idx) { return idx ? idx->last_evaluated : 0; }
 int64_t gm_last_incomplete(gm_index* idx) { return idx ? idx->last_incomplete : 0; }
+int gm_pigeon_blocks(gm_index* idx) { return idx ? gm_pg_blocks_of(idx) : 0; }
 
 }  // extern "C"

@@ -141,6 +141,8 @@ int64_t gm_last_kernel_pairs(gm_index* idx);
  * scan afterwards (both equal the plain figures / 0 for the other kernels). */
 int64_t gm_last_kernel_evaluated(gm_index* idx);
 int64_t gm_last_incomplete(gm_index* idx);
+/* Number of blocks B of the K1P layout currently built for this handle (0: none built yet). */
+int gm_pigeon_blocks(gm_index* idx);
 
 /* Per-launch timing history: gm_timing_reserve(idx, n) arms n HIP-event pairs (and resets the
  * history); every later scan-kernel launch on this handle records into the next pair (wrapping);
