@@ -74,6 +74,8 @@ def lib():
     L.gm_last_incomplete.restype = i64
     L.gm_pigeon_blocks.argtypes = [vp]
     L.gm_pigeon_blocks.restype = i32
+    L.gm_pigeon_plan.argtypes = [i64, i32, i32, c.c_double]
+    L.gm_pigeon_plan.restype = i32
     L.gm_set_variant.argtypes = [vp, i32]
     L.gm_timing_reserve.argtypes = [vp, i32]
     L.gm_timing_reserve.restype = i32
@@ -110,7 +112,7 @@ EXPORTS = [
     "gm_cfd_batch_dev", "gm_last_kernel_ms", "gm_last_query_ms", "gm_last_kernel_name", "gm_last_kernel_pairs",
     "gm_set_variant", "gm_timing_reserve", "gm_timing_read", "gm_pam_count", "gm_pam_emit", "gm_pam_free",
     "gm_pack_keys_dev", "gm_unpack_keys_dev", "gm_site_flags", "gm_seed_duplicated",
-    "gm_last_kernel_evaluated", "gm_last_incomplete", "gm_pigeon_blocks",
+    "gm_last_kernel_evaluated", "gm_last_incomplete", "gm_pigeon_blocks", "gm_pigeon_plan",
 ]
 
 
@@ -287,6 +289,11 @@ def pam_scan(seq, pam, five_prime, guidelen, device=0):
     finally:
         lib().gm_pam_free(h)
     return packed, tstart, mstart, int(nf.value)
+
+
+def pigeon_plan(n_db, guidelen, k, p_match=0.25):
+    """Blocks the pigeonhole-partitioned scan would use (0: plain scan).  Host arithmetic, no GPU needed."""
+    return int(lib().gm_pigeon_plan(int(n_db), int(guidelen), int(k), float(p_match)))
 
 
 def site_flags(packed, guidelen, sites, device=0):
