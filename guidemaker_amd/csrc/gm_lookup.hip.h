@@ -347,28 +347,43 @@ __global__ __launch_bounds__(WAVE, lk_min_waves(L, KCAP)) void k_hamming_knn_lk(
 // whose merged list is full is exact (everything within r was enumerated); the others, and those whose slot
 // list overflowed, are re-scanned by the plain kernel (host side, gmhip.hip).
 // ---------------------------------------------------------------------------------------------------
+// The append path.  Both halves of the group go through ONE divergent loop (a lane rarely has more than one
+// hit, so the loop usually runs once for all hit lanes of the wave together); the slot address is a running
+// pointer; the distance is read back from the bit-sliced counter with bit-field extracts.
 // Bound tightening without a sorted list (positions ascend with the pool ids inside a bucket, so a later
 // target never wins a tie): once k hits were appended (all with d < thr0) nothing at distance thr0 - 1 can
 // enter the top k any more -> d < thr0 - 1; once k of them had d < thr0 - 1 -> d < thr0 - 2.  k == 1: the
-// bound simply follows the best distance so far.
+// bound simply follows the best distance so far.  (A hit flagged under an older, looser bound may still be
+// appended: harmless, the merge selects.)
 template <int L>
-__device__ __forceinline__ void pg_append_hits(uint32_t hits, const uint32_t (&c)[5], int id0, int lo, int hi, int k,
-                                               int thr0, int cap, int64_t n_q, uint32_t* __restrict__ slot0, int& cnt,
-                                               int& cnt_lt, int& thr, uint32_t (&Tb)[5]) {
-    while (hits != 0u) {
-        const int j = __builtin_ctz(hits);
-        hits &= hits - 1u;
-        const int matches = (int)(((c[0] >> j) & 1u) | (((c[1] >> j) & 1u) << 1) | (((c[2] >> j) & 1u) << 2) |
-                                  (((c[3] >> j) & 1u) << 3) | (((c[4] >> j) & 1u) << 4));
-        const int d = L - matches;
-        const int pos = id0 + j;
-        if (d < thr && pos >= lo && pos < hi) {
-            if (cnt < cap) slot0[(int64_t)cnt * n_q] = ((uint32_t)d << ID_BITS) | (uint32_t)pos;
+__device__ __forceinline__ void pg_append_hits(uint32_t h0, uint32_t h1, const uint32_t (&c0)[5],
+                                               const uint32_t (&c1)[5], int id0, int lo, int hi, int k, int thr0,
+                                               int cap, int64_t slot_stride, uint32_t*& wp, int& cnt, int& cnt_lt,
+                                               int& thr, uint32_t (&Tb)[5]) {
+    while ((h0 | h1) != 0u) {
+        const bool low = h0 != 0u;
+        const uint32_t w = low ? h0 : h1;
+        const int j = __builtin_ctz(w);
+        const uint32_t rest = w & (w - 1u);
+        h0 = low ? rest : h0;
+        h1 = low ? h1 : rest;
+        uint32_t m = 0;
+#pragma unroll
+        for (int i = 4; i >= 0; --i) m = (m << 1) | __builtin_amdgcn_ubfe(low ? c0[i] : c1[i], (uint32_t)j, 1u);
+        const int d = L - (int)m;
+        const int pos = id0 + j + (low ? 0 : 32);
+        if (pos >= lo && pos < hi) {
+            if (cnt < cap) *wp = ((uint32_t)d << ID_BITS) | (uint32_t)pos;
+            wp += slot_stride;
             ++cnt;
-            cnt_lt += d < thr0 - 1 ? 1 : 0;
-            int nt = k == 1 ? d : (cnt_lt >= k ? thr0 - 2 : (cnt >= k ? thr0 - 1 : thr0));
-            nt = nt < thr ? nt : thr;
-            if (nt != thr) {
+            int nt;
+            if (k == 1) {
+                nt = d;
+            } else {
+                cnt_lt += d < thr0 - 1 ? 1 : 0;
+                nt = thr0 - (cnt >= k ? 1 : 0) - (cnt_lt >= k ? 1 : 0);
+            }
+            if (nt < thr) {
                 thr = nt;
                 lk_set_bound(Tb, L, thr);
             }
@@ -378,15 +393,13 @@ __device__ __forceinline__ void pg_append_hits(uint32_t hits, const uint32_t (&c
 
 template <int L>
 __device__ __forceinline__ void pg_process_group(const LkGroupRegs<L>& r, int id0, int lo, int hi, int k, int thr0,
-                                                 int cap, int64_t n_q, uint32_t* __restrict__ slot0, int& cnt,
-                                                 int& cnt_lt, int& thr, uint32_t (&Tb)[5]) {
+                                                 int cap, int64_t slot_stride, uint32_t*& wp, int& cnt, int& cnt_lt,
+                                                 int& thr, uint32_t (&Tb)[5]) {
     uint32_t c0[5], c1[5];
     const uint32_t h0 = lk_eval_half<L>(r.m0, Tb, c0);
     const uint32_t h1 = lk_eval_half<L>(r.m1, Tb, c1);
-    if (__builtin_amdgcn_ballot_w64((h0 | h1) != 0u) != 0ull) {
-        pg_append_hits<L>(h0, c0, id0, lo, hi, k, thr0, cap, n_q, slot0, cnt, cnt_lt, thr, Tb);
-        pg_append_hits<L>(h1, c1, id0 + 32, lo, hi, k, thr0, cap, n_q, slot0, cnt, cnt_lt, thr, Tb);
-    }
+    if (__builtin_amdgcn_ballot_w64((h0 | h1) != 0u) != 0ull)
+        pg_append_hits<L>(h0, h1, c0, c1, id0, lo, hi, k, thr0, cap, slot_stride, wp, cnt, cnt_lt, thr, Tb);
 }
 
 // hits: [B][cap][n_q] keys (distance << 27 | position in copy b), n_hits: [B][n_q] (> cap: overflow)
@@ -421,7 +434,7 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
     int thr = valid ? thr0 : 0;
     uint32_t Tb[5];
     lk_set_bound(Tb, L, thr);
-    uint32_t* slot0 = hits + (int64_t)ch.b * cap * n_q + qi;      // slot s of this lane: slot0[s * n_q]
+    uint32_t* wp = hits + (int64_t)ch.b * cap * n_q + qi;      // next free slot of this lane (slot stride n_q)
     int cnt = 0, cnt_lt = 0;
 
     // tiles covering the bucket's targets [lo, hi) in this copy, widened to an even tile range
@@ -442,7 +455,7 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
             if (gl == 1) lk_read_group<L, 1 * GW>(r, ptr);
             if (gl == 2) lk_read_group<L, 2 * GW>(r, ptr);
             if (gl == 3) lk_read_group<L, 3 * GW>(r, ptr);
-            pg_process_group<L>(r, (t * LK_TG + gl) * LK_GROUP, lo, hi, k, thr0, cap, n_q, slot0, cnt, cnt_lt, thr, Tb);
+            pg_process_group<L>(r, (t * LK_TG + gl) * LK_GROUP, lo, hi, k, thr0, cap, n_q, wp, cnt, cnt_lt, thr, Tb);
         }
         lk_stage_wait();
         if (t + 2 < t1) lk_stage<L>(table, t + 2, tiles, lane);
@@ -453,7 +466,7 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
             if (gl == 1) lk_read_group<L, TILE_W + 1 * GW>(r, ptr);
             if (gl == 2) lk_read_group<L, TILE_W + 2 * GW>(r, ptr);
             if (gl == 3) lk_read_group<L, TILE_W + 3 * GW>(r, ptr);
-            pg_process_group<L>(r, ((t + 1) * LK_TG + gl) * LK_GROUP, lo, hi, k, thr0, cap, n_q, slot0, cnt, cnt_lt, thr,
+            pg_process_group<L>(r, ((t + 1) * LK_TG + gl) * LK_GROUP, lo, hi, k, thr0, cap, n_q, wp, cnt, cnt_lt, thr,
                                 Tb);
         }
     }
