@@ -49,11 +49,11 @@ int launch_lk(gm_index* idx, const gm_lk_args& a, hipStream_t st) {
 
 template <int L>
 int launch_pg_cfg(gm_index* idx, const gm_pg_blocks* blocks, const gm_pg_chunk* chunks, const int* n_chunks,
-                  int64_t grid, int64_t n_q, int k, int thr0, int cap, uint32_t* hits, int32_t* n_hits,
+                  int64_t grid, int64_t n_q, int k, int thr0, int cap, int cap_x, uint32_t* hits, int32_t* n_hits,
                   hipStream_t st) {
     const size_t lds = 2 * (size_t)gm::lk_tile_bytes(L);
     hipLaunchKernelGGL((gm::k_hamming_scan_pg<L>), dim3((unsigned)grid), dim3(gm::WAVE), lds, st, *blocks, chunks,
-                       n_chunks, (int)idx->n_lk_tiles, idx->d_q, n_q, k, thr0, cap, hits, n_hits);
+                       n_chunks, (int)idx->n_lk_tiles, idx->d_q, n_q, k, thr0, cap, cap_x, hits, n_hits);
     HIP_TRY(hipGetLastError());
     return GM_OK;
 }
@@ -69,6 +69,6 @@ int GM_CAT(gm_launch_lk_L, GM_LEN)(gm_index* idx, const gm_lk_args* a, hipStream
 
 int GM_CAT(gm_launch_pg_L, GM_LEN)(gm_index* idx, const gm_pg_blocks* blocks, const gm_pg_chunk* chunks,
                                    const int* n_chunks, int64_t grid, int64_t n_q, int k, int thr0, int cap,
-                                   uint32_t* hits, int32_t* n_hits, hipStream_t st) {
-    return launch_pg_cfg<GM_LEN>(idx, blocks, chunks, n_chunks, grid, n_q, k, thr0, cap, hits, n_hits, st);
+                                   int cap_x, uint32_t* hits, int32_t* n_hits, hipStream_t st) {
+    return launch_pg_cfg<GM_LEN>(idx, blocks, chunks, n_chunks, grid, n_q, k, thr0, cap, cap_x, hits, n_hits, st);
 }

@@ -358,8 +358,8 @@ __global__ __launch_bounds__(WAVE, lk_min_waves(L, KCAP)) void k_hamming_knn_lk(
 template <int L>
 __device__ __forceinline__ void pg_append_hits(uint32_t h0, uint32_t h1, const uint32_t (&c0)[5],
                                                const uint32_t (&c1)[5], int id0, int lo, int hi, int k, int thr0,
-                                               int cap, int64_t slot_stride, uint32_t*& wp, int& cnt, int& cnt_lt,
-                                               int& thr, uint32_t (&Tb)[5]) {
+                                               int add, int cap, int64_t slot_stride, uint32_t*& wp, int& cnt,
+                                               int& cnt_lt, int& thr, uint32_t (&Tb)[5]) {
     while ((h0 | h1) != 0u) {
         const bool low = h0 != 0u;
         const uint32_t w = low ? h0 : h1;
@@ -370,7 +370,7 @@ __device__ __forceinline__ void pg_append_hits(uint32_t h0, uint32_t h1, const u
         uint32_t m = 0;
 #pragma unroll
         for (int i = 4; i >= 0; --i) m = (m << 1) | __builtin_amdgcn_ubfe(low ? c0[i] : c1[i], (uint32_t)j, 1u);
-        const int d = L - (int)m;
+        const int d = L - (int)m + add;      // + the mismatches known to sit on positions the table leaves out
         const int pos = id0 + j + (low ? 0 : 32);
         if (pos >= lo && pos < hi) {
             if (cnt < cap) *wp = ((uint32_t)d << ID_BITS) | (uint32_t)pos;
@@ -385,7 +385,7 @@ __device__ __forceinline__ void pg_append_hits(uint32_t h0, uint32_t h1, const u
             }
             if (nt < thr) {
                 thr = nt;
-                lk_set_bound(Tb, L, thr);
+                lk_set_bound(Tb, L, thr - add);
             }
         }
     }
@@ -393,20 +393,21 @@ __device__ __forceinline__ void pg_append_hits(uint32_t h0, uint32_t h1, const u
 
 template <int L>
 __device__ __forceinline__ void pg_process_group(const LkGroupRegs<L>& r, int id0, int lo, int hi, int k, int thr0,
-                                                 int cap, int64_t slot_stride, uint32_t*& wp, int& cnt, int& cnt_lt,
-                                                 int& thr, uint32_t (&Tb)[5]) {
+                                                 int add, int cap, int64_t slot_stride, uint32_t*& wp, int& cnt,
+                                                 int& cnt_lt, int& thr, uint32_t (&Tb)[5]) {
     uint32_t c0[5], c1[5];
     const uint32_t h0 = lk_eval_half<L>(r.m0, Tb, c0);
     const uint32_t h1 = lk_eval_half<L>(r.m1, Tb, c1);
     if (__builtin_amdgcn_ballot_w64((h0 | h1) != 0u) != 0ull)
-        pg_append_hits<L>(h0, h1, c0, c1, id0, lo, hi, k, thr0, cap, slot_stride, wp, cnt, cnt_lt, thr, Tb);
+        pg_append_hits<L>(h0, h1, c0, c1, id0, lo, hi, k, thr0, add, cap, slot_stride, wp, cnt, cnt_lt, thr, Tb);
 }
 
-// hits: [B][cap][n_q] keys (distance << 27 | position in copy b), n_hits: [B][n_q] (> cap: overflow)
+// hits: [B][cap][n_q] keys (distance << 27 | position in the copy) followed by [n_expand][cap_x][n_q] for the
+// neighbour lists; n_hits: [B + n_expand][n_q] (a count above the list's capacity = overflow)
 template <int L>
 __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
     gm_pg_blocks P, const gm_pg_chunk* __restrict__ chunks, const int* __restrict__ n_chunks, int n_tiles,
-    const uint2* __restrict__ q, int64_t n_q, int k, int thr0, int cap, uint32_t* __restrict__ hits,
+    const uint2* __restrict__ q, int64_t n_q, int k, int thr0, int cap, int cap_x, uint32_t* __restrict__ hits,
     int32_t* __restrict__ n_hits) {
     extern __shared__ __align__(16) uint32_t smem[];
     constexpr int TILE_W = lk_tile_bytes(L) / 4;
@@ -431,10 +432,14 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
         uint32_t code = ((qv.x >> sp) & 1u) | (((qv.y >> sp) & 1u) << 1);
         ptr[p] = tiles + p * 8 + (int)code * 2;
     }
+    const int add = ch.add;
     int thr = valid ? thr0 : 0;
     uint32_t Tb[5];
-    lk_set_bound(Tb, L, thr);
-    uint32_t* wp = hits + (int64_t)ch.b * cap * n_q + qi;      // next free slot of this lane (slot stride n_q)
+    lk_set_bound(Tb, L, thr - add);
+    // next free slot of this lane in list ch.lst (slot stride n_q)
+    const bool own = ch.lst < P.n_blocks;
+    const int my_cap = own ? cap : cap_x;
+    uint32_t* wp = hits + (own ? (int64_t)ch.lst * cap : (int64_t)P.n_blocks * cap + (int64_t)(ch.lst - P.n_blocks) * cap_x) * n_q + qi;
     int cnt = 0, cnt_lt = 0;
 
     // tiles covering the bucket's targets [lo, hi) in this copy, widened to an even tile range
@@ -455,7 +460,7 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
             if (gl == 1) lk_read_group<L, 1 * GW>(r, ptr);
             if (gl == 2) lk_read_group<L, 2 * GW>(r, ptr);
             if (gl == 3) lk_read_group<L, 3 * GW>(r, ptr);
-            pg_process_group<L>(r, (t * LK_TG + gl) * LK_GROUP, lo, hi, k, thr0, cap, n_q, wp, cnt, cnt_lt, thr, Tb);
+            pg_process_group<L>(r, (t * LK_TG + gl) * LK_GROUP, lo, hi, k, thr0, add, my_cap, n_q, wp, cnt, cnt_lt, thr, Tb);
         }
         lk_stage_wait();
         if (t + 2 < t1) lk_stage<L>(table, t + 2, tiles, lane);
@@ -466,17 +471,17 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
             if (gl == 1) lk_read_group<L, TILE_W + 1 * GW>(r, ptr);
             if (gl == 2) lk_read_group<L, TILE_W + 2 * GW>(r, ptr);
             if (gl == 3) lk_read_group<L, TILE_W + 3 * GW>(r, ptr);
-            pg_process_group<L>(r, ((t + 1) * LK_TG + gl) * LK_GROUP, lo, hi, k, thr0, cap, n_q, wp, cnt, cnt_lt, thr,
-                                Tb);
+            pg_process_group<L>(r, ((t + 1) * LK_TG + gl) * LK_GROUP, lo, hi, k, thr0, add, my_cap, n_q, wp, cnt, cnt_lt,
+                                thr, Tb);
         }
     }
-    if (valid) n_hits[(int64_t)ch.b * n_q + qi] = cnt;
+    if (valid) n_hits[(int64_t)ch.lst * n_q + qi] = cnt;
 }
 
-// K1P merge: one thread per candidate folds its B slot lists into the top k (duplicates taken once).
+// K1P merge: one thread per candidate folds its slot lists into the top k (duplicates taken once).
 // A slot list that overflowed makes the row incomplete (count 0 / distance -1): the host re-scans it.
 template <int KCAP>
-__global__ void k_merge_hits(gm_pg_blocks P, int B, int cap, const uint32_t* __restrict__ hits,
+__global__ void k_merge_hits(gm_pg_blocks P, int cap, int cap_x, const uint32_t* __restrict__ hits,
                              const int32_t* __restrict__ n_hits, int64_t n_q, int k, int32_t* __restrict__ ids,
                              int32_t* __restrict__ dists, int32_t* __restrict__ counts, int nearest) {
     const int64_t qi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -484,14 +489,18 @@ __global__ void k_merge_hits(gm_pg_blocks P, int B, int cap, const uint32_t* __r
     RegList<KCAP> list;
     list.init(k, nullptr, 0);
     bool overflow = false;
-    for (int b = 0; b < B; ++b) {
-        int c = n_hits[(int64_t)b * n_q + qi];
-        if (c > cap) {
+    const int n_lists = P.n_blocks + P.n_expand;
+    for (int l = 0; l < n_lists; ++l) {
+        const bool own = l < P.n_blocks;
+        const int lcap = own ? cap : cap_x;
+        int c = n_hits[(int64_t)l * n_q + qi];
+        if (c > lcap) {
             overflow = true;
-            c = cap;
+            c = lcap;
         }
-        const int32_t* __restrict__ perm = P.perm[b];
-        const uint32_t* slot0 = hits + (int64_t)b * cap * n_q + qi;
+        const int32_t* __restrict__ perm = P.perm[own ? l : P.xblock];
+        const uint32_t* slot0 =
+            hits + (own ? (int64_t)l * cap : (int64_t)P.n_blocks * cap + (int64_t)(l - P.n_blocks) * cap_x) * n_q + qi;
         for (int i = 0; i < c; ++i) {
             const uint32_t key = slot0[(int64_t)i * n_q];
             list.insert_unique((key & ~ID_MASK) | (uint32_t)perm[key & ID_MASK]);

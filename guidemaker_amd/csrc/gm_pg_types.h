@@ -13,9 +13,15 @@ struct gm_pg_blocks {
     const uint32_t* cperm[GM_PG_MAXB];   // candidates sorted by block b: sorted position -> candidate row
     int skip[GM_PG_MAXB];                // copy b's table leaves out sequence positions [skip[b], skip[b] + skip_len)
     int skip_len;
+    int n_blocks;                        // B: slot lists 0 .. B-1 have `cap` slots, lists B .. have `cap_x`
+    int xblock;                          // expansion block (-1: none); its copy serves the neighbour lists
+    int n_expand;                        // neighbour lists (3 x length of the expansion block, or 0)
 };
 
-// one workgroup's work: cn (<= 64) candidates starting at sorted position c0, all in bucket v of block b
+// one workgroup's work: cn (<= 64) candidates starting at sorted position c0 of block b's candidate order,
+// against target bucket v of copy b.  lst = slot list the hits go to (b for the candidates' own bucket,
+// B + e for the e-th one-substitution neighbour bucket of the expansion block); add = mismatches the pair is
+// known to have on positions the copy's table leaves out (1 for a neighbour bucket that differs there).
 struct gm_pg_chunk {
-    int b, v, c0, cn;
+    int b, v, c0, cn, lst, add;
 };

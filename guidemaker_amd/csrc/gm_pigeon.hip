@@ -31,6 +31,15 @@ struct PgLayoutArg {              // per-block geometry + offsets, by value
     int ebase[GM_PG_MAXB + 1];    // first entry of block b in the flattened (block, bucket) list
     const int32_t* coff[GM_PG_MAXB];
     const int32_t* toff[GM_PG_MAXB];
+    // expansion: after the ebase[B] (block, bucket) entries come nb(xb) * xne entries (bucket, neighbour)
+    int xb;                       // expansion block, -1 = none
+    int xne;                      // neighbours per bucket = 3 x block length
+    int xskip;                    // leading block positions the copy's table leaves out
+    int n_entries;
+};
+
+struct PgEntry {
+    int b, vc, vt, lst, add;      // block, candidates' bucket, target bucket, slot list, known hidden mismatches
 };
 
 struct PgCounters {               // device-resident
@@ -209,14 +218,38 @@ __device__ __forceinline__ void pg_entry(const PgLayoutArg& A, int e, int& b, in
     v = e - A.ebase[b];
 }
 
-// chunks per (block, bucket) entry
+// entry -> (block, candidates' bucket, target bucket, list, add).  Neighbour e of bucket v replaces the base at
+// block position e / 3 by one of the three others; if that position is one the table leaves out, the scan
+// cannot see the mismatch and the chunk carries add = 1.
+__device__ __forceinline__ PgEntry pg_entry_ex(const PgLayoutArg& A, int e) {
+    PgEntry r;
+    if (e < A.ebase[A.B]) {
+        pg_entry(A, e, r.b, r.vc);
+        r.vt = r.vc;
+        r.lst = r.b;
+        r.add = 0;
+        return r;
+    }
+    const int x = e - A.ebase[A.B];
+    const int v = x / A.xne, ne = x % A.xne;
+    const int pidx = ne / 3, alt = ne % 3;
+    const int code = (v >> (2 * pidx)) & 3;
+    r.b = A.xb;
+    r.vc = v;
+    r.vt = (v & ~(3 << (2 * pidx))) | (((code + 1 + alt) & 3) << (2 * pidx));
+    r.lst = A.B + ne;
+    r.add = pidx < A.xskip ? 1 : 0;
+    return r;
+}
+
+// chunks per entry (none when either side of the entry is empty)
 __global__ __launch_bounds__(256) void k_chunk_count(PgLayoutArg A, int* __restrict__ nch) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= A.ebase[A.B]) return;
-    int b, v;
-    pg_entry(A, e, b, v);
-    const int cnt = A.coff[b][v + 1] - A.coff[b][v];
-    nch[e] = (cnt + 63) / 64;
+    if (e >= A.n_entries) return;
+    const PgEntry en = pg_entry_ex(A, e);
+    const int cnt = A.coff[en.b][en.vc + 1] - A.coff[en.b][en.vc];
+    const int tgt = A.toff[en.b][en.vt + 1] - A.toff[en.b][en.vt];
+    nch[e] = tgt > 0 ? (cnt + 63) / 64 : 0;
 }
 
 // exclusive scan of n ints by ONE workgroup; total -> *total
@@ -246,19 +279,18 @@ __global__ __launch_bounds__(1024) void k_scan_excl(const int* __restrict__ in, 
 __global__ __launch_bounds__(256) void k_fill_chunks(PgLayoutArg A, const int* __restrict__ cbase, int n_tiles,
                                                      gm_pg_chunk* __restrict__ chunks, PgCounters* __restrict__ ctr) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= A.ebase[A.B]) return;
-    int b, v;
-    pg_entry(A, e, b, v);
-    const int c0 = A.coff[b][v], c1 = A.coff[b][v + 1];
-    if (c1 <= c0) return;
+    if (e >= A.n_entries) return;
+    const PgEntry en = pg_entry_ex(A, e);
+    const int c0 = A.coff[en.b][en.vc], c1 = A.coff[en.b][en.vc + 1];
+    const int lo = A.toff[en.b][en.vt], hi = A.toff[en.b][en.vt + 1];
+    if (c1 <= c0 || hi <= lo) return;
     int w = cbase[e];
-    for (int c = c0; c < c1; c += 64, ++w) chunks[w] = gm_pg_chunk{b, v, c, c1 - c < 64 ? c1 - c : 64};
-    // the tiles the kernel will scan for this bucket (same rounding as k_hamming_knn_pg)
+    for (int c = c0; c < c1; c += 64, ++w)
+        chunks[w] = gm_pg_chunk{en.b, en.vt, c, c1 - c < 64 ? c1 - c : 64, en.lst, en.add};
+    // the tiles the kernel will scan for this bucket (same rounding as k_hamming_scan_pg)
     constexpr int TILE_IDS = gm::LK_TG * gm::LK_GROUP;
-    const int lo = A.toff[b][v], hi = A.toff[b][v + 1];
     int t0 = (lo / TILE_IDS) & ~1, t1 = ((hi + TILE_IDS - 1) / TILE_IDS + 1) & ~1;
     if (t1 > n_tiles) t1 = n_tiles;
-    if (hi <= lo) t1 = t0;
     const unsigned long long pairs = (unsigned long long)((c1 - c0 + 63) / 64) * 64ull * (unsigned long long)(t1 - t0) * TILE_IDS;
     atomicAdd(&ctr->pairs, pairs);
 }
@@ -313,6 +345,8 @@ struct gm_pigeon {
     int B = 0;
     double p_match = 0.0;              // P(two pool sequences carry the same base at a position); 0 = not measured
     int max_bucket[GM_PG_MAXB]{};      // largest bucket of every pool copy
+    int expand = 0;                    // 1: B blocks serve radius r = B through the neighbour buckets of block 0
+    int cap_x = 0;                     // slots per neighbour list
     int skip_len = 0;                  // positions of its own block each copy's table leaves out
     int Lp = 0;                        // positions the scan evaluates = L - skip_len (>= 10)
     int bstart[GM_PG_MAXB]{}, blen[GM_PG_MAXB]{};
@@ -400,32 +434,42 @@ static double tail_within(int n, int r, double pm) {
     return cum;
 }
 
-// Layout choice under an independent-base model with the pool's own composition (p_match = sum_b f_b^2):
-// E(r) = expected pool targets within r mismatches of a candidate; a candidate is incomplete when fewer
-// than k of them exist (Poisson), and costs a plain scan.  Minimise  sum_b p_match^len(b)  (fraction of the
-// pairs that share block b)  +  P(incomplete)  over B = r + 1; 0 when the plain scan is at least as good.
-int gm_pg_plan(int64_t n_db, int L, int k, double p_match) {
+// Layout choice under an independent-base model with the pool's own composition (p_match = sum_b f_b^2).
+// Plain mode: B = r + 1 blocks, every pair within r shares a block.  Expansion mode: B = r blocks -- a pair
+// within r that shares none has exactly one mismatch in EVERY block, so it also sits in one of the 3 x len
+// one-substitution neighbour buckets of the (longest) block 0, which get one extra pass.
+// cost = fraction of the pairs evaluated + P(Poisson(n P(d <= r)) < k) (rows re-scanned); 0 when the plain
+// scan is at least as good.
+int gm_pg_plan(int64_t n_db, int L, int k, double p_match, int* expand) {
+    if (expand) *expand = 0;
     if (L < 12 || L > GM_MAX_GUIDELEN || n_db < 32768 || k < 1 || k > 20) return 0;
     if (!(p_match >= 0.25 && p_match < 0.9)) p_match = 0.25;
     double best = 0.45;      // K1P has to be clearly cheaper than scanning everything
     int best_B = 0;
-    for (int r = 1; r < GM_PG_MAXB; ++r) {
-        const int B = r + 1;
-        const int base = L / B, extra = L % B;
-        if (base < 2 || base + (extra ? 1 : 0) > GM_PG_MAXLEN) continue;
-        double work = 0.0;
-        for (int b = 0; b < B; ++b) work += std::pow(p_match, (double)(base + (b < extra ? 1 : 0)));
-        const double mean = (double)n_db * tail_within(L, r, p_match);
-        double p_inc = 0.0, term = std::exp(-mean);      // P(Poisson(mean) < k)
-        for (int j = 0; j < k; ++j) {
-            p_inc += term;
-            term *= mean / (j + 1);
-        }
-        if (mean > 700.0) p_inc = 0.0;
-        const double cost = work + (p_inc < 1.0 ? p_inc : 1.0);
-        if (cost < best) {
-            best = cost;
-            best_B = B;
+    for (int mode = 0; mode < 2; ++mode) {
+        for (int B = 2; B <= GM_PG_MAXB; ++B) {
+            const int r = mode ? B : B - 1;
+            const int base = L / B, extra = L % B;
+            if (base < 2 || base + (extra ? 1 : 0) > GM_PG_MAXLEN) continue;
+            double work = 0.0;
+            for (int b = 0; b < B; ++b) work += std::pow(p_match, (double)(base + (b < extra ? 1 : 0)));
+            if (mode) {
+                const int len0 = base + (extra ? 1 : 0);
+                work += 3.0 * len0 * std::pow(p_match, (double)(len0 - 1)) * (1.0 - p_match) / 3.0;
+            }
+            const double mean = (double)n_db * tail_within(L, r, p_match);
+            double p_inc = 0.0, term = std::exp(-mean);      // P(Poisson(mean) < k)
+            for (int j = 0; j < k; ++j) {
+                p_inc += term;
+                term *= mean / (j + 1);
+            }
+            if (mean > 700.0) p_inc = 0.0;
+            const double cost = work + (p_inc < 1.0 ? p_inc : 1.0);
+            if (cost < best) {
+                best = cost;
+                best_B = B;
+                if (expand) *expand = mode;
+            }
         }
     }
     return best_B;
@@ -473,10 +517,11 @@ void gm_pg_free(gm_index* idx) {
     idx->pg = nullptr;
 }
 
-int gm_pg_prepare(gm_index* idx, int B, hipStream_t st) {
+int gm_pg_prepare(gm_index* idx, int B, int expand, hipStream_t st) {
     if (B < 2 || B > GM_PG_MAXB) return gm_fail(GM_ERR_ARG, "gm_pg_prepare: bad block count");
     if (!idx->pg) idx->pg = new gm_pigeon();
     gm_pigeon* pg = idx->pg;
+    pg->expand = expand ? 1 : 0;       // same pool copies either way
     if (pg->B == B) return GM_OK;
     free_pool_side(pg);
     const int L = idx->L;
@@ -549,7 +594,7 @@ int gm_pg_candidates(gm_index* idx, int64_t n_q, hipStream_t st) {
     if (!pg || pg->B < 2) return gm_fail(GM_ERR_ARG, "gm_pg_candidates: no layout prepared");
     if (n_q >= (int64_t)1 << 31) return gm_fail(GM_ERR_ARG, "gm_pg_candidates: too many candidates");
     int rc;
-    const int n_entries = pg->ebase[pg->B];
+    const int n_entries = pg->ebase[pg->B];      // (block, bucket) entries = histogram bins
     if ((rc = ensure(&pg->hist, &pg->hist_cap, n_entries, "bucket histogram"))) return rc;
     if ((rc = ensure(&pg->cursor, &pg->cursor_cap, n_entries, "bucket cursors"))) return rc;
     PgLayoutArg A{};
@@ -576,24 +621,32 @@ int gm_pg_candidates(gm_index* idx, int64_t n_q, hipStream_t st) {
     hipLaunchKernelGGL(k_cand_offsets, dim3(pg->B), dim3(1024), 0, st, K, pg->hist, pg->cursor);
     hipLaunchKernelGGL(k_cand_scatter, grid_for(n_q, 1024), dim3(1024), lds, st, idx->d_q, n_q, K, pg->cursor, use_lds);
     HIP_TRY(hipGetLastError());
-    if ((rc = ensure(&pg->nch, &pg->nch_cap, n_entries, "chunk counts"))) return rc;
-    if ((rc = ensure(&pg->cbase, &pg->cbase_cap, n_entries, "chunk offsets"))) return rc;
+    // chunk table: the own-bucket entries of every block, plus (expansion) the neighbour buckets of block 0
+    A.xb = pg->expand ? 0 : -1;
+    A.xne = pg->expand ? 3 * pg->blen[0] : 0;
+    A.xskip = pg->skip_len;
+    const int nb0 = 1 << (2 * pg->blen[0]);
+    A.n_entries = n_entries + (pg->expand ? nb0 * A.xne : 0);
+    if (pg->expand) grid += (int64_t)A.xne * ((n_q + 63) / 64 + nb0);
+    if ((rc = ensure(&pg->nch, &pg->nch_cap, A.n_entries, "chunk counts"))) return rc;
+    if ((rc = ensure(&pg->cbase, &pg->cbase_cap, A.n_entries, "chunk offsets"))) return rc;
     if ((rc = ensure(&pg->chunks, &pg->chunks_cap, grid, "chunk table"))) return rc;
     HIP_TRY(hipMemsetAsync(pg->ctr, 0, sizeof(PgCounters), st));
-    hipLaunchKernelGGL(k_chunk_count, grid_for(n_entries), dim3(256), 0, st, A, pg->nch);
-    hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, st, pg->nch, n_entries, pg->cbase, &pg->ctr->n_chunks);
-    hipLaunchKernelGGL(k_fill_chunks, grid_for(n_entries), dim3(256), 0, st, A, pg->cbase, (int)idx->n_lk_tiles, pg->chunks,
-                       pg->ctr);
+    hipLaunchKernelGGL(k_chunk_count, grid_for(A.n_entries), dim3(256), 0, st, A, pg->nch);
+    hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, st, pg->nch, A.n_entries, pg->cbase, &pg->ctr->n_chunks);
+    hipLaunchKernelGGL(k_fill_chunks, grid_for(A.n_entries), dim3(256), 0, st, A, pg->cbase, (int)idx->n_lk_tiles,
+                       pg->chunks, pg->ctr);
     HIP_TRY(hipGetLastError());
     pg->grid = grid;
     return GM_OK;
 }
 
-// slots per (candidate, block): 1.25 x (mean + 6 sigma) of the hits expected in the LARGEST bucket of any copy
-// under the independent-base model with the pool's own composition, at least 16.  A list that still
-// overflows (repeat families) only makes its row incomplete: the row is re-scanned by the plain kernel.
-static int pg_slot_capacity(const gm_index* idx, const gm_pigeon* pg, int64_t n_q) {
-    const int L = idx->L, r = pg->B - 1;
+// slots per (candidate, list): 1.25 x (mean + 6 sigma) of the hits expected in the LARGEST bucket of any copy
+// under the independent-base model with the pool's own composition (own buckets: >= 16; neighbour buckets of
+// the expansion pass, where the pair already has one mismatch: >= 8).  A list that still overflows (repeat
+// families) only makes its row incomplete: the row is re-scanned by the plain kernel.
+static void pg_slot_capacity(const gm_index* idx, gm_pigeon* pg, int64_t n_q) {
+    const int L = idx->L, r = pg->expand ? pg->B : pg->B - 1;
     const double pm = pg->p_match >= 0.25 ? pg->p_match : 0.25;
     double worst = 0.0;
     for (int b = 0; b < pg->B; ++b) {
@@ -603,21 +656,36 @@ static int pg_slot_capacity(const gm_index* idx, const gm_pigeon* pg, int64_t n_
     double cap = std::ceil(1.25 * (worst + 6.0 * std::sqrt(worst)) + 8.0);
     if (cap < 16.0) cap = 16.0;
     if (cap > 1024.0) cap = 1024.0;
+    double cap_x = 0.0;
+    const int n_x = pg->expand ? 3 * pg->blen[0] : 0;
+    if (pg->expand) {
+        const double h = (double)pg->max_bucket[0] * tail_within(L - pg->blen[0], r - 1, pm);
+        cap_x = std::ceil(1.25 * (h + 6.0 * std::sqrt(h)) + 8.0);
+        if (cap_x > 512.0) cap_x = 512.0;
+    }
     // keep the slot lists within a quarter of the free device memory (at least 2 GiB)
     size_t free_b = 0, total_b = 0;
     double limit = 2.0 * 1024 * 1024 * 1024;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)free_b / 4.0 > limit) limit = (double)free_b / 4.0;
-    const double per_slot = (double)pg->B * (double)n_q * 4.0;
-    while (cap > 16.0 && cap * per_slot > limit) cap = std::floor(cap * 0.75);
-    return (int)cap;
+    while ((cap > 16.0 || cap_x > 8.0) && (cap * pg->B + cap_x * n_x) * (double)n_q * 4.0 > limit) {
+        cap = cap > 16.0 ? std::floor(cap * 0.75) : cap;
+        cap_x = cap_x > 8.0 ? std::floor(cap_x * 0.75) : cap_x;
+    }
+    pg->cap = (int)cap;
+    pg->cap_x = (int)cap_x;
 }
 
 int gm_pg_scan(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
     gm_pigeon* pg = idx->pg;
     int rc;
-    pg->cap = pg_slot_capacity(idx, pg, n_q);
-    if ((rc = ensure(&pg->keys, &pg->keys_cap, (int64_t)pg->B * pg->cap * n_q, "K1P slot lists"))) return rc;
-    if ((rc = ensure(&pg->n_hits, &pg->n_hits_cap, (int64_t)pg->B * n_q, "K1P hit counts"))) return rc;
+    pg_slot_capacity(idx, pg, n_q);
+    const int n_x = pg->expand ? 3 * pg->blen[0] : 0;
+    if ((rc = ensure(&pg->keys, &pg->keys_cap, ((int64_t)pg->B * pg->cap + (int64_t)n_x * pg->cap_x) * n_q,
+                     "K1P slot lists")))
+        return rc;
+    if ((rc = ensure(&pg->n_hits, &pg->n_hits_cap, (int64_t)(pg->B + n_x) * n_q, "K1P hit counts"))) return rc;
+    // a (list, candidate) pair whose target bucket is empty gets no workgroup: its count must read 0
+    HIP_TRY(hipMemsetAsync(pg->n_hits, 0, sizeof(int32_t) * (size_t)(pg->B + n_x) * (size_t)n_q, st));
     gm_pg_blocks& blocks = pg->blocks;
     for (int b = 0; b < pg->B; ++b) {
         blocks.table[b] = pg->table[b];
@@ -627,10 +695,13 @@ int gm_pg_scan(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
         blocks.skip[b] = pg->bstart[b];
     }
     blocks.skip_len = pg->skip_len;
-    const int thr0 = pg->B;      // accept d < B, i.e. d <= r
+    blocks.n_blocks = pg->B;
+    blocks.xblock = pg->expand ? 0 : -1;
+    blocks.n_expand = n_x;
+    const int thr0 = pg->expand ? pg->B + 1 : pg->B;      // accept d < thr0, i.e. d <= r
     switch (pg->Lp) {            // the kernel instantiated for the positions actually evaluated
 #define GM_CASE(LEN) \
-    case LEN: return gm_launch_pg_L##LEN(idx, &blocks, pg->chunks, &pg->ctr->n_chunks, pg->grid, n_q, k, thr0, pg->cap, pg->keys, pg->n_hits, st);
+    case LEN: return gm_launch_pg_L##LEN(idx, &blocks, pg->chunks, &pg->ctr->n_chunks, pg->grid, n_q, k, thr0, pg->cap, pg->cap_x, pg->keys, pg->n_hits, st);
         GM_FOR_EACH_LEN(GM_CASE)
 #undef GM_CASE
         default: return gm_fail(GM_ERR_ARG, "pigeonhole kernel: guidelen out of range");
@@ -643,10 +714,10 @@ int gm_pg_merge(gm_index* idx, int kcap, int64_t n_q, int k, int32_t* ids, int32
     const dim3 grid = grid_for(n_q), block(256);
     const int nr = nearest ? 1 : 0;
     switch (kcap) {
-        case 1: hipLaunchKernelGGL(gm::k_merge_hits<1>, grid, block, 0, st, pg->blocks, pg->B, pg->cap, pg->keys, pg->n_hits, n_q, k, ids, dists, counts, nr); break;
-        case 5: hipLaunchKernelGGL(gm::k_merge_hits<5>, grid, block, 0, st, pg->blocks, pg->B, pg->cap, pg->keys, pg->n_hits, n_q, k, ids, dists, counts, nr); break;
-        case 10: hipLaunchKernelGGL(gm::k_merge_hits<10>, grid, block, 0, st, pg->blocks, pg->B, pg->cap, pg->keys, pg->n_hits, n_q, k, ids, dists, counts, nr); break;
-        default: hipLaunchKernelGGL(gm::k_merge_hits<20>, grid, block, 0, st, pg->blocks, pg->B, pg->cap, pg->keys, pg->n_hits, n_q, k, ids, dists, counts, nr); break;
+        case 1: hipLaunchKernelGGL(gm::k_merge_hits<1>, grid, block, 0, st, pg->blocks, pg->cap, pg->cap_x, pg->keys, pg->n_hits, n_q, k, ids, dists, counts, nr); break;
+        case 5: hipLaunchKernelGGL(gm::k_merge_hits<5>, grid, block, 0, st, pg->blocks, pg->cap, pg->cap_x, pg->keys, pg->n_hits, n_q, k, ids, dists, counts, nr); break;
+        case 10: hipLaunchKernelGGL(gm::k_merge_hits<10>, grid, block, 0, st, pg->blocks, pg->cap, pg->cap_x, pg->keys, pg->n_hits, n_q, k, ids, dists, counts, nr); break;
+        default: hipLaunchKernelGGL(gm::k_merge_hits<20>, grid, block, 0, st, pg->blocks, pg->cap, pg->cap_x, pg->keys, pg->n_hits, n_q, k, ids, dists, counts, nr); break;
     }
     HIP_TRY(hipGetLastError());
     return GM_OK;

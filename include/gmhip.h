@@ -143,9 +143,10 @@ int64_t gm_last_kernel_evaluated(gm_index* idx);
 int64_t gm_last_incomplete(gm_index* idx);
 /* Number of blocks B of the K1P layout currently built for this handle (0: none built yet). */
 int gm_pigeon_blocks(gm_index* idx);
-/* The layout planner on its own (host arithmetic only, no device needed): number of blocks K1P would use for
+/* The layout planner on its own (host arithmetic only, no device needed): number of blocks B K1P would use for
  * a pool of n_db targets of this length, k neighbours and base-match probability p_match (sum of squared base
- * frequencies; 0.25 = uniform), or 0 when the plain scan is the better choice. */
+ * frequencies; 0.25 = uniform); 100 + B when the layout uses the neighbour-bucket expansion (B blocks serving
+ * radius B); 0 when the plain scan is the better choice. */
 int gm_pigeon_plan(int64_t n_db, int guidelen, int k, double p_match);
 
 /* Per-launch timing history: gm_timing_reserve(idx, n) arms n HIP-event pairs (and resets the
