@@ -442,12 +442,14 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
     uint32_t* wp = hits + (own ? (int64_t)ch.lst * cap : (int64_t)P.n_blocks * cap + (int64_t)(ch.lst - P.n_blocks) * cap_x) * n_q + qi;
     int cnt = 0, cnt_lt = 0;
 
-    // tiles covering the bucket's targets [lo, hi) in this copy, widened to an even tile range
+    // tiles covering the bucket's targets [lo, hi) in this copy, widened to an even tile range for the
+    // double-buffered staging; only the 64-target groups [g_lo, g_hi) that overlap the bucket are evaluated
     const int lo = P.toff[ch.b][ch.v], hi = P.toff[ch.b][ch.v + 1];
     int t0 = (lo / TILE_IDS) & ~1;
     int t1 = ((hi + TILE_IDS - 1) / TILE_IDS + 1) & ~1;
     if (t1 > n_tiles) t1 = n_tiles;
     if (hi <= lo) t1 = t0;
+    const int g_lo = lo / LK_GROUP, g_hi = (hi + LK_GROUP - 1) / LK_GROUP;
 
     if (t0 < t1) lk_stage<L>(table, t0, tiles, lane);
     for (int t = t0; t < t1; t += 2) {
@@ -455,24 +457,27 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
         lk_stage<L>(table, t + 1, tiles + TILE_W, lane);
 #pragma unroll
         for (int gl = 0; gl < LK_TG; ++gl) {
+            const int g = t * LK_TG + gl;
+            if (g < g_lo || g >= g_hi) continue;      // wave-uniform
             LkGroupRegs<L> r;
             if (gl == 0) lk_read_group<L, 0 * GW>(r, ptr);
             if (gl == 1) lk_read_group<L, 1 * GW>(r, ptr);
             if (gl == 2) lk_read_group<L, 2 * GW>(r, ptr);
             if (gl == 3) lk_read_group<L, 3 * GW>(r, ptr);
-            pg_process_group<L>(r, (t * LK_TG + gl) * LK_GROUP, lo, hi, k, thr0, add, my_cap, n_q, wp, cnt, cnt_lt, thr, Tb);
+            pg_process_group<L>(r, g * LK_GROUP, lo, hi, k, thr0, add, my_cap, n_q, wp, cnt, cnt_lt, thr, Tb);
         }
         lk_stage_wait();
         if (t + 2 < t1) lk_stage<L>(table, t + 2, tiles, lane);
 #pragma unroll
         for (int gl = 0; gl < LK_TG; ++gl) {
+            const int g = (t + 1) * LK_TG + gl;
+            if (g < g_lo || g >= g_hi) continue;
             LkGroupRegs<L> r;
             if (gl == 0) lk_read_group<L, TILE_W + 0 * GW>(r, ptr);
             if (gl == 1) lk_read_group<L, TILE_W + 1 * GW>(r, ptr);
             if (gl == 2) lk_read_group<L, TILE_W + 2 * GW>(r, ptr);
             if (gl == 3) lk_read_group<L, TILE_W + 3 * GW>(r, ptr);
-            pg_process_group<L>(r, ((t + 1) * LK_TG + gl) * LK_GROUP, lo, hi, k, thr0, add, my_cap, n_q, wp, cnt, cnt_lt,
-                                thr, Tb);
+            pg_process_group<L>(r, g * LK_GROUP, lo, hi, k, thr0, add, my_cap, n_q, wp, cnt, cnt_lt, thr, Tb);
         }
     }
     if (valid) n_hits[(int64_t)ch.lst * n_q + qi] = cnt;

@@ -287,11 +287,11 @@ __global__ __launch_bounds__(256) void k_fill_chunks(PgLayoutArg A, const int* _
     int w = cbase[e];
     for (int c = c0; c < c1; c += 64, ++w)
         chunks[w] = gm_pg_chunk{en.b, en.vt, c, c1 - c < 64 ? c1 - c : 64, en.lst, en.add};
-    // the tiles the kernel will scan for this bucket (same rounding as k_hamming_scan_pg)
-    constexpr int TILE_IDS = gm::LK_TG * gm::LK_GROUP;
-    int t0 = (lo / TILE_IDS) & ~1, t1 = ((hi + TILE_IDS - 1) / TILE_IDS + 1) & ~1;
-    if (t1 > n_tiles) t1 = n_tiles;
-    const unsigned long long pairs = (unsigned long long)((c1 - c0 + 63) / 64) * 64ull * (unsigned long long)(t1 - t0) * TILE_IDS;
+    // the 64-target groups the kernel will evaluate for this bucket (same rounding as k_hamming_scan_pg)
+    (void)n_tiles;
+    const int g_lo = lo / gm::LK_GROUP, g_hi = (hi + gm::LK_GROUP - 1) / gm::LK_GROUP;
+    const unsigned long long pairs =
+        (unsigned long long)((c1 - c0 + 63) / 64) * 64ull * (unsigned long long)(g_hi - g_lo) * gm::LK_GROUP;
     atomicAdd(&ctr->pairs, pairs);
 }
 
