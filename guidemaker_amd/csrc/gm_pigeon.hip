@@ -46,6 +46,8 @@ struct PgCounters {               // device-resident
     int n_chunks;
     int n_inc;
     unsigned long long pairs;     // pairs the last K1P launch evaluates (chunks x 64 x scanned targets)
+    int n_bad;                    // re-scanned rows that did not fill under the guessed bound
+    int pad;
 };
 
 __global__ __launch_bounds__(256) void k_block_keys(const uint2* __restrict__ planes, int64_t n, int start, int len,
@@ -304,6 +306,13 @@ __global__ __launch_bounds__(256) void k_collect_incomplete(const int32_t* __res
     if (incomplete) inc[atomicAdd(&ctr->n_inc, 1)] = (int32_t)i;
 }
 
+__global__ __launch_bounds__(256) void k_count_incomplete(const int32_t* __restrict__ counts, const int32_t* __restrict__ d1,
+                                                          int64_t n, int need, int* __restrict__ n_bad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (counts != nullptr ? counts[i] < need : d1[i] < 0) atomicAdd(n_bad, 1);
+}
+
 __global__ __launch_bounds__(256) void k_gather_rows(const uint2* __restrict__ q, const int32_t* __restrict__ inc, int64_t n,
                                                      uint2* __restrict__ q2) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -502,6 +511,7 @@ int gm_pg_pool_stats(gm_index* idx, hipStream_t st, double* p_match) {
 }
 
 int gm_pg_blocks_of(const gm_index* idx) { return idx->pg ? idx->pg->B : 0; }
+int gm_pg_radius(const gm_index* idx) { return idx->pg ? (idx->pg->expand ? idx->pg->B : idx->pg->B - 1) : 0; }
 
 void gm_pg_free(gm_index* idx) {
     gm_pigeon* pg = idx->pg;
@@ -735,6 +745,19 @@ int gm_pg_incomplete(gm_index* idx, int64_t n_q, int need, const int32_t* counts
     HIP_TRY(hipStreamSynchronize(st));
     *n_inc = h.n_inc;
     *pairs_evaluated = (int64_t)h.pairs;
+    return GM_OK;
+}
+
+int gm_pg_count_incomplete(gm_index* idx, int64_t n, int need, const int32_t* counts, const int32_t* d1,
+                           int64_t* n_bad, hipStream_t st) {
+    gm_pigeon* pg = idx->pg;
+    HIP_TRY(hipMemsetAsync(&pg->ctr->n_bad, 0, sizeof(int), st));
+    hipLaunchKernelGGL(k_count_incomplete, grid_for(n), dim3(256), 0, st, counts, d1, n, need, &pg->ctr->n_bad);
+    HIP_TRY(hipGetLastError());
+    int h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, &pg->ctr->n_bad, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *n_bad = h;
     return GM_OK;
 }
 

@@ -124,8 +124,18 @@ int launch_merge(int kcap, const uint32_t* keys, int n_seg, int64_t n_q, int k, 
 
 // K1L Hamming scan of the candidates in idx->d_q.  nearest: k = 1, distances only (into dists).
 // timed: record the HIP events around the dominant launch (false when used as the Levenshtein seeder).
+// all lists of a candidate start with the bound `key`'s distance: seeds[q][kcap - 1] = key, the rest empty
+__global__ void k_fill_seeds(uint32_t* __restrict__ seeds, int64_t n_q, int kcap, uint32_t key) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_q * kcap) seeds[t] = (t % kcap) == kcap - 1 ? key : 0xffffffffu;
+}
+
+// guess_thr > 0 (K1P's re-scan): the caller knows a distance bound that almost surely holds for these rows;
+// every segment is scanned in ONE seeded launch under it (no unseeded first phase).  A row whose list does
+// not fill under the guess is NOT exact -- the caller checks the counts and repeats without a guess.
 int run_hamming_lookup(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t* ids, int32_t* dists,
-                       int32_t* counts, bool timed, hipStream_t st, const uint2* qplanes = nullptr) {
+                       int32_t* counts, bool timed, hipStream_t st, const uint2* qplanes = nullptr,
+                       int guess_thr = 0) {
     gm_lk_args a;
     a.q = qplanes;
     a.kcap = nearest ? 1 : (idx->variant == 7 || k > 20 ? 0 : (k <= 5 ? 5 : (k <= 10 ? 10 : 20)));
@@ -161,9 +171,20 @@ int run_hamming_lookup(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
     int64_t tps = (n_tiles + n_seg - 1) / n_seg;
     tps += tps & 1;
     n_seg = (n_tiles + tps - 1) / tps;
-    if ((rc = ensure_u32(&idx->d_keys, &idx->keys_cap, n_seg * n_q * a.kcap))) return rc;
+    if ((rc = ensure_u32(&idx->d_keys, &idx->keys_cap, (n_seg + 1) * n_q * a.kcap))) return rc;
     a.tiles_per_seg = (int)tps;
     a.out_keys = idx->d_keys;
+    if (guess_thr > 0) {      // one seeded launch over all segments under the caller's bound
+        uint32_t* seeds = idx->d_keys + n_seg * n_q * a.kcap;
+        hipLaunchKernelGGL(k_fill_seeds, dim3((unsigned)((n_q * a.kcap + 255) / 256)), dim3(256), 0, st, seeds, n_q,
+                           a.kcap, ((uint32_t)guess_thr << 27) + 1u);
+        HIP_TRY(hipGetLastError());
+        a.n_seg = (int)n_seg;
+        a.seg_base = 0;
+        a.seed_keys = seeds;
+        if ((rc = launch_lk_len(idx, a, st))) return rc;
+        return launch_merge(a.kcap, idx->d_keys, (int)n_seg, n_q, a.k, ids, dists, counts, nearest, st);
+    }
     a.n_seg = 1;
     a.seg_base = 0;
     if ((rc = launch_lk_len(idx, a, st))) return rc;               // phase A
@@ -274,7 +295,16 @@ int run_hamming_pigeon(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
         const uint2* q2 = nullptr;
         int32_t *ids2 = nullptr, *dists2 = nullptr, *counts2 = nullptr;
         if ((rc = gm_pg_gather(idx, n_inc, keff, nearest, &q2, &ids2, &dists2, &counts2, st))) return rc;
-        if ((rc = run_hamming_lookup(idx, nearest, n_inc, keff, ids2, dists2, counts2, false, st, q2))) return rc;
+        // these rows have fewer than k neighbours within r (or a flooded slot list): their k-th neighbour is
+        // almost surely at r + 1, so scan under the bound d < r + 2 first and fall back to the unseeded scan
+        // only if a list still does not fill
+        const int guess = gm_pg_radius(idx) + 2;
+        if ((rc = run_hamming_lookup(idx, nearest, n_inc, keff, ids2, dists2, counts2, false, st, q2, guess))) return rc;
+        int64_t n_bad = 0;
+        if ((rc = gm_pg_count_incomplete(idx, n_inc, keff, counts2, nearest ? dists2 : nullptr, &n_bad, st))) return rc;
+        if (n_bad > 0 &&
+            (rc = run_hamming_lookup(idx, nearest, n_inc, keff, ids2, dists2, counts2, false, st, q2)))
+            return rc;
         if ((rc = gm_pg_scatter(idx, n_inc, keff, nearest, ids, dists, counts, st))) return rc;
     }
     *used = true;
