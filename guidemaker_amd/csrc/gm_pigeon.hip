@@ -448,9 +448,10 @@ static double tail_within(int n, int r, double pm) {
 // within r that shares none has exactly one mismatch in EVERY block, so it also sits in one of the 3 x len
 // one-substitution neighbour buckets of the (longest) block 0, which get one extra pass.
 // cost = fraction of the pairs evaluated + P(Poisson(n P(d <= r)) < k) (rows re-scanned); 0 when the plain
-// scan is at least as good.
-int gm_pg_plan(int64_t n_db, int L, int k, double p_match, int* expand) {
+// scan is at least as good.  max_len = longest block the caller can use (buckets must hold enough candidates).
+int gm_pg_plan(int64_t n_db, int L, int k, double p_match, int* expand, int max_len) {
     if (expand) *expand = 0;
+    if (max_len > GM_PG_MAXLEN) max_len = GM_PG_MAXLEN;
     if (L < 12 || L > GM_MAX_GUIDELEN || n_db < 32768 || k < 1 || k > 20) return 0;
     if (!(p_match >= 0.25 && p_match < 0.9)) p_match = 0.25;
     double best = 0.45;      // K1P has to be clearly cheaper than scanning everything
@@ -459,7 +460,7 @@ int gm_pg_plan(int64_t n_db, int L, int k, double p_match, int* expand) {
         for (int B = 2; B <= GM_PG_MAXB; ++B) {
             const int r = mode ? B : B - 1;
             const int base = L / B, extra = L % B;
-            if (base < 2 || base + (extra ? 1 : 0) > GM_PG_MAXLEN) continue;
+            if (base < 2 || base + (extra ? 1 : 0) > max_len) continue;
             double work = 0.0;
             for (int b = 0; b < B; ++b) work += std::pow(p_match, (double)(base + (b < extra ? 1 : 0)));
             if (mode) {

@@ -267,13 +267,15 @@ int run_hamming_pigeon(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
     if (idx->n_db >= 32768 || forced) {
         if ((rc = gm_pg_pool_stats(idx, st, &p_match))) return rc;
     }
+    // enough candidates per bucket to fill the 64-lane chunks: at least 160 x 4^(longest block)
+    // (measured break-even on a 600k pool: ~10k candidates for 3-base blocks)
+    int len_ok = 0;
+    while (len_ok < GM_PG_MAXLEN && n_q >= ((int64_t)160 << (2 * (len_ok + 1)))) ++len_ok;
     int expand = forced_x ? 1 : 0;
-    const int B = forced ? idx->variant % 100 : gm_pg_plan(idx->n_db, idx->L, keff, p_match, &expand);
+    const int B = forced ? idx->variant % 100 : gm_pg_plan(idx->n_db, idx->L, keff, p_match, &expand, len_ok);
     if (B == 0 || idx->L / B < 1) return GM_OK;
     const int max_len = (idx->L + B - 1) / B;
     if (max_len > GM_PG_MAXLEN) return GM_OK;
-    // enough candidates per bucket to fill the 64-lane chunks (measured break-even on a 600k pool: ~10k)
-    if (!forced && n_q < (int64_t)160 << (2 * max_len)) return GM_OK;
     if ((rc = gm_pg_prepare(idx, B, expand, st))) return rc;
     if ((rc = gm_pg_candidates(idx, n_q, st))) return rc;
     const int kcap = nearest ? 1 : (k <= 5 ? 5 : (k <= 10 ? 10 : 20));
@@ -833,7 +835,7 @@ int64_t gm_last_incomplete(gm_index* idx) { return idx ? idx->last_incomplete : 
 int gm_pigeon_blocks(gm_index* idx) { return idx ? gm_pg_blocks_of(idx) : 0; }
 int gm_pigeon_plan(int64_t n_db, int guidelen, int k, double p_match) {
     int expand = 0;
-    const int B = gm_pg_plan(n_db, guidelen, k, p_match, &expand);
+    const int B = gm_pg_plan(n_db, guidelen, k, p_match, &expand, GM_PG_MAXLEN);
     return B ? B + 100 * expand : 0;
 }
 
