@@ -91,9 +91,9 @@ GM_FOR_EACH_LEN(GM_DECL_PG)
 // gm_pg_prepare: block-sorted pool copies for B; gm_pg_candidates: group the candidates in idx->d_q;
 // gm_pg_scan: the K1P launch; gm_pg_merge: slot lists -> top k; gm_pg_incomplete: rows whose merged list is not full (device list + count,
 // synchronises the stream); gm_pg_gather / gm_pg_scatter: move those rows to / from a compact query.
-int gm_pg_plan(int64_t n_db, int L, int k, double p_match, int* expand, int max_len);
+int gm_pg_plan(int64_t n_db, int64_t n_q, int L, int k, double p_match, int max_len, int* expand, int* len0);
 int gm_pg_pool_stats(gm_index* idx, hipStream_t st, double* p_match);
-int gm_pg_prepare(gm_index* idx, int B, int expand, hipStream_t st);
+int gm_pg_prepare(gm_index* idx, int B, int expand, int len0, hipStream_t st);
 int gm_pg_candidates(gm_index* idx, int64_t n_q, hipStream_t st);
 int gm_pg_scan(gm_index* idx, int64_t n_q, int k, hipStream_t st);
 int gm_pg_merge(gm_index* idx, int kcap, int64_t n_q, int k, int32_t* ids, int32_t* dists, int32_t* counts,

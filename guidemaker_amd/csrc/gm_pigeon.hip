@@ -435,6 +435,21 @@ double log_choose(int n, int r) { return std::lgamma(n + 1.0) - std::lgamma(r + 
 
 }  // namespace
 
+// Block lengths of a layout: block 0 has len0 bases, the other B - 1 share the rest as evenly as possible
+// (longer ones first).  len0 = 0 asks for the even split of all B blocks.  false: not a usable layout.
+static bool pg_block_lengths(int L, int B, int len0, int max_len, int (&blen)[GM_PG_MAXB]) {
+    if (B < 2 || B > GM_PG_MAXB) return false;
+    if (len0 <= 0) len0 = (L + B - 1) / B;
+    const int rest = L - len0;
+    if (rest < 2 * (B - 1)) return false;
+    const int base = rest / (B - 1), extra = rest % (B - 1);
+    blen[0] = len0;
+    for (int b = 1; b < B; ++b) blen[b] = base + (b - 1 < extra ? 1 : 0);
+    for (int b = 0; b < B; ++b)
+        if (blen[b] < 2 || blen[b] > max_len) return false;
+    return len0 >= blen[1];      // block 0 is (one of) the longest: it carries the expansion
+}
+
 // P(at most r mismatches over n positions) when a position matches with probability pm
 static double tail_within(int n, int r, double pm) {
     double cum = 0.0;
@@ -449,36 +464,47 @@ static double tail_within(int n, int r, double pm) {
 // one-substitution neighbour buckets of the (longest) block 0, which get one extra pass.
 // cost = fraction of the pairs evaluated + P(Poisson(n P(d <= r)) < k) (rows re-scanned); 0 when the plain
 // scan is at least as good.  max_len = longest block the caller can use (buckets must hold enough candidates).
-int gm_pg_plan(int64_t n_db, int L, int k, double p_match, int* expand, int max_len) {
+// The block lengths are chosen too: block 0 (the expansion block) may be longer than the others.
+int gm_pg_plan(int64_t n_db, int64_t n_q, int L, int k, double p_match, int max_len, int* expand, int* len0_out) {
     if (expand) *expand = 0;
+    if (len0_out) *len0_out = 0;
     if (max_len > GM_PG_MAXLEN) max_len = GM_PG_MAXLEN;
     if (L < 12 || L > GM_MAX_GUIDELEN || n_db < 32768 || k < 1 || k > 20) return 0;
     if (!(p_match >= 0.25 && p_match < 0.9)) p_match = 0.25;
+    if (n_q < 1) n_q = n_db;
     double best = 0.45;      // K1P has to be clearly cheaper than scanning everything
     int best_B = 0;
     for (int mode = 0; mode < 2; ++mode) {
         for (int B = 2; B <= GM_PG_MAXB; ++B) {
             const int r = mode ? B : B - 1;
-            const int base = L / B, extra = L % B;
-            if (base < 2 || base + (extra ? 1 : 0) > max_len) continue;
-            double work = 0.0;
-            for (int b = 0; b < B; ++b) work += std::pow(p_match, (double)(base + (b < extra ? 1 : 0)));
-            if (mode) {
-                const int len0 = base + (extra ? 1 : 0);
-                work += 3.0 * len0 * std::pow(p_match, (double)(len0 - 1)) * (1.0 - p_match) / 3.0;
-            }
-            const double mean = (double)n_db * tail_within(L, r, p_match);
-            double p_inc = 0.0, term = std::exp(-mean);      // P(Poisson(mean) < k)
-            for (int j = 0; j < k; ++j) {
-                p_inc += term;
-                term *= mean / (j + 1);
-            }
-            if (mean > 700.0) p_inc = 0.0;
-            const double cost = work + (p_inc < 1.0 ? p_inc : 1.0);
-            if (cost < best) {
-                best = cost;
-                best_B = B;
-                if (expand) *expand = mode;
+            const int even = (L + B - 1) / B;
+            // expansion: a longer block 0 (small buckets) against shorter others is usually the better trade
+            for (int len0 = even; len0 <= (mode ? max_len : even); ++len0) {
+                int blen[GM_PG_MAXB];
+                if (!pg_block_lengths(L, B, len0, max_len, blen)) continue;
+                // fraction of the pairs evaluated, with the padding of a bucket's ends to 64 targets / candidates
+                double work = 0.0;
+                for (int b = 0; b < B; ++b) {
+                    const double share = std::pow(p_match, (double)blen[b]);
+                    const double pad = (1.0 + 32.0 / (share * (double)n_db)) * (1.0 + 32.0 / (share * (double)n_q));
+                    double passes = 1.0;
+                    if (mode && b == 0) passes += 3.0 * blen[0] * ((1.0 - p_match) / 3.0) / p_match;
+                    work += share * pad * passes;
+                }
+                const double mean = (double)n_db * tail_within(L, r, p_match);
+                double p_inc = 0.0, term = std::exp(-mean);      // P(Poisson(mean) < k)
+                for (int j = 0; j < k; ++j) {
+                    p_inc += term;
+                    term *= mean / (j + 1);
+                }
+                if (mean > 700.0) p_inc = 0.0;
+                const double cost = work + (p_inc < 1.0 ? p_inc : 1.0);
+                if (cost < best) {
+                    best = cost;
+                    best_B = B;
+                    if (expand) *expand = mode;
+                    if (len0_out) *len0_out = len0;
+                }
             }
         }
     }
@@ -528,21 +554,22 @@ void gm_pg_free(gm_index* idx) {
     idx->pg = nullptr;
 }
 
-int gm_pg_prepare(gm_index* idx, int B, int expand, hipStream_t st) {
-    if (B < 2 || B > GM_PG_MAXB) return gm_fail(GM_ERR_ARG, "gm_pg_prepare: bad block count");
+int gm_pg_prepare(gm_index* idx, int B, int expand, int len0, hipStream_t st) {
+    const int L = idx->L;
+    int blen[GM_PG_MAXB];
+    if (!pg_block_lengths(L, B, len0, GM_PG_MAXLEN, blen)) return gm_fail(GM_ERR_ARG, "gm_pg_prepare: bad layout");
     if (!idx->pg) idx->pg = new gm_pigeon();
     gm_pigeon* pg = idx->pg;
     pg->expand = expand ? 1 : 0;       // same pool copies either way
-    if (pg->B == B) return GM_OK;
+    if (pg->B == B && pg->blen[0] == blen[0]) return GM_OK;
     free_pool_side(pg);
-    const int L = idx->L;
     const int64_t n = idx->n_db;
-    const int base = L / B, extra = L % B;
-    int pos = 0;
+    int pos = 0, base = blen[0];
     pg->ebase[0] = 0;
     for (int b = 0; b < B; ++b) {
         pg->bstart[b] = pos;
-        pg->blen[b] = base + (b < extra ? 1 : 0);
+        pg->blen[b] = blen[b];
+        base = blen[b] < base ? blen[b] : base;      // shortest block
         pos += pg->blen[b];
         pg->ebase[b + 1] = pg->ebase[b] + (1 << (2 * pg->blen[b]));
     }

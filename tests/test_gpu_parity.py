@@ -369,10 +369,12 @@ def test_kernel_variants_agree(oracle):
 
 
 @pytest.mark.parametrize("L,B", [(12, 4), (16, 8), (20, 4), (20, 7), (23, 5), (27, 8),
-                                 (12, 104), (16, 108), (20, 104), (20, 106), (23, 105), (27, 108)])
+                                 (12, 104), (16, 108), (20, 104), (20, 106), (23, 105), (27, 108),
+                                 (12, 204), (16, 206), (20, 206), (23, 205), (27, 208)])
 def test_pigeonhole_layouts_match_oracle(oracle, L, B):
     """K1P, the pigeonhole-partitioned scan, with a forced layout (variant 100 + B; B > 100 here = variant
-    200 + B % 100, the same blocks with the neighbour-bucket expansion).  It must be exact for any block count: candidates whose merged lists do not fill are re-scanned by the plain kernel, so a
+    200 + B % 100, the same blocks with the neighbour-bucket expansion; B > 200 = variant 300 + B % 100, the
+    expansion with block 0 one base longer than the others' even split).  It must be exact for any block count: candidates whose merged lists do not fill are re-scanned by the plain kernel, so a
     small pool with planted near-duplicates exercises the bucket scan, the duplicate-dropping merge and the
     re-scan.  The skewed base composition gives crowded and empty buckets."""
     rng = random.Random(1000 * L + B)

@@ -164,20 +164,22 @@ def test_neighbor_map_schema_and_duplicates():
 
 def test_pigeonhole_planner_choices():
     """gm_pigeon_plan is host arithmetic: runs without a GPU.  Layouts for the BASELINE shapes (100 + B = B
-    blocks with the neighbour-bucket expansion), and the cases where the plain scan must stay in charge."""
+    blocks with the neighbour-bucket expansion, 1000 * len0 = block 0 longer than the even split), and the
+    cases where the plain scan must stay in charge."""
     from guidemaker_amd import _lib
-    assert _lib.pigeon_plan(599_093, 20, 10) == 106        # S1: blocks 4,4,3,3,3,3 + neighbours of block 0
-    assert _lib.pigeon_plan(3_124_711, 20, 20) == 106      # S4
-    assert _lib.pigeon_plan(891_135, 20, 5, 0.2637) == 106 # S3 (gc 0.383)
+    assert _lib.pigeon_plan(599_093, 20, 10) == 5106        # S1: blocks 5,3,3,3,3,3 + 15 neighbours of block 0
+    assert _lib.pigeon_plan(3_124_711, 20, 20) == 5106      # S4
+    assert _lib.pigeon_plan(891_135, 20, 5, 0.2637) == 5106 # S3 (gc 0.383)
     assert _lib.pigeon_plan(3_814, 20, 10) == 0            # Carsonella-sized pool: plain scan
     assert _lib.pigeon_plan(600_000, 20, 21) == 0          # lists beyond the register capacity
     assert _lib.pigeon_plan(600_000, 11, 10) == 0          # too short
     for n in (40_000, 200_000, 1_000_000, 20_000_000):
         for L in range(12, 28):
             for k in (1, 2, 10, 20):
-                B = _lib.pigeon_plan(n, L, k) % 100
-                assert B == 0 or (2 <= B <= 8 and L // B >= 2 and -(-L // B) <= 6), (n, L, k, B)
+                code = _lib.pigeon_plan(n, L, k)
+                B, len0 = code % 100, code // 1000
+                assert code == 0 or (2 <= B <= 8 and len0 <= 6 and (L - max(len0, -(-L // B))) // (B - 1) >= 2), (n, L, k, code)
     # a larger pool never needs a wider radius (radius = B - 1 plain, B with the expansion)
     def radius(code):
-        return code % 100 - (0 if code >= 100 else 1)
+        return code % 100 - (0 if code % 1000 >= 100 else 1)
     assert radius(_lib.pigeon_plan(20_000_000, 20, 10)) <= radius(_lib.pigeon_plan(600_000, 20, 10))
