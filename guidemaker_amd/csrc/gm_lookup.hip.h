@@ -503,7 +503,7 @@ __global__ void k_merge_hits(gm_pg_blocks P, int cap, int cap_x, const uint32_t*
             overflow = true;
             c = lcap;
         }
-        const int32_t* __restrict__ perm = P.perm[own ? l : P.xblock];
+        const int32_t* __restrict__ perm = P.perm[own ? l : (l - P.n_blocks) / P.xne];
         const uint32_t* slot0 =
             hits + (own ? (int64_t)l * cap : (int64_t)P.n_blocks * cap + (int64_t)(l - P.n_blocks) * cap_x) * n_q + qi;
         for (int i = 0; i < c; ++i) {

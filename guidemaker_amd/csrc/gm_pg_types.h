@@ -14,8 +14,9 @@ struct gm_pg_blocks {
     int skip[GM_PG_MAXB];                // copy b's table leaves out sequence positions [skip[b], skip[b] + skip_len)
     int skip_len;
     int n_blocks;                        // B: slot lists 0 .. B-1 have `cap` slots, lists B .. have `cap_x`
-    int xblock;                          // expansion block (-1: none); its copy serves the neighbour lists
-    int n_expand;                        // neighbour lists (3 x length of the expansion block, or 0)
+    int xne;                             // neighbour lists per expansion block (3 x its length); list B + x * xne + e
+                                         // belongs to expansion block x and is served by copy x
+    int n_expand;                        // neighbour lists in total (expansion blocks x xne, or 0)
 };
 
 // one workgroup's work: cn (<= 64) candidates starting at sorted position c0 of block b's candidate order,

@@ -31,8 +31,10 @@ struct PgLayoutArg {              // per-block geometry + offsets, by value
     int ebase[GM_PG_MAXB + 1];    // first entry of block b in the flattened (block, bucket) list
     const int32_t* coff[GM_PG_MAXB];
     const int32_t* toff[GM_PG_MAXB];
-    // expansion: after the ebase[B] (block, bucket) entries come nb(xb) * xne entries (bucket, neighbour)
-    int xb;                       // expansion block, -1 = none
+    // expansion: after the ebase[B] (block, bucket) entries come, for each of the X expansion blocks (blocks
+    // 0 .. X-1, all of the same length), nbx * xne entries (bucket, neighbour)
+    int X;                        // expansion blocks, 0 = none
+    int nbx;                      // buckets of an expansion block
     int xne;                      // neighbours per bucket = 3 x block length
     int xskip;                    // leading block positions the copy's table leaves out
     int n_entries;
@@ -232,14 +234,15 @@ __device__ __forceinline__ PgEntry pg_entry_ex(const PgLayoutArg& A, int e) {
         r.add = 0;
         return r;
     }
-    const int x = e - A.ebase[A.B];
+    const int rem = e - A.ebase[A.B], per = A.nbx * A.xne;
+    const int xb = rem / per, x = rem % per;
     const int v = x / A.xne, ne = x % A.xne;
     const int pidx = ne / 3, alt = ne % 3;
     const int code = (v >> (2 * pidx)) & 3;
-    r.b = A.xb;
+    r.b = xb;
     r.vc = v;
     r.vt = (v & ~(3 << (2 * pidx))) | (((code + 1 + alt) & 3) << (2 * pidx));
-    r.lst = A.B + ne;
+    r.lst = A.B + xb * A.xne + ne;
     r.add = pidx < A.xskip ? 1 : 0;
     return r;
 }
@@ -354,7 +357,8 @@ struct gm_pigeon {
     int B = 0;
     double p_match = 0.0;              // P(two pool sequences carry the same base at a position); 0 = not measured
     int max_bucket[GM_PG_MAXB]{};      // largest bucket of every pool copy
-    int expand = 0;                    // 1: B blocks serve radius r = B through the neighbour buckets of block 0
+    int expand = 0;                    // X: the neighbour buckets of blocks 0 .. X-1 are scanned too, B blocks then
+                                       // serve radius r = B + X - 1
     int cap_x = 0;                     // slots per neighbour list
     int skip_len = 0;                  // positions of its own block each copy's table leaves out
     int Lp = 0;                        // positions the scan evaluates = L - skip_len (>= 10)
@@ -435,19 +439,25 @@ double log_choose(int n, int r) { return std::lgamma(n + 1.0) - std::lgamma(r + 
 
 }  // namespace
 
-// Block lengths of a layout: block 0 has len0 bases, the other B - 1 share the rest as evenly as possible
-// (longer ones first).  len0 = 0 asks for the even split of all B blocks.  false: not a usable layout.
-static bool pg_block_lengths(int L, int B, int len0, int max_len, int (&blen)[GM_PG_MAXB]) {
-    if (B < 2 || B > GM_PG_MAXB) return false;
-    if (len0 <= 0) len0 = (L + B - 1) / B;
-    const int rest = L - len0;
-    if (rest < 2 * (B - 1)) return false;
-    const int base = rest / (B - 1), extra = rest % (B - 1);
-    blen[0] = len0;
-    for (int b = 1; b < B; ++b) blen[b] = base + (b - 1 < extra ? 1 : 0);
+// Block lengths of a layout.  X = 0: the even split of L over B blocks (longer ones first).  X > 0: the X
+// expansion blocks (blocks 0 .. X-1) have lenx bases each, the other B - X share the rest as evenly as
+// possible and are not longer than lenx.  false: not a usable layout.
+static bool pg_block_lengths(int L, int B, int X, int lenx, int max_len, int (&blen)[GM_PG_MAXB]) {
+    if (B < 2 || B > GM_PG_MAXB || X < 0 || X >= B) return false;
+    if (X == 0) {
+        const int base = L / B, extra = L % B;
+        for (int b = 0; b < B; ++b) blen[b] = base + (b < extra ? 1 : 0);
+    } else {
+        const int others = B - X, rest = L - X * lenx;
+        if (rest < 2 * others) return false;
+        const int base = rest / others, extra = rest % others;
+        for (int b = 0; b < X; ++b) blen[b] = lenx;
+        for (int b = X; b < B; ++b) blen[b] = base + (b - X < extra ? 1 : 0);
+        if (blen[X] > lenx) return false;
+    }
     for (int b = 0; b < B; ++b)
         if (blen[b] < 2 || blen[b] > max_len) return false;
-    return len0 >= blen[1];      // block 0 is (one of) the longest: it carries the expansion
+    return true;
 }
 
 // P(at most r mismatches over n positions) when a position matches with probability pm
@@ -459,9 +469,11 @@ static double tail_within(int n, int r, double pm) {
 }
 
 // Layout choice under an independent-base model with the pool's own composition (p_match = sum_b f_b^2).
-// Plain mode: B = r + 1 blocks, every pair within r shares a block.  Expansion mode: B = r blocks -- a pair
-// within r that shares none has exactly one mismatch in EVERY block, so it also sits in one of the 3 x len
-// one-substitution neighbour buckets of the (longest) block 0, which get one extra pass.
+// Plain mode (X = 0): B = r + 1 blocks, every pair within r shares a block.  Expansion (X > 0): B blocks serve
+// r = B + X - 1 -- a pair within r that shares no block has m_b >= 1 mismatches in every block with
+// sum m_b <= r, so at most X - 1 blocks carry two or more and at least one of the X expansion blocks carries
+// exactly one: the pair sits in a one-substitution neighbour bucket of that block (3 x len per bucket), and
+// those buckets get one extra pass each.
 // cost = fraction of the pairs evaluated + P(Poisson(n P(d <= r)) < k) (rows re-scanned); 0 when the plain
 // scan is at least as good.  max_len = longest block the caller can use (buckets must hold enough candidates).
 // The block lengths are chosen too: block 0 (the expansion block) may be longer than the others.
@@ -474,21 +486,21 @@ int gm_pg_plan(int64_t n_db, int64_t n_q, int L, int k, double p_match, int max_
     if (n_q < 1) n_q = n_db;
     double best = 0.45;      // K1P has to be clearly cheaper than scanning everything
     int best_B = 0;
-    for (int mode = 0; mode < 2; ++mode) {
-        for (int B = 2; B <= GM_PG_MAXB; ++B) {
-            const int r = mode ? B : B - 1;
+    for (int X = 0; X <= 3; ++X) {
+        for (int B = X + 1 > 2 ? X + 1 : 2; B <= GM_PG_MAXB; ++B) {
+            const int r = B + X - 1;
             const int even = (L + B - 1) / B;
-            // expansion: a longer block 0 (small buckets) against shorter others is usually the better trade
-            for (int len0 = even; len0 <= (mode ? max_len : even); ++len0) {
+            // longer expansion blocks (small buckets, cheap neighbour passes) against shorter others
+            for (int lenx = even; lenx <= (X ? max_len : even); ++lenx) {
                 int blen[GM_PG_MAXB];
-                if (!pg_block_lengths(L, B, len0, max_len, blen)) continue;
+                if (!pg_block_lengths(L, B, X, lenx, max_len, blen)) continue;
                 // fraction of the pairs evaluated, with the padding of a bucket's ends to 64 targets / candidates
                 double work = 0.0;
                 for (int b = 0; b < B; ++b) {
                     const double share = std::pow(p_match, (double)blen[b]);
                     const double pad = (1.0 + 32.0 / (share * (double)n_db)) * (1.0 + 32.0 / (share * (double)n_q));
                     double passes = 1.0;
-                    if (mode && b == 0) passes += 3.0 * blen[0] * ((1.0 - p_match) / 3.0) / p_match;
+                    if (b < X) passes += 3.0 * blen[b] * ((1.0 - p_match) / 3.0) / p_match;
                     work += share * pad * passes;
                 }
                 const double mean = (double)n_db * tail_within(L, r, p_match);
@@ -502,8 +514,8 @@ int gm_pg_plan(int64_t n_db, int64_t n_q, int L, int k, double p_match, int max_
                 if (cost < best) {
                     best = cost;
                     best_B = B;
-                    if (expand) *expand = mode;
-                    if (len0_out) *len0_out = len0;
+                    if (expand) *expand = X;
+                    if (len0_out) *len0_out = X ? lenx : 0;
                 }
             }
         }
@@ -538,7 +550,7 @@ int gm_pg_pool_stats(gm_index* idx, hipStream_t st, double* p_match) {
 }
 
 int gm_pg_blocks_of(const gm_index* idx) { return idx->pg ? idx->pg->B : 0; }
-int gm_pg_radius(const gm_index* idx) { return idx->pg ? (idx->pg->expand ? idx->pg->B : idx->pg->B - 1) : 0; }
+int gm_pg_radius(const gm_index* idx) { return idx->pg ? idx->pg->B + idx->pg->expand - 1 : 0; }
 
 void gm_pg_free(gm_index* idx) {
     gm_pigeon* pg = idx->pg;
@@ -557,11 +569,13 @@ void gm_pg_free(gm_index* idx) {
 int gm_pg_prepare(gm_index* idx, int B, int expand, int len0, hipStream_t st) {
     const int L = idx->L;
     int blen[GM_PG_MAXB];
-    if (!pg_block_lengths(L, B, len0, GM_PG_MAXLEN, blen)) return gm_fail(GM_ERR_ARG, "gm_pg_prepare: bad layout");
+    if (!pg_block_lengths(L, B, expand, len0, GM_PG_MAXLEN, blen)) return gm_fail(GM_ERR_ARG, "gm_pg_prepare: bad layout");
     if (!idx->pg) idx->pg = new gm_pigeon();
     gm_pigeon* pg = idx->pg;
-    pg->expand = expand ? 1 : 0;       // same pool copies either way
-    if (pg->B == B && pg->blen[0] == blen[0]) return GM_OK;
+    pg->expand = expand;
+    bool same = pg->B == B;
+    for (int b = 0; b < B && same; ++b) same = pg->blen[b] == blen[b];
+    if (same) return GM_OK;            // the pool copies depend on the block lengths only
     free_pool_side(pg);
     const int64_t n = idx->n_db;
     int pos = 0, base = blen[0];
@@ -659,13 +673,13 @@ int gm_pg_candidates(gm_index* idx, int64_t n_q, hipStream_t st) {
     hipLaunchKernelGGL(k_cand_offsets, dim3(pg->B), dim3(1024), 0, st, K, pg->hist, pg->cursor);
     hipLaunchKernelGGL(k_cand_scatter, grid_for(n_q, 1024), dim3(1024), lds, st, idx->d_q, n_q, K, pg->cursor, use_lds);
     HIP_TRY(hipGetLastError());
-    // chunk table: the own-bucket entries of every block, plus (expansion) the neighbour buckets of block 0
-    A.xb = pg->expand ? 0 : -1;
-    A.xne = pg->expand ? 3 * pg->blen[0] : 0;
+    // chunk table: the own-bucket entries of every block, plus the neighbour buckets of the expansion blocks
+    A.X = pg->expand;
+    A.xne = pg->expand ? 3 * pg->blen[0] : 1;
+    A.nbx = 1 << (2 * pg->blen[0]);
     A.xskip = pg->skip_len;
-    const int nb0 = 1 << (2 * pg->blen[0]);
-    A.n_entries = n_entries + (pg->expand ? nb0 * A.xne : 0);
-    if (pg->expand) grid += (int64_t)A.xne * ((n_q + 63) / 64 + nb0);
+    A.n_entries = n_entries + pg->expand * A.nbx * A.xne;
+    grid += (int64_t)pg->expand * A.xne * ((n_q + 63) / 64 + A.nbx);
     if ((rc = ensure(&pg->nch, &pg->nch_cap, A.n_entries, "chunk counts"))) return rc;
     if ((rc = ensure(&pg->cbase, &pg->cbase_cap, A.n_entries, "chunk offsets"))) return rc;
     if ((rc = ensure(&pg->chunks, &pg->chunks_cap, grid, "chunk table"))) return rc;
@@ -684,7 +698,7 @@ int gm_pg_candidates(gm_index* idx, int64_t n_q, hipStream_t st) {
 // the expansion pass, where the pair already has one mismatch: >= 8).  A list that still overflows (repeat
 // families) only makes its row incomplete: the row is re-scanned by the plain kernel.
 static void pg_slot_capacity(const gm_index* idx, gm_pigeon* pg, int64_t n_q) {
-    const int L = idx->L, r = pg->expand ? pg->B : pg->B - 1;
+    const int L = idx->L, r = pg->B + pg->expand - 1;
     const double pm = pg->p_match >= 0.25 ? pg->p_match : 0.25;
     double worst = 0.0;
     for (int b = 0; b < pg->B; ++b) {
@@ -695,9 +709,11 @@ static void pg_slot_capacity(const gm_index* idx, gm_pigeon* pg, int64_t n_q) {
     if (cap < 16.0) cap = 16.0;
     if (cap > 1024.0) cap = 1024.0;
     double cap_x = 0.0;
-    const int n_x = pg->expand ? 3 * pg->blen[0] : 0;
+    const int n_x = pg->expand * 3 * pg->blen[0];
     if (pg->expand) {
-        const double h = (double)pg->max_bucket[0] * tail_within(L - pg->blen[0], r - 1, pm);
+        int mx = 0;
+        for (int b = 0; b < pg->expand; ++b) mx = pg->max_bucket[b] > mx ? pg->max_bucket[b] : mx;
+        const double h = (double)mx * tail_within(L - pg->blen[0], r - 1, pm);
         cap_x = std::ceil(1.25 * (h + 6.0 * std::sqrt(h)) + 8.0);
         if (cap_x > 512.0) cap_x = 512.0;
     }
@@ -717,7 +733,7 @@ int gm_pg_scan(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
     gm_pigeon* pg = idx->pg;
     int rc;
     pg_slot_capacity(idx, pg, n_q);
-    const int n_x = pg->expand ? 3 * pg->blen[0] : 0;
+    const int n_x = pg->expand * 3 * pg->blen[0];
     if ((rc = ensure(&pg->keys, &pg->keys_cap, ((int64_t)pg->B * pg->cap + (int64_t)n_x * pg->cap_x) * n_q,
                      "K1P slot lists")))
         return rc;
@@ -734,9 +750,9 @@ int gm_pg_scan(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
     }
     blocks.skip_len = pg->skip_len;
     blocks.n_blocks = pg->B;
-    blocks.xblock = pg->expand ? 0 : -1;
+    blocks.xne = pg->expand ? 3 * pg->blen[0] : 1;
     blocks.n_expand = n_x;
-    const int thr0 = pg->expand ? pg->B + 1 : pg->B;      // accept d < thr0, i.e. d <= r
+    const int thr0 = pg->B + pg->expand;      // accept d < thr0, i.e. d <= r = B + X - 1
     switch (pg->Lp) {            // the kernel instantiated for the positions actually evaluated
 #define GM_CASE(LEN) \
     case LEN: return gm_launch_pg_L##LEN(idx, &blocks, pg->chunks, &pg->ctr->n_chunks, pg->grid, n_q, k, thr0, pg->cap, pg->cap_x, pg->keys, pg->n_hits, st);

@@ -258,12 +258,12 @@ int run_hamming_pigeon(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
     *used = false;
     const int keff = nearest ? 1 : k;
     if (keff > 20 || idx->n_db < keff || n_q < 1) return GM_OK;
-    // variants 102..108 force a layout of 2..8 blocks, 202..208 the same with the neighbour-bucket expansion,
-    // 302..308 the expansion with block 0 one base longer than the even split (tests, A/B); the result is exact
-    // for any layout
-    const bool forced_u = idx->variant >= 302 && idx->variant <= 300 + GM_PG_MAXB;
-    const bool forced_x = forced_u || (idx->variant >= 202 && idx->variant <= 200 + GM_PG_MAXB);
-    const bool forced = forced_x || (idx->variant >= 102 && idx->variant <= 100 + GM_PG_MAXB);
+    // variants 100 + B force the plain layout of B blocks; 200 + B one expansion block (even lengths), 300 + B
+    // the same with the expansion block one base longer, 400 + B / 500 + B two / three expansion blocks one
+    // base longer than the even split, 600 + B / 700 + B two / three expansion blocks of even length (tests,
+    // A/B); the result is exact for any layout
+    const int vcode = idx->variant / 100;
+    const bool forced = vcode >= 1 && vcode <= 7 && idx->variant % 100 >= 2 && idx->variant % 100 <= GM_PG_MAXB;
     int rc;
     double p_match = 0.25;
     if (idx->n_db >= 32768 || forced) {
@@ -273,15 +273,23 @@ int run_hamming_pigeon(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
     // (measured break-even on a 600k pool: ~10k candidates for 3-base blocks)
     int len_ok = 0;
     while (len_ok < GM_PG_MAXLEN && n_q >= ((int64_t)160 << (2 * (len_ok + 1)))) ++len_ok;
-    int expand = forced_x ? 1 : 0, len0 = 0;
-    const int B = forced ? idx->variant % 100
-                         : gm_pg_plan(idx->n_db, n_q, idx->L, keff, p_match, len_ok, &expand, &len0);
-    if (B == 0 || idx->L / B < 1) return GM_OK;
+    int expand = 0, len0 = 0;
+    int B = 0;
     if (forced) {
-        len0 = (idx->L + B - 1) / B + (forced_u ? 1 : 0);
-        if (len0 > GM_PG_MAXLEN || idx->L - len0 < 2 * (B - 1)) return GM_OK;      // not a usable layout
+        B = idx->variant % 100;
+        expand = vcode == 1 ? 0 : (vcode <= 3 ? 1 : (vcode <= 5 ? vcode - 2 : vcode - 4));
+        len0 = (idx->L + B - 1) / B + (vcode >= 3 && vcode <= 5 ? 1 : 0);
+        if (expand >= B || len0 > GM_PG_MAXLEN) return GM_OK;      // not a usable layout: plain scan
+        if (expand > 0 && idx->L - expand * len0 < 2 * (B - expand)) return GM_OK;
+        if (idx->L / B < 2 && expand == 0) return GM_OK;
+    } else {
+        B = gm_pg_plan(idx->n_db, n_q, idx->L, keff, p_match, len_ok, &expand, &len0);
     }
-    if ((rc = gm_pg_prepare(idx, B, expand, len0, st))) return rc;
+    if (B == 0) return GM_OK;
+    if ((rc = gm_pg_prepare(idx, B, expand, len0, st))) {
+        if (forced && rc == GM_ERR_ARG) return GM_OK;      // forced layout not usable for this length
+        return rc;
+    }
     if ((rc = gm_pg_candidates(idx, n_q, st))) return rc;
     const int kcap = nearest ? 1 : (k <= 5 ? 5 : (k <= 10 ? 10 : 20));
     if ((rc = timing_begin(idx, st))) return rc;
@@ -320,7 +328,7 @@ int run_hamming_pigeon(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
 
 // variant 0 = default (K1L look-up kernel), 1 = popcount kernel K1, 5 and 2x/3x = K1v knobs
 bool use_lookup(const gm_index* idx) {
-    return idx->metric == GM_METRIC_HAMMING && idx->d_onehot != nullptr && (idx->variant == 0 || idx->variant == 7 || idx->variant == 8 || idx->variant == 9 || (idx->variant >= 40 && idx->variant < 100) || (idx->variant >= 102 && idx->variant <= 100 + GM_PG_MAXB) || (idx->variant >= 202 && idx->variant <= 200 + GM_PG_MAXB) || (idx->variant >= 302 && idx->variant <= 300 + GM_PG_MAXB));
+    return idx->metric == GM_METRIC_HAMMING && idx->d_onehot != nullptr && (idx->variant == 0 || idx->variant == 7 || idx->variant == 8 || idx->variant == 9 || (idx->variant >= 40 && idx->variant < 100) || (idx->variant >= 102 && idx->variant < 800 && idx->variant % 100 >= 2 && idx->variant % 100 <= GM_PG_MAXB));
 }
 
 bool use_bitslice(const gm_index* idx) {
@@ -843,7 +851,7 @@ int gm_pigeon_plan(int64_t n_db, int guidelen, int k, double p_match) {
     int len0 = 0;
     const int B = gm_pg_plan(n_db, n_db, guidelen, k, p_match, GM_PG_MAXLEN, &expand, &len0);
     if (!B) return 0;
-    return B + 100 * expand + (len0 != (guidelen + B - 1) / B ? 1000 * len0 : 0);
+    return B + 100 * expand + (expand && len0 != (guidelen + B - 1) / B ? 1000 * len0 : 0);
 }
 
 }  // extern "C"

@@ -145,9 +145,9 @@ int64_t gm_last_incomplete(gm_index* idx);
 int gm_pigeon_blocks(gm_index* idx);
 /* The layout planner on its own (host arithmetic only, no device needed): number of blocks B K1P would use for
  * a pool of n_db targets of this length, k neighbours and base-match probability p_match (sum of squared base
- * frequencies; 0.25 = uniform), assuming as many candidates as targets; + 100 when the layout uses the
- * neighbour-bucket expansion (B blocks serving radius B); + 1000 * len0 when block 0 is longer than the even
- * split (len0 bases); 0 when the plain scan is the better choice. */
+ * frequencies; 0.25 = uniform), assuming as many candidates as targets; + 100 * X when X blocks get the
+ * neighbour-bucket expansion (B blocks then serve radius B + X - 1); + 1000 * len when those blocks are longer
+ * than the even split (len bases each); 0 when the plain scan is the better choice. */
 int gm_pigeon_plan(int64_t n_db, int guidelen, int k, double p_match);
 
 /* Per-launch timing history: gm_timing_reserve(idx, n) arms n HIP-event pairs (and resets the

@@ -368,15 +368,19 @@ def test_kernel_variants_agree(oracle):
     idx.close()
 
 
-@pytest.mark.parametrize("L,B", [(12, 4), (16, 8), (20, 4), (20, 7), (23, 5), (27, 8),
-                                 (12, 104), (16, 108), (20, 104), (20, 106), (23, 105), (27, 108),
-                                 (12, 204), (16, 206), (20, 206), (23, 205), (27, 208)])
-def test_pigeonhole_layouts_match_oracle(oracle, L, B):
-    """K1P, the pigeonhole-partitioned scan, with a forced layout (variant 100 + B; B > 100 here = variant
-    200 + B % 100, the same blocks with the neighbour-bucket expansion; B > 200 = variant 300 + B % 100, the
-    expansion with block 0 one base longer than the others' even split).  It must be exact for any block count: candidates whose merged lists do not fill are re-scanned by the plain kernel, so a
-    small pool with planted near-duplicates exercises the bucket scan, the duplicate-dropping merge and the
-    re-scan.  The skewed base composition gives crowded and empty buckets."""
+@pytest.mark.parametrize("L,variant", [
+    (12, 104), (16, 108), (20, 104), (20, 107), (23, 105), (27, 108),      # plain: B blocks, radius B - 1
+    (12, 204), (16, 208), (20, 204), (20, 206), (23, 205), (27, 208),      # one expansion block, even lengths
+    (12, 304), (16, 306), (20, 306), (23, 305), (27, 308),                 # ... one base longer
+    (16, 406), (20, 405), (23, 405), (20, 504), (27, 507),                 # two / three longer expansion blocks
+    (20, 605), (20, 704), (24, 706)])                                      # two / three, even lengths
+def test_pigeonhole_layouts_match_oracle(oracle, L, variant):
+    """K1P, the pigeonhole-partitioned scan, with a forced layout (gm_set_variant codes of
+    run_hamming_pigeon: 100 + B plain, 200..700 + B with one to three expansion blocks).  It must be exact
+    for any layout: candidates whose merged lists do not fill are re-scanned by the plain kernel, so a
+    small pool with planted near-duplicates exercises the bucket scans, the neighbour-bucket passes, the
+    duplicate-dropping merge and the re-scan.  The skewed base composition gives crowded and empty buckets."""
+    B = variant
     rng = random.Random(1000 * L + B)
     skew = "AAAAACCGT"
     db = ["".join(rng.choice(skew) for _ in range(L)) for _ in range(5000)]
@@ -389,7 +393,7 @@ def test_pigeonhole_layouts_match_oracle(oracle, L, B):
     rng.shuffle(db)
     q = db[::2] + ["".join(rng.choice("ACGT") for _ in range(L)) for _ in range(700)] + db[:5]
     idx = _lib.Index(_lib.pack(db, L), L, _lib.METRIC_HAMMING)
-    idx.set_variant(100 + B)
+    idx.set_variant(variant)
     qp = _lib.pack(q, L)
     for k in (2, 5, 10, 20):
         ids, dists, counts = idx.knn(qp, k)

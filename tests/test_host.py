@@ -163,13 +163,13 @@ def test_neighbor_map_schema_and_duplicates():
 
 
 def test_pigeonhole_planner_choices():
-    """gm_pigeon_plan is host arithmetic: runs without a GPU.  Layouts for the BASELINE shapes (100 + B = B
-    blocks with the neighbour-bucket expansion, 1000 * len0 = block 0 longer than the even split), and the
-    cases where the plain scan must stay in charge."""
+    """gm_pigeon_plan is host arithmetic: runs without a GPU.  Layouts for the BASELINE shapes (B + 100 X: B
+    blocks, X of them with the neighbour-bucket expansion; + 1000 len: those blocks longer than the even split),
+    and the cases where the plain scan must stay in charge."""
     from guidemaker_amd import _lib
-    assert _lib.pigeon_plan(599_093, 20, 10) == 5106        # S1: blocks 5,3,3,3,3,3 + 15 neighbours of block 0
-    assert _lib.pigeon_plan(3_124_711, 20, 20) == 5106      # S4
-    assert _lib.pigeon_plan(891_135, 20, 5, 0.2637) == 5106 # S3 (gc 0.383)
+    assert _lib.pigeon_plan(599_093, 20, 10) == 304         # S1: blocks 5,5,5,5, neighbour buckets of three of them
+    assert _lib.pigeon_plan(3_124_711, 20, 20) == 304       # S4
+    assert _lib.pigeon_plan(891_135, 20, 5, 0.2637) == 304  # S3 (gc 0.383)
     assert _lib.pigeon_plan(3_814, 20, 10) == 0            # Carsonella-sized pool: plain scan
     assert _lib.pigeon_plan(600_000, 20, 21) == 0          # lists beyond the register capacity
     assert _lib.pigeon_plan(600_000, 11, 10) == 0          # too short
@@ -177,9 +177,9 @@ def test_pigeonhole_planner_choices():
         for L in range(12, 28):
             for k in (1, 2, 10, 20):
                 code = _lib.pigeon_plan(n, L, k)
-                B, len0 = code % 100, code // 1000
-                assert code == 0 or (2 <= B <= 8 and len0 <= 6 and (L - max(len0, -(-L // B))) // (B - 1) >= 2), (n, L, k, code)
+                B, X, lenx = code % 100, code % 1000 // 100, code // 1000
+                assert code == 0 or (2 <= B <= 8 and X < B and X <= 3 and lenx <= 6), (n, L, k, code)
     # a larger pool never needs a wider radius (radius = B - 1 plain, B with the expansion)
     def radius(code):
-        return code % 100 - (0 if code % 1000 >= 100 else 1)
+        return code % 100 + code % 1000 // 100 - 1
     assert radius(_lib.pigeon_plan(20_000_000, 20, 10)) <= radius(_lib.pigeon_plan(600_000, 20, 10))
