@@ -485,22 +485,30 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
 
 // K1P merge: one thread per candidate folds its slot lists into the top k (duplicates taken once).
 // A slot list that overflowed makes the row incomplete (count 0 / distance -1): the host re-scans it.
+constexpr int PG_MERGE_SPLIT = 4;      // threads per candidate in k_merge_hits
+
+// FOUR adjacent lanes per candidate, each folding every fourth slot list into its own register list (the
+// kernel is bound by the count -> key -> permutation load chains, so shorter chains on more lanes pay), then
+// lane 0 of the quad takes the other three lists over by shuffles and writes the row.
 template <int KCAP>
 __global__ void k_merge_hits(gm_pg_blocks P, int cap, int cap_x, const uint32_t* __restrict__ hits,
                              const int32_t* __restrict__ n_hits, int64_t n_q, int k, int32_t* __restrict__ ids,
                              int32_t* __restrict__ dists, int32_t* __restrict__ counts, int nearest) {
-    const int64_t qi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (qi >= n_q) return;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int sub = (int)(t % PG_MERGE_SPLIT);
+    const int64_t qi_raw = t / PG_MERGE_SPLIT;
+    const bool valid = qi_raw < n_q;
+    const int64_t qi = valid ? qi_raw : n_q - 1;      // (whole quads stay in the shuffles)
     RegList<KCAP> list;
     list.init(k, nullptr, 0);
-    bool overflow = false;
+    int overflow = 0;
     const int n_lists = P.n_blocks + P.n_expand;
-    for (int l = 0; l < n_lists; ++l) {
+    for (int l = sub; l < n_lists; l += PG_MERGE_SPLIT) {
         const bool own = l < P.n_blocks;
         const int lcap = own ? cap : cap_x;
         int c = n_hits[(int64_t)l * n_q + qi];
         if (c > lcap) {
-            overflow = true;
+            overflow = 1;
             c = lcap;
         }
         const int32_t* __restrict__ perm = P.perm[own ? l : (l - P.n_blocks) / P.xne];
@@ -511,6 +519,17 @@ __global__ void k_merge_hits(gm_pg_blocks P, int cap, int cap_x, const uint32_t*
             list.insert_unique((key & ~ID_MASK) | (uint32_t)perm[key & ID_MASK]);
         }
     }
+    // quad reduction: lane 0 of the quad inserts the entries of lanes 1..3
+#pragma unroll
+    for (int s = 1; s < PG_MERGE_SPLIT; ++s) {
+        overflow |= __shfl_down(overflow, s, PG_MERGE_SPLIT);
+#pragma unroll
+        for (int i = 0; i < KCAP; ++i) {
+            const uint32_t v = __shfl_down(list.v[i], s, PG_MERGE_SPLIT);
+            if (sub == 0 && v != 0u && v != RegList<KCAP>::EMPTY) list.insert_unique(v - 1u);
+        }
+    }
+    if (sub != 0 || !valid) return;
     if (overflow) list.init(k, nullptr, 0);
     list.store(k, qi, ids, dists, counts, nearest != 0);
 }

@@ -21,6 +21,7 @@
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include "gm_lookup.hip.h"      // k_to_onehot, tile geometry
 
@@ -257,28 +258,9 @@ __global__ __launch_bounds__(256) void k_chunk_count(PgLayoutArg A, int* __restr
     nch[e] = tgt > 0 ? (cnt + 63) / 64 : 0;
 }
 
-// exclusive scan of n ints by ONE workgroup; total -> *total
-__global__ __launch_bounds__(1024) void k_scan_excl(const int* __restrict__ in, int n, int* __restrict__ out,
-                                                    int* __restrict__ total) {
-    __shared__ int s[1024];
-    const int per = (n + 1023) / 1024;
-    const int lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
-    int sum = 0;
-    for (int i = lo; i < hi; ++i) sum += in[i];
-    s[threadIdx.x] = sum;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        const int v = threadIdx.x >= d ? s[threadIdx.x - d] : 0;
-        __syncthreads();
-        s[threadIdx.x] += v;
-        __syncthreads();
-    }
-    int run = threadIdx.x ? s[threadIdx.x - 1] : 0;
-    for (int i = lo; i < hi; ++i) {
-        out[i] = run;
-        run += in[i];
-    }
-    if (threadIdx.x == 1023) *total = s[1023];
+// n_chunks = last exclusive offset + last count
+__global__ void k_chunk_total(const int* __restrict__ nch, const int* __restrict__ cbase, int n, int* __restrict__ total) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *total = n > 0 ? cbase[n - 1] + nch[n - 1] : 0;
 }
 
 __global__ __launch_bounds__(256) void k_fill_chunks(PgLayoutArg A, const int* __restrict__ cbase, int n_tiles,
@@ -685,7 +667,21 @@ int gm_pg_candidates(gm_index* idx, int64_t n_q, hipStream_t st) {
     if ((rc = ensure(&pg->chunks, &pg->chunks_cap, grid, "chunk table"))) return rc;
     HIP_TRY(hipMemsetAsync(pg->ctr, 0, sizeof(PgCounters), st));
     hipLaunchKernelGGL(k_chunk_count, grid_for(A.n_entries), dim3(256), 0, st, A, pg->nch);
-    hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, st, pg->nch, A.n_entries, pg->cbase, &pg->ctr->n_chunks);
+    {      // exclusive scan of the per-entry chunk counts (rocPRIM; up to ~50k entries)
+        size_t bytes = 0;
+        HIP_TRY(rocprim::exclusive_scan(nullptr, bytes, pg->nch, pg->cbase, 0, (size_t)A.n_entries, rocprim::plus<int>(), st));
+        if (bytes > pg->sort_tmp_cap || pg->sort_tmp == nullptr) {
+            if (pg->sort_tmp) (void)hipFree(pg->sort_tmp);
+            pg->sort_tmp = nullptr;
+            pg->sort_tmp_cap = 0;
+            if (hipMalloc(&pg->sort_tmp, bytes ? bytes : 1) != hipSuccess)
+                return gm_fail(GM_ERR_ALLOC, "hipMalloc(scan workspace) failed");
+            pg->sort_tmp_cap = bytes;
+        }
+        HIP_TRY(rocprim::exclusive_scan(pg->sort_tmp, bytes, pg->nch, pg->cbase, 0, (size_t)A.n_entries,
+                                        rocprim::plus<int>(), st));
+        hipLaunchKernelGGL(k_chunk_total, dim3(1), dim3(64), 0, st, pg->nch, pg->cbase, A.n_entries, &pg->ctr->n_chunks);
+    }
     hipLaunchKernelGGL(k_fill_chunks, grid_for(A.n_entries), dim3(256), 0, st, A, pg->cbase, (int)idx->n_lk_tiles,
                        pg->chunks, pg->ctr);
     HIP_TRY(hipGetLastError());
@@ -765,7 +761,7 @@ int gm_pg_scan(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
 int gm_pg_merge(gm_index* idx, int kcap, int64_t n_q, int k, int32_t* ids, int32_t* dists, int32_t* counts,
                 bool nearest, hipStream_t st) {
     gm_pigeon* pg = idx->pg;
-    const dim3 grid = grid_for(n_q), block(256);
+    const dim3 grid = grid_for(n_q * gm::PG_MERGE_SPLIT), block(256);
     const int nr = nearest ? 1 : 0;
     switch (kcap) {
         case 1: hipLaunchKernelGGL(gm::k_merge_hits<1>, grid, block, 0, st, pg->blocks, pg->cap, pg->cap_x, pg->keys, pg->n_hits, n_q, k, ids, dists, counts, nr); break;
