@@ -480,7 +480,7 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
             pg_process_group<L>(r, g * LK_GROUP, lo, hi, k, thr0, add, my_cap, n_q, wp, cnt, cnt_lt, thr, Tb);
         }
     }
-    if (valid) n_hits[(int64_t)ch.lst * n_q + qi] = cnt;
+    if (valid && cnt > 0) n_hits[(int64_t)ch.lst * n_q + qi] = cnt;      // (the counts are zeroed before the launch)
 }
 
 // K1P merge: one thread per candidate folds its slot lists into the top k (duplicates taken once).
