@@ -110,8 +110,20 @@ int ensure_u32(uint32_t** buf, int64_t* cap, int64_t need) {
 
 int launch_merge(int kcap, const uint32_t* keys, int n_seg, int64_t n_q, int k, int32_t* ids, int32_t* dists,
                  int32_t* counts, bool nearest, hipStream_t st) {
-    const dim3 grid((unsigned)((n_q + 255) / 256)), block(256);
     const int nr = nearest ? 1 : 0;
+    if (n_seg >= 16 && n_q <= 65536) {      // few candidates, many lists: 16 lanes per candidate
+        constexpr int SP = 16;
+        const dim3 grid((unsigned)((n_q * SP + 255) / 256)), block(256);
+        switch (kcap) {
+            case 1: hipLaunchKernelGGL((gm::k_merge_lists_split<1, SP>), grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
+            case 5: hipLaunchKernelGGL((gm::k_merge_lists_split<5, SP>), grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
+            case 10: hipLaunchKernelGGL((gm::k_merge_lists_split<10, SP>), grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
+            default: hipLaunchKernelGGL((gm::k_merge_lists_split<20, SP>), grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
+        }
+        HIP_TRY(hipGetLastError());
+        return GM_OK;
+    }
+    const dim3 grid((unsigned)((n_q + 255) / 256)), block(256);
     switch (kcap) {
         case 1: hipLaunchKernelGGL(gm::k_merge_lists<1>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
         case 5: hipLaunchKernelGGL(gm::k_merge_lists<5>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
@@ -155,7 +167,7 @@ int run_hamming_lookup(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
     if (n_seg > n_tiles / 2) n_seg = n_tiles / 2;
     // the merge is one thread per candidate walking n_seg lists: with few candidates it is the serial part,
     // so long lists get fewer segments (5 000 candidates, k = 10: 512 segments merged in 1.2 ms, 64 in 0.1 ms)
-    const int64_t seg_cap = a.kcap == 1 ? 512 : (a.kcap == 5 ? 128 : 64);
+    const int64_t seg_cap = a.kcap == 1 ? 512 : (a.kcap == 5 ? 128 : 64);      // (lists x keys the merge walks)
     if (n_seg > seg_cap) n_seg = seg_cap;
     if (idx->variant >= 50 && idx->variant < 100) n_seg = idx->variant - 50;     // A/B knob: force the segment count
     int rc;
