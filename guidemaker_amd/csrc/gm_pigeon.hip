@@ -1,20 +1,21 @@
-// gm_pigeon.hip -- host side of K1P, the pigeonhole-partitioned Hamming scan (kernel: k_hamming_knn_pg in
-// gm_lookup.hip.h).  Exact k-NN without evaluating all pairs:
+// gm_pigeon.hip -- host side of K1P, the pigeonhole-partitioned Hamming scan (kernels: k_hamming_scan_pg and
+// k_merge_hits in gm_lookup.hip.h).  Exact k-NN without evaluating all pairs:
 //
-//   two sequences with at most r mismatches agree exactly on at least one of B = r + 1 disjoint blocks of
-//   positions, so the neighbours of a candidate within distance r all sit in the B buckets "same bases on
-//   block b".  Pool side (once per index and layout): for every block a stable sort of the pool by the
-//   block's value (ids ascend inside a bucket -> the kernels' strict test keeps the canonical (distance, id)
-//   order), the permutation, the bucket offsets and a one-hot table of the sorted copy.  Query side: the
-//   candidates are sorted by the same value and cut into chunks of <= 64 that do not straddle buckets; one
-//   workgroup scans one chunk against its bucket; B lists per candidate are merged (duplicates dropped).
-//   Work: sum_b 4^-len(b) of all pairs (15.6 % for L = 20, B = 7).
+//   two sequences with at most r mismatches agree exactly on at least one of r + 1 disjoint blocks of
+//   positions; with the one-substitution neighbour buckets of X of the blocks scanned as well, B blocks
+//   serve r = B + X - 1 (see gm_pg_plan).  Pool side (once per index and layout): for every block a stable
+//   sort of the pool by the block's value (ids ascend inside a bucket -> the kernels' strict test keeps the
+//   canonical (distance, id) order), the permutation, the bucket offsets and a one-hot table of the sorted
+//   copy.  Query side: the candidates are grouped by the same values and cut into chunks of <= 64 that do not
+//   straddle buckets; one workgroup scans one chunk against one bucket (its own, or a neighbour bucket of an
+//   expansion block) and appends its hits to the candidate's slot list; the lists of a candidate are merged
+//   (duplicates dropped).  Work on S1: 5.6 % of all pairs (L = 20, blocks 5,5,5,5, three of them expanded).
 //   A candidate whose merged list is full is exact: every target within r was enumerated.  The rest (the
 //   layout is chosen so that they are few) are re-scanned by the plain two-phase kernel (gmhip.hip).
 //
 // Everything here is integer bookkeeping on the device: block keys, a stable rocPRIM sort per pool copy, one
-// counting sort of the candidates for all blocks, a chunk table built by a count / scan / fill triple.  No host round trip except the one
-// read-back of the incomplete-row count.
+// counting sort of the candidates for all blocks, a chunk table built by a count / scan / fill triple.  No
+// host round trip except the read-backs of the incomplete-row counts.
 #include "gm_host.h"
 
 #include <cmath>
