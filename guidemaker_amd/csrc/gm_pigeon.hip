@@ -370,6 +370,8 @@ struct gm_pigeon {
     int32_t* n_hits = nullptr;    // [B][n_q]
     int64_t n_hits_cap = 0;
     int cap = 0;
+    int64_t cap_nq = -1;          // candidate count / expansion the capacities were sized for
+    int cap_x_for = -1;
     gm_pg_blocks blocks{};
     int32_t* inc = nullptr;
     int64_t inc_cap = 0;
@@ -416,6 +418,7 @@ void free_pool_side(gm_pigeon* pg) {
         pg->coff[b] = nullptr;
     }
     pg->B = 0;
+    pg->cap = 0;
 }
 
 double log_choose(int n, int r) { return std::lgamma(n + 1.0) - std::lgamma(r + 1.0) - std::lgamma(n - r + 1.0); }
@@ -729,7 +732,11 @@ static void pg_slot_capacity(const gm_index* idx, gm_pigeon* pg, int64_t n_q) {
 int gm_pg_scan(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
     gm_pigeon* pg = idx->pg;
     int rc;
-    pg_slot_capacity(idx, pg, n_q);
+    if (pg->cap == 0 || pg->cap_nq != n_q || pg->cap_x_for != pg->expand) {      // (hipMemGetInfo is not free)
+        pg_slot_capacity(idx, pg, n_q);
+        pg->cap_nq = n_q;
+        pg->cap_x_for = pg->expand;
+    }
     const int n_x = pg->expand * 3 * pg->blen[0];
     if ((rc = ensure(&pg->keys, &pg->keys_cap, ((int64_t)pg->B * pg->cap + (int64_t)n_x * pg->cap_x) * n_q,
                      "K1P slot lists")))
