@@ -111,7 +111,7 @@ __device__ __forceinline__ void lvb_eval_half(uint32_t (&adr)[L], uint32_t (&c)[
 // Dynamic LDS: 2 tiles.  seed_*: Hamming k-NN of the same candidates (lev <= hamming).
 // keys: [n_seg][n_q][KCAP] raw RegList contents, folded by k_merge_lists.
 template <int L, int KCAP>
-__global__ __launch_bounds__(WAVE) void k_leven_knn_bs(const uint32_t* __restrict__ table, int n_db, int n_tiles,
+__global__ __launch_bounds__(WAVE, (L <= 23 ? 4 : 3)) void k_leven_knn_bs(const uint32_t* __restrict__ table, int n_db, int n_tiles,
                                                        int tiles_per_seg, const uint2* __restrict__ q,
                                                        int64_t n_q, int k, const int32_t* __restrict__ seed_dists,
                                                        const int32_t* __restrict__ seed_counts, int seed_k,
