@@ -24,9 +24,19 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--nearest", action="store_true")
     ap.add_argument("--check", action="store_true", help="compare every variant's output with variant 0")
+    ap.add_argument("--planted", type=float, default=0.0,
+                    help="fraction of pool entries replaced by near-duplicates (1-3 substitutions) of others")
     a = ap.parse_args()
     rng = np.random.default_rng(5)
-    db = np.unique(core.pack_codes(rng.integers(0, 4, size=(a.n, a.L), dtype=np.uint8)))
+    codes = rng.integers(0, 4, size=(a.n, a.L), dtype=np.uint8)
+    if a.planted > 0:      # SURVEY.md 8(d) "direct pool mode": planted near-duplicates exercise thresholds and ties
+        m = int(a.n * a.planted)
+        dst, src = rng.integers(0, a.n, size=m), rng.integers(0, a.n, size=m)
+        codes[dst] = codes[src]
+        for _ in range(3):
+            hit = rng.random(m) < 0.67
+            codes[dst[hit], rng.integers(0, a.L, size=int(hit.sum()))] = rng.integers(0, 4, size=int(hit.sum()))
+    db = np.unique(core.pack_codes(codes))
     rng.shuffle(db)
     q = db if a.nq == 0 else db[:a.nq]
     idx = _lib.Index(db, a.L, _lib.METRIC_HAMMING if a.metric == "hamming" else _lib.METRIC_LEVEN)
