@@ -71,10 +71,14 @@ def _tree_ops(L):
 
 
 def bitsliced_leven_ops_per_pair(L):
-    """VALU lane-ops per guide pair of K2B (gm_leven_bs.hip.h): per 32-target word 5 ops per DP cell,
-    one address bump per row per 4 columns (+ one per row per group), two count trees, the 5-bit
-    subtract and the 5-op threshold compare."""
-    per_word = 5.0 * L * L + L * (L / 4.0) + L / 2.0 + 2 * _tree_ops(L) + 10 + 5
+    """VALU lane-ops per guide pair of K2B (gm_leven_bs.hip.h) on its BANDED path (every lane's bound within
+    the band, the common case once the bounds are seeded): per 32-target word 5 ops per DP cell of the band
+    |i - j| <= (3L + 4) // 8, one count tree over the diagonal, the 5-op threshold compare and one address
+    bump per row per group.  Groups that take the full-matrix path execute more (5 L^2 + two trees), so the
+    fraction derived from this figure is a lower bound."""
+    band = (3 * L + 4) // 8
+    cells = L * L - (L - band - 1) * (L - band)
+    per_word = 5.0 * cells + _tree_ops(L) + 5 + L / 2.0
     return per_word / 32.0
 
 
@@ -254,7 +258,8 @@ def main():
                         "streaming model (SURVEY.md 8d)"}
         if pool["metric"] != "hamming" and 10 <= L <= 27:
             if "knn_bs" in kname:      # K2B: 5 ops per DP cell per 32 pairs + counts, compare, address bumps
-                opp, reads = bitsliced_leven_ops_per_pair(L), L * L / 32.0
+                band = (3 * L + 4) // 8
+                opp, reads = bitsliced_leven_ops_per_pair(L), (L * L - (L - band - 1) * (L - band)) / 32.0
             else:                      # K2L: 11 VALU ops per text position + distance/threshold tail
                 opp, reads = 11.0 * L + 12.0, float(L)
             ops = launch_pairs * opp / kern_s

@@ -20,6 +20,8 @@
 #pragma once
 #include "gm_leven.hip.h"
 
+#include <utility>
+
 namespace gm {
 
 constexpr int TT_OR3 = (0xF0 | 0xCC | 0xAA) & 0xFF;                               // a | b | c
@@ -107,11 +109,79 @@ __device__ __forceinline__ void lvb_eval_half(uint32_t (&adr)[L], uint32_t (&c)[
     asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]));
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Banded evaluation.  A pair can only be a hit if its distance is below the lane's bound, and an alignment of
+// cost <= BAND never leaves the diagonal band |i - j| <= BAND, so while every lane of the wave has a bound
+// <= BAND + 1 only the band's cells are evaluated.  Outside cells are replaced by upper bounds that cost
+// nothing: a column starts at the top of its band with the horizontal delta +1 (exact in row 0, an upper
+// bound below it), and a row enters the band from below with the vertical delta it was initialised with
+// (+1).  All values computed this way are >= the true ones and exact along every path inside the band, so
+// the result is the true distance when that is <= BAND and something larger (never a false hit) otherwise.
+// The last column is no longer complete, so the distance is read off the DIAGONAL instead: it grows by
+// 0 or 1 per step and D0(i, i) says which, i.e. s = L - distance = popcount over i of D0(i, i): one
+// carry-save tree.  Columns are fully unrolled (row ranges and read offsets are compile-time); the delta
+// registers of rows above the band die and those below it are still constants, so the banded code also needs
+// fewer VGPRs.  L = 23, BAND = 9: 347 of 529 cells.  (While a lane's bound is above BAND + 1 -- unseeded
+// candidates, k-th neighbours far away -- the wave takes the full evaluation above.)
+// ---------------------------------------------------------------------------------------------------
+// band width per guide length: about 3/8 of it -- the k-th Hamming distance that seeds the bounds sits near
+// L / 3 for pools of 10^5 .. 10^6 random targets (L = 20: 8, 23: 9, 27: 10)
+__host__ __device__ constexpr int lvb_band(int L) { return (3 * L + 4) / 8; }
+
+template <int L, int HB, int BAND, int J>
+__device__ __forceinline__ void lvb_column_banded(const uint32_t (&adr)[L], uint32_t (&Pv)[L], uint32_t (&Mv)[L],
+                                                  uint32_t (&dd)[L]) {
+    constexpr int LO = J - BAND > 0 ? J - BAND : 0;
+    constexpr int HI = J + BAND < L - 1 ? J + BAND : L - 1;
+    constexpr int N = HI - LO + 1, NP = (N + 3) / 4 * 4;
+    uint32_t eq[NP];
+#pragma unroll
+    for (int r = 0; r < NP; ++r) eq[r] = r < N ? lvb_read<HB + 32 * J>(adr[LO + r]) : 0u;
+#pragma unroll
+    for (int g = 0; g < NP / 4; ++g) lvb_wait4(eq[4 * g], eq[4 * g + 1], eq[4 * g + 2], eq[4 * g + 3]);
+    uint32_t Ph = 0xffffffffu, Mh = 0u;
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+        const int i = LO + r;
+        const uint32_t D0 = GM_BITOP3(eq[r], Mv[i], Mh, TT_OR3);
+        const uint32_t Pho = GM_BITOP3(Mv[i], D0, Pv[i], TT_A_OR_NOR_BC);
+        const uint32_t Mho = Pv[i] & D0;
+        Pv[i] = GM_BITOP3(Mh, D0, Ph, TT_A_OR_NOR_BC);
+        Mv[i] = Ph & D0;
+        Ph = Pho;
+        Mh = Mho;
+        if (i == J) dd[J] = D0;
+    }
+    // the deltas leaving the column close its dependency chain: pinning them keeps the compiler from sinking
+    // this column's work below the next column's reads
+    asm volatile("" : "+v"(Ph), "+v"(Mh));
+}
+
+template <int L, int HB, int BAND, int... J>
+__device__ __forceinline__ void lvb_columns_banded(const uint32_t (&adr)[L], uint32_t (&Pv)[L], uint32_t (&Mv)[L],
+                                                   uint32_t (&dd)[L], std::integer_sequence<int, J...>) {
+    (lvb_column_banded<L, HB, BAND, J>(adr, Pv, Mv, dd), ...);
+}
+
+// banded DP of one half group; adr[] is NOT advanced (every read carries its column's offset)
+template <int L, int HB, int BAND>
+__device__ __forceinline__ void lvb_eval_half_banded(const uint32_t (&adr)[L], uint32_t (&c)[5]) {
+    uint32_t Pv[L], Mv[L], dd[L];
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        Pv[i] = 0xffffffffu;
+        Mv[i] = 0u;
+    }
+    lvb_columns_banded<L, HB, BAND>(adr, Pv, Mv, dd, std::make_integer_sequence<int, L>{});
+    bitslice_count<L>(dd, c);
+    asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]));
+}
+
 // K2B scan.  grid = (ceil(n_q / 64), n_seg); tiles = the K1L one-hot table tiles (LK_TG groups of 64).
 // Dynamic LDS: 2 tiles.  seed_*: Hamming k-NN of the same candidates (lev <= hamming).
 // keys: [n_seg][n_q][KCAP] raw RegList contents, folded by k_merge_lists.
 template <int L, int KCAP>
-__global__ __launch_bounds__(WAVE, (L <= 23 ? 4 : 3)) void k_leven_knn_bs(const uint32_t* __restrict__ table, int n_db, int n_tiles,
+__global__ __launch_bounds__(WAVE, 3) void k_leven_knn_bs(const uint32_t* __restrict__ table, int n_db, int n_tiles,
                                                        int tiles_per_seg, const uint2* __restrict__ q,
                                                        int64_t n_q, int k, const int32_t* __restrict__ seed_dists,
                                                        const int32_t* __restrict__ seed_counts, int seed_k,
@@ -156,10 +226,21 @@ __global__ __launch_bounds__(WAVE, (L <= 23 ? 4 : 3)) void k_leven_knn_bs(const 
         }
         for (int gl = 0; gl < LK_TG; ++gl) {
             uint32_t c0[5], c1[5];
-            lvb_eval_half<L, 0>(adr, c0);                              // adr: -> next group
+            constexpr int BAND = lvb_band(L);
+            const bool banded = __builtin_amdgcn_ballot_w64(thr > BAND + 1) == 0ull;
+            if (banded) {
+                {
+                    lvb_eval_half_banded<L, 0, BAND>(adr, c0);
+                    lvb_eval_half_banded<L, 4, BAND>(adr, c1);
 #pragma unroll
-            for (int i = 0; i < L; ++i) asm volatile("v_subrev_u32 %0, %1, %0" : "+v"(adr[i]) : "n"(GW * 4));
-            lvb_eval_half<L, 4>(adr, c1);
+                    for (int i = 0; i < L; ++i) asm volatile("v_add_u32 %0, %1, %0" : "+v"(adr[i]) : "n"(GW * 4));
+                }
+            } else {
+                lvb_eval_half<L, 0>(adr, c0);                              // adr: -> next group
+#pragma unroll
+                for (int i = 0; i < L; ++i) asm volatile("v_subrev_u32 %0, %1, %0" : "+v"(adr[i]) : "n"(GW * 4));
+                lvb_eval_half<L, 4>(adr, c1);
+            }
             uint32_t h0 = GM_BITOP3(c0[0], Tb[0], Tb[0], TT_A_OR_NOTB), h1 = GM_BITOP3(c1[0], Tb[0], Tb[0], TT_A_OR_NOTB);
 #pragma unroll
             for (int b = 1; b < 5; ++b) {
