@@ -158,7 +158,10 @@ def unpack(packed, guidelen):
     buf = np.empty((n, guidelen), np.uint8)
     if n:
         _check(lib().gm_unpack(_ptr(packed), n, guidelen, _ptr(buf)))
-    return [row.tobytes().decode("ascii") for row in buf]
+    if n == 0:
+        return []
+    # one vectorised bytes -> str conversion instead of a Python-level decode per row
+    return np.ascontiguousarray(buf).view("S%d" % guidelen).ravel().astype(str).tolist()
 
 
 class Index:
