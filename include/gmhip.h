@@ -157,7 +157,14 @@ int gm_pigeon_plan(int64_t n_db, int guidelen, int k, double p_match);
 int gm_timing_reserve(gm_index* idx, int n);
 int gm_timing_read(gm_index* idx, double* ms_out, int max_n);
 
-/* Tuning knob for experiments (bench/tests): select a kernel variant; 0 = default. */
+/* A/B knob for experiments, benchmarks and tests; results are identical for every value.  0 = default.
+ *   Hamming:     8 = plain two-phase look-up scan K1L (no pigeonhole partition); 9 = K1L in a single pass;
+ *                7 = K1L with its k-lists in LDS; 1 = popcount kernel K1; 20..36 = scalar-load bit-sliced kernel
+ *                K1v (L = 20 only); 40..49 = K1L with the resident waves capped; 50..99 = K1L with
+ *                (variant - 50) pool segments; 100 + B = K1P with B blocks, no expansion; 200 + B / 300 + B one
+ *                expansion block (even length / one base longer); 400 + B / 500 + B two / three longer expansion
+ *                blocks; 600 + B / 700 + B two / three expansion blocks of even length.
+ *   Levenshtein: 2 = per-pair Myers kernel K2L; 1 = plane-based kernel (also used for L < 10 and k > 20). */
 int gm_set_variant(gm_index* idx, int variant);
 
 #ifdef __cplusplus
