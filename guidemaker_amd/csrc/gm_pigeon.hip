@@ -372,6 +372,7 @@ struct gm_pigeon {
     int cap = 0;
     int64_t cap_nq = -1;          // candidate count / expansion the capacities were sized for
     int cap_x_for = -1;
+    bool cap_k1 = false;
     gm_pg_blocks blocks{};
     int32_t* inc = nullptr;
     int64_t inc_cap = 0;
@@ -697,7 +698,7 @@ int gm_pg_candidates(gm_index* idx, int64_t n_q, hipStream_t st) {
 // under the independent-base model with the pool's own composition (own buckets: >= 16; neighbour buckets of
 // the expansion pass, where the pair already has one mismatch: >= 8).  A list that still overflows (repeat
 // families) only makes its row incomplete: the row is re-scanned by the plain kernel.
-static void pg_slot_capacity(const gm_index* idx, gm_pigeon* pg, int64_t n_q) {
+static void pg_slot_capacity(const gm_index* idx, gm_pigeon* pg, int64_t n_q, int k) {
     const int L = idx->L, r = pg->B + pg->expand - 1;
     const double pm = pg->p_match >= 0.25 ? pg->p_match : 0.25;
     double worst = 0.0;
@@ -717,6 +718,10 @@ static void pg_slot_capacity(const gm_index* idx, gm_pigeon* pg, int64_t n_q) {
         cap_x = std::ceil(1.25 * (h + 6.0 * std::sqrt(h)) + 8.0);
         if (cap_x > 512.0) cap_x = 512.0;
     }
+    if (k == 1) {      // nearest distance: the bound follows the best hit, a list only grows by improvements
+        cap = cap > 12.0 ? 12.0 : cap;
+        cap_x = cap_x > 6.0 ? 6.0 : cap_x;
+    }
     // keep the slot lists within a quarter of the free device memory (at least 2 GiB)
     size_t free_b = 0, total_b = 0;
     double limit = 2.0 * 1024 * 1024 * 1024;
@@ -732,10 +737,11 @@ static void pg_slot_capacity(const gm_index* idx, gm_pigeon* pg, int64_t n_q) {
 int gm_pg_scan(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
     gm_pigeon* pg = idx->pg;
     int rc;
-    if (pg->cap == 0 || pg->cap_nq != n_q || pg->cap_x_for != pg->expand) {      // (hipMemGetInfo is not free)
-        pg_slot_capacity(idx, pg, n_q);
+    if (pg->cap == 0 || pg->cap_nq != n_q || pg->cap_x_for != pg->expand || pg->cap_k1 != (k == 1)) {
+        pg_slot_capacity(idx, pg, n_q, k);      // (cached: hipMemGetInfo is not free)
         pg->cap_nq = n_q;
         pg->cap_x_for = pg->expand;
+        pg->cap_k1 = k == 1;
     }
     const int n_x = pg->expand * 3 * pg->blen[0];
     if ((rc = ensure(&pg->keys, &pg->keys_cap, ((int64_t)pg->B * pg->cap + (int64_t)n_x * pg->cap_x) * n_q,
