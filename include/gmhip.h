@@ -27,7 +27,10 @@
  *   - neighbour lists are exact and ordered by (distance ascending, db index ascending); rows with
  *     fewer than k db points are padded with -1 and counts[] holds the valid length
  *   - *_dev variants take DEVICE pointers (HBM-resident inputs/outputs) and a hipStream_t passed as
- *     void*; they enqueue asynchronously on that stream
+ *     void*; they enqueue on that stream and return without waiting for the results.  (Large Hamming pools go
+ *     through the pigeonhole-partitioned scan, which waits for the stream twice inside the call: to learn how
+ *     many rows need the follow-up scan and to verify it; the first call on a handle also builds the
+ *     block-sorted pool copies.)
  *   - one host thread per handle; handles are independent; one handle = one GPU (multi-GPU is one
  *     process per GPU)
  *   - there is NO CPU fallback: without a gfx950 device every compute entry point fails with
