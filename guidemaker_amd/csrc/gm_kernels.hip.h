@@ -404,22 +404,46 @@ __global__ __launch_bounds__(WAVE) void k_leven_nearest(const uint2* __restrict_
 // K3: CFD (cfd_score_calculator.py:60-85): float64 product in ascending position; the table holds
 // 1.0 on the Watson-Crick (= matching) entries, and x * 1.0 is exact, so the loop is branch-free.
 // ---------------------------------------------------------------------------------------------
-static __global__ void k_cfd(const uint64_t* __restrict__ guides, const uint64_t* __restrict__ offs, int64_t n,
-                      int L, const double* __restrict__ mm, double* __restrict__ out) {
+constexpr int CFD_PER_THREAD = 4;      // pairs per thread: all eight operand loads are in flight before the products
+
+__device__ __forceinline__ double cfd_product(uint64_t a, uint64_t b, int L, const double* __restrict__ smm) {
+    double score = 1.0;
+    const int p0 = L > 20 ? L - 20 : 0;
+    // only mismatching positions contribute (the reference multiplies only where wt[i] != off[i],
+    // cfd_score_calculator.py:79-83); walk them in ascending position = the reference's product order
+    const uint64_t x = a ^ b;
+    uint64_t m = (x | (x >> 1)) & 0x5555555555555555ull;
+    m &= ~0ull << (2 * p0);
+    if (L < 32) m &= (1ull << (2 * L)) - 1ull;
+    while (m != 0ull) {
+        const int bit = __builtin_ctzll(m);
+        m &= m - 1ull;
+        const int r = (int)((a >> bit) & 3u);
+        const int o = (int)((b >> bit) & 3u);
+        score *= smm[(20 + (bit >> 1) - L) * 16 + r * 4 + (3 - o)];
+    }
+    return score;
+}
+
+static __global__ __launch_bounds__(256) void k_cfd(const uint64_t* __restrict__ guides, const uint64_t* __restrict__ offs,
+                                                    int64_t n, int L, const double* __restrict__ mm,
+                                                    double* __restrict__ out) {
     __shared__ double smm[320];
     for (int i = threadIdx.x; i < 320; i += blockDim.x) smm[i] = mm[i];
     __syncthreads();
-    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n) return;
-    uint64_t a = guides[idx], b = offs[idx];
-    double score = 1.0;
-    int p0 = L > 20 ? L - 20 : 0;
-    for (int p = p0; p < L; ++p) {
-        int r = (int)((a >> (2 * p)) & 3u);
-        int o = (int)((b >> (2 * p)) & 3u);
-        score *= smm[(20 + p - L) * 16 + r * 4 + (3 - o)];
+    const int64_t base = (int64_t)blockIdx.x * (256 * CFD_PER_THREAD) + threadIdx.x;
+    uint64_t a[CFD_PER_THREAD], b[CFD_PER_THREAD];
+#pragma unroll
+    for (int j = 0; j < CFD_PER_THREAD; ++j) {
+        const int64_t idx = base + j * 256;
+        a[j] = idx < n ? guides[idx] : 0ull;
+        b[j] = idx < n ? offs[idx] : 0ull;
     }
-    out[idx] = score;
+#pragma unroll
+    for (int j = 0; j < CFD_PER_THREAD; ++j) {
+        const int64_t idx = base + j * 256;
+        if (idx < n) out[idx] = cfd_product(a[j], b[j], L, smm);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

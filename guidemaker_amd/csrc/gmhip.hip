@@ -740,7 +740,7 @@ int gm_cfd_batch_dev(const void* d_guides, const void* d_offs, int64_t n_pairs, 
         return fail(GM_ERR_ARG, "gm_cfd_batch: bad argument");
     if (n_pairs == 0) return GM_OK;
     if (!d_guides || !d_offs || !d_mm || !d_out) return fail(GM_ERR_ARG, "gm_cfd_batch: null buffer");
-    int64_t blocks = (n_pairs + 255) / 256;
+    int64_t blocks = (n_pairs + 256 * gm::CFD_PER_THREAD - 1) / (256 * gm::CFD_PER_THREAD);
     hipLaunchKernelGGL(gm::k_cfd, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        static_cast<const uint64_t*>(d_guides), static_cast<const uint64_t*>(d_offs), n_pairs,
                        guidelen, static_cast<const double*>(d_mm), static_cast<double*>(d_out));
