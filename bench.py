@@ -185,23 +185,44 @@ def main():
 
     d_db = torch.from_numpy(db_np.view(np.int64)).to(dev)
     d_q = torch.from_numpy(np.ascontiguousarray(q_np).view(np.int64)).to(dev)
-    ids = torch.empty((n_q, k), dtype=torch.int32, device=dev)
-    dists = torch.empty((n_q, k), dtype=torch.int32, device=dev)
-    counts = torch.empty((n_q,), dtype=torch.int32, device=dev)
+    # two result buffers: with N > 1 the all-gather of one step (RCCL, its own stream) overlaps the scan of the
+    # next step; every gather is waited for and unpacked inside the timed region
+    nbuf = 2 if world > 1 and backend == "nccl" else 1
+    ids_b = [torch.empty((n_q, k), dtype=torch.int32, device=dev) for _ in range(nbuf)]
+    dists_b = [torch.empty((n_q, k), dtype=torch.int32, device=dev) for _ in range(nbuf)]
+    counts_b = [torch.empty((n_q,), dtype=torch.int32, device=dev) for _ in range(nbuf)]
+    gather_b = [torch.empty((world * n_q, k), dtype=torch.int32, device=dev) for _ in range(nbuf)] if nbuf == 2 else []
+    pending = [None] * nbuf
     gathered = [None, None, None]
+    ids, dists, counts = ids_b[0], dists_b[0], counts_b[0]
     stream = torch.cuda.current_stream().cuda_stream
     idx = _lib.Index.from_device(d_db.data_ptr(), n_db, L, metric_code, local_rank, stream)
+    step_no = [0]
+
+    def drain(b):
+        if pending[b] is not None:
+            gathered[:] = pending[b].result()
+            pending[b] = None
 
     def step():
-        idx.knn_dev(d_q.data_ptr(), n_q, k, ids.data_ptr(), dists.data_ptr(), counts.data_ptr(), stream)
+        b = step_no[0] % nbuf
+        step_no[0] += 1
+        drain(b)                          # the gather that last used this buffer pair
+        idx.knn_dev(d_q.data_ptr(), n_q, k, ids_b[b].data_ptr(), dists_b[b].data_ptr(), counts_b[b].data_ptr(), stream)
         if world > 1:   # the one exchange of the path: per-shard neighbour lists over RCCL/xGMI
             if backend == "nccl":
-                gathered[:] = distributed.all_gather_neighbors(ids, dists, counts, world * n_q)
+                pending[b] = distributed.all_gather_neighbors_async(ids_b[b], dists_b[b], world * n_q, out=gather_b[b])
             else:
-                gathered[:] = distributed.all_gather_neighbors(ids.cpu(), dists.cpu(), counts.cpu(), world * n_q)
+                gathered[:] = distributed.all_gather_neighbors(ids_b[b].cpu(), dists_b[b].cpu(), counts_b[b].cpu(),
+                                                               world * n_q)
+
+    def finish():
+        for b in range(nbuf):
+            drain(b)
 
     for _ in range(args.warmup):
         step()
+    finish()
     idx.timing_reserve(max(1, args.steps))
     torch.cuda.synchronize()
     if world > 1:
@@ -210,6 +231,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    finish()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -301,7 +323,8 @@ def main():
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": pool["label"], "n_candidates_per_gpu": int(n_q), "n_targets": int(n_db),
                        "guidelen": L, "k": k, "distance": pool["metric"],
-                       "parallelism": "candidate shards x%d, replicated pool, 1 RCCL all-gather" % world},
+                       "parallelism": "candidate shards x%d, replicated pool, 1 RCCL all-gather per step"
+                                      "%s" % (world, " (overlapping the next step's scan)" if nbuf == 2 else "")},
             "roofline": roof,
         }
         if world == 1:

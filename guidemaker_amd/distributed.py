@@ -86,6 +86,35 @@ def all_gather_neighbors(ids, dists, counts, n_total, group=None):
     return g_ids[:n_total], g_dists[:n_total], g_counts[:n_total]
 
 
+class PendingGather:
+    """An all-gather of neighbour lists in flight (RCCL runs it on its own stream).  result() makes the
+    current stream wait for it and unpacks the keys: (ids, dists, counts) trimmed to n_total rows."""
+
+    def __init__(self, work, gathered, n_total):
+        self._work, self._gathered, self._n = work, gathered, n_total
+
+    def result(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        g_ids, g_dists, g_counts = unpack_keys(self._gathered)
+        return g_ids[:self._n], g_dists[:self._n], g_counts[:self._n]
+
+
+def all_gather_neighbors_async(ids, dists, n_total, group=None, out=None):
+    """Like all_gather_neighbors, but returns at once with a PendingGather: the collective overlaps whatever
+    the caller enqueues next (the following candidate batch's scan).  `out`: optional [world * per, k] int32
+    tensor to gather into (double buffering); the caller must not reuse it before result()."""
+    import torch
+    dist = _dist()
+    world = dist.get_world_size(group)
+    per, k = ids.shape
+    keys = pack_keys(ids.contiguous(), dists.contiguous())
+    gathered = out if out is not None else torch.empty((world * per, k), dtype=torch.int32, device=keys.device)
+    work = dist.all_gather_into_tensor(gathered, keys, group=group, async_op=True)
+    return PendingGather(work, gathered, n_total)
+
+
 def sharded_knn(local_knn, q_packed, k, device=None, group=None):
     """k-NN of all candidates with the work split over the ranks of the process group.
 

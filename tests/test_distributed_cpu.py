@@ -45,6 +45,19 @@ def _worker(rank, world, port, n_q, k, out_dir):
         want = local_knn(_lib.pack(q, L), k) if n_q else (np.empty((0, k), np.int32),) * 2 + (np.empty(0, np.int32),)
         for g, w in zip(got, want):
             assert g.shape == w.shape and (g == w).all()
+        # the asynchronous form (bench.py overlaps it with the next batch's scan): two gathers in flight into
+        # caller-owned buffers, results taken in order
+        if n_q:
+            shard = [torch.from_numpy(np.ascontiguousarray(a)) for a in
+                     (np.full((per, k), -1, np.int32), np.full((per, k), -1, np.int32))]
+            if hi > lo:
+                i, d, _ = local_knn(_lib.pack(q, L)[lo:hi], k)
+                shard[0][:hi - lo], shard[1][:hi - lo] = torch.from_numpy(i), torch.from_numpy(d.astype(np.int32))
+            bufs = [torch.empty((world * per, k), dtype=torch.int32) for _ in range(2)]
+            pend = [distributed.all_gather_neighbors_async(shard[0], shard[1], n_q, out=b) for b in bufs]
+            for p in pend:
+                gi, gd, gc = p.result()
+                assert (gi.numpy() == want[0]).all() and (gd.numpy() == want[1]).all() and (gc.numpy() == want[2]).all()
         np.save(os.path.join(out_dir, "ok_%d.npy" % rank), np.array([1]))
     finally:
         dist.destroy_process_group()
