@@ -198,6 +198,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     idx = _lib.Index.from_device(d_db.data_ptr(), n_db, L, metric_code, local_rank, stream)
     step_no = [0]
+    use_async = [True]
 
     def drain(b):
         if pending[b] is not None:
@@ -210,8 +211,16 @@ def main():
         drain(b)                          # the gather that last used this buffer pair
         idx.knn_dev(d_q.data_ptr(), n_q, k, ids_b[b].data_ptr(), dists_b[b].data_ptr(), counts_b[b].data_ptr(), stream)
         if world > 1:   # the one exchange of the path: per-shard neighbour lists over RCCL/xGMI
-            if backend == "nccl":
-                pending[b] = distributed.all_gather_neighbors_async(ids_b[b], dists_b[b], world * n_q, out=gather_b[b])
+            if backend == "nccl" and use_async[0]:
+                try:
+                    pending[b] = distributed.all_gather_neighbors_async(ids_b[b], dists_b[b], world * n_q,
+                                                                        out=gather_b[b])
+                except Exception as e:      # an RCCL build without async support: gather in line from now on
+                    print("bench: async all-gather unavailable (%s); using the blocking form" % e, file=sys.stderr)
+                    use_async[0] = False
+                    gathered[:] = distributed.all_gather_neighbors(ids_b[b], dists_b[b], counts_b[b], world * n_q)
+            elif backend == "nccl":
+                gathered[:] = distributed.all_gather_neighbors(ids_b[b], dists_b[b], counts_b[b], world * n_q)
             else:
                 gathered[:] = distributed.all_gather_neighbors(ids_b[b].cpu(), dists_b[b].cpu(), counts_b[b].cpu(),
                                                                world * n_q)
@@ -324,7 +333,7 @@ def main():
             "config": {"workload": pool["label"], "n_candidates_per_gpu": int(n_q), "n_targets": int(n_db),
                        "guidelen": L, "k": k, "distance": pool["metric"],
                        "parallelism": "candidate shards x%d, replicated pool, 1 RCCL all-gather per step"
-                                      "%s" % (world, " (overlapping the next step's scan)" if nbuf == 2 else "")},
+                                      "%s" % (world, " (overlapping the next step's scan)" if nbuf == 2 and use_async[0] else "")},
             "roofline": roof,
         }
         if world == 1:
