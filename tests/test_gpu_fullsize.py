@@ -1,0 +1,161 @@
+"""Full-size GPU parity tests: every BASELINE.json configuration at its real size, on the layout bench.py runs.
+
+For each synthetic stand-in workload of SURVEY.md section 8(d) (S1 = configs[1] E. coli, S2 = configs[2]
+B. subtilis / Levenshtein, S3 = configs[3] yeast + CFD, S4 = configs[4] 100 Mb NNGRRT) the FULL candidate set
+is searched against the FULL pool through the C-ABI and
+
+  * the production kernel is asserted (pigeonhole-partitioned scan, 4 blocks, for the Hamming workloads),
+  * the whole result is compared with an independent kernel of the library (plain two-phase scan,
+    gm_set_variant(8); per-pair Myers kernel, variant 2, for Levenshtein),
+  * >= 512 random rows are compared with the CPU oracle over the full pool (bit-exact ids / distances / counts),
+  * size-independent properties hold (self is nearest, sortedness, canonical tie order, idempotence).
+
+The pools are built once per session (the 100 Mb genome of S4 takes the longest)."""
+import functools
+
+import numpy as np
+import pytest
+
+import guidemaker_amd
+from guidemaker_amd import _lib, core, workloads
+
+pytestmark = pytest.mark.gpu
+ORACLE_ROWS = 512
+
+
+@functools.lru_cache(maxsize=None)
+def _pool(name):
+    return workloads.make_pool(name)
+
+
+def _oracle_rows(orc, pool, rows):
+    """Oracle k-NN (true units) of the candidate rows `rows` over the full pool."""
+    L, metric, k = pool["guidelen"], pool["metric"], pool["k"]
+    asc = np.frombuffer(b"ACGT", np.uint8)
+    shifts = (2 * np.arange(L, dtype=np.uint64))[None, :]
+    db = asc[((pool["packed_db"][:, None] >> shifts) & np.uint64(3)).astype(np.uint8)]
+    q = asc[((pool["packed_all"][rows][:, None] >> shifts) & np.uint64(3)).astype(np.uint8)]
+    ids, dists, counts = orc.knn(np.ascontiguousarray(db), np.ascontiguousarray(q), L, metric, k)
+    if metric == "hamming":
+        dists = np.where(dists >= 0, dists // 2, -1)
+    return ids, dists, counts
+
+
+def _check_properties(pool, ids, dists, counts):
+    k, n_db = pool["k"], pool["packed_db"].shape[0]
+    assert (counts == min(k, n_db)).all()
+    assert (dists[:, 0] == 0).all()                                     # every candidate is a pool member
+    assert (pool["packed_db"][ids[:, 0]] == pool["packed_all"]).all()   # ... and is its own nearest hit
+    assert (np.diff(dists, axis=1) >= 0).all()                          # sorted by distance
+    same = np.diff(dists, axis=1) == 0
+    assert (np.diff(ids, axis=1)[same] > 0).all()                       # ties by pool index
+
+
+def _hamming_of(pool, ids):
+    """True Hamming distances of the reported ids (numpy on the packed words, in row blocks)."""
+    out = np.empty(ids.shape, np.int32)
+    m1, m2, m4 = np.uint64(0x5555555555555555), np.uint64(0x3333333333333333), np.uint64(0x0F0F0F0F0F0F0F0F)
+    for lo in range(0, ids.shape[0], 400_000):
+        hi = min(ids.shape[0], lo + 400_000)
+        x = pool["packed_all"][lo:hi, None] ^ pool["packed_db"][ids[lo:hi]]
+        m = (x | (x >> np.uint64(1))) & m1                  # one bit per mismatching base
+        m = (m & m2) + ((m >> np.uint64(2)) & m2)
+        m = (m + (m >> np.uint64(4))) & m4
+        out[lo:hi] = ((m * np.uint64(0x0101010101010101)) >> np.uint64(56)).astype(np.int32)
+    return out
+
+
+@pytest.mark.parametrize("name", ["s1", "s3", "s4"])
+def test_hamming_workload_full_size(oracle, name):
+    pool = _pool(name)
+    L, k = pool["guidelen"], pool["k"]
+    q, db = pool["packed_all"], pool["packed_db"]
+    idx = _lib.Index(db, L, _lib.METRIC_HAMMING)
+    try:
+        ids, dists, counts = idx.knn(q, k)
+        # the layout bench.py runs: pigeonhole-partitioned scan, four blocks
+        assert idx.last_kernel()[0] == "k_hamming_scan_pg"
+        assert idx.pigeon_blocks() == 4
+        evaluated, rescanned = idx.last_evaluated()
+        assert 0 < evaluated < 0.15 * q.shape[0] * db.shape[0]
+        _check_properties(pool, ids, dists, counts)
+        assert (_hamming_of(pool, ids) == dists).all()                  # reported distances are the true ones
+        # idempotence
+        ids2, dists2, counts2 = idx.knn(q, k)
+        assert (ids2 == ids).all() and (dists2 == dists).all() and (counts2 == counts).all()
+        # the whole result against the plain two-phase scan (no pigeonhole partition)
+        idx.set_variant(8)
+        i8, d8, c8 = idx.knn(q, k)
+        assert idx.last_kernel()[0].startswith("k_hamming_knn_lk")
+        assert (i8 == ids).all() and (d8 == dists).all() and (c8 == counts).all()
+        idx.set_variant(0)
+        # nearest-distance entry point (controls) on the same layout
+        d1 = idx.nearest(q[: 200_000])
+        assert (d1 == 0).all()
+        # oracle over the full pool for a random sample of rows
+        rng = np.random.default_rng(101)
+        rows = np.sort(rng.choice(q.shape[0], size=ORACLE_ROWS, replace=False))
+        oi, od, oc = _oracle_rows(oracle, pool, rows)
+        assert (oc == counts[rows]).all() and (od == dists[rows]).all() and (oi == ids[rows]).all()
+    finally:
+        idx.close()
+    if name == "s3":
+        _check_cfd_all_pairs(oracle, pool, ids, dists)
+
+
+def _check_cfd_all_pairs(orc, pool, ids, dists):
+    """BASELINE configs[3]: --cfd_score over every retained guide x its k similar guides, through the
+    reference-shaped entry point core.cfd_score, against the oracle's calc_cfd restatement."""
+    import json
+    import os
+    import pandas as pd
+    L, k = pool["guidelen"], pool["k"]
+    keep = np.flatnonzero(dists[:, 1] >= pool["editdist"])              # reference core.py:512
+    assert keep.size > 0.5 * dists.shape[0]
+    db_str = np.asarray(_lib.unpack(pool["packed_db"], L), dtype=object)
+    guides = np.asarray(_lib.unpack(pool["packed_all"][keep], L), dtype=object)
+    sims = db_str[ids[keep]]                                            # (n, k) neighbour sequences
+    joined = [";".join(r) for r in sims.tolist()]
+    df = pd.DataFrame({"Guide sequence": guides, "Similar guides": joined})
+    out = core.cfd_score(df)
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfd_table.json")) as fh:
+        mm = json.load(fh)["mm"]
+    want = orc.cfd_batch(np.repeat(guides, k).tolist(), sims.reshape(-1).tolist(), L, mm).reshape(-1, k)
+    got = np.array(out["CFD Similar Guides"].tolist(), dtype=object)
+    assert got.shape == want.shape
+    assert np.abs(got.astype(np.float64) - want).max() <= 1e-6          # north-star tolerance
+    assert (got.astype(np.float64) == want).all()                       # observed: bit-exact
+    sample = np.random.default_rng(5).choice(keep.size, size=2000, replace=False)
+    for r in sample.tolist():                                           # str(float) formatting, row by row
+        assert got[r].tolist() == [str(v) for v in want[r].tolist()]
+    assert (out["Max CFD"].to_numpy() == want.max(axis=1)).all()
+    assert (want[:, 0] == 1.0).all()                                    # a guide against itself
+
+
+def test_leven_workload_full_size(oracle):
+    pool = _pool("s2")
+    L, k = pool["guidelen"], pool["k"]
+    q, db = pool["packed_all"], pool["packed_db"]
+    idx = _lib.Index(db, L, _lib.METRIC_LEVEN)
+    try:
+        ids, dists, counts = idx.knn(q, k)
+        assert idx.last_kernel()[0] == "k_leven_knn_bs"
+        _check_properties(pool, ids, dists, counts)
+        # lev <= hamming, column by column
+        hidx = _lib.Index(db, L, _lib.METRIC_HAMMING)
+        _, hd, _ = hidx.knn(q, k)
+        hidx.close()
+        assert (dists <= hd).all()
+        # the whole result against the per-pair Myers kernel K2L
+        idx.set_variant(2)
+        i2, d2, c2 = idx.knn(q, k)
+        assert idx.last_kernel()[0] == "k_leven_knn_lk"
+        assert (i2 == ids).all() and (d2 == dists).all() and (c2 == counts).all()
+        idx.set_variant(0)
+        assert (idx.nearest(q[:50_000]) == 0).all()
+        rng = np.random.default_rng(202)
+        rows = np.sort(rng.choice(q.shape[0], size=ORACLE_ROWS, replace=False))
+        oi, od, oc = _oracle_rows(oracle, pool, rows)
+        assert (oc == counts[rows]).all() and (od == dists[rows]).all() and (oi == ids[rows]).all()
+    finally:
+        idx.close()
