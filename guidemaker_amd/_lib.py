@@ -77,6 +77,8 @@ def lib():
     L.gm_pigeon_plan.argtypes = [i64, i32, i32, c.c_double]
     L.gm_pigeon_plan.restype = i32
     L.gm_set_variant.argtypes = [vp, i32]
+    L.gm_set_param.argtypes = [vp, c.c_char_p, i32]
+    L.gm_set_param.restype = i32
     L.gm_timing_reserve.argtypes = [vp, i32]
     L.gm_timing_reserve.restype = i32
     L.gm_timing_read.argtypes = [vp, vp, i32]
@@ -112,7 +114,7 @@ EXPORTS = [
     "gm_cfd_batch_dev", "gm_last_kernel_ms", "gm_last_query_ms", "gm_last_kernel_name", "gm_last_kernel_pairs",
     "gm_set_variant", "gm_timing_reserve", "gm_timing_read", "gm_pam_count", "gm_pam_emit", "gm_pam_free",
     "gm_pack_keys_dev", "gm_unpack_keys_dev", "gm_site_flags", "gm_seed_duplicated",
-    "gm_last_kernel_evaluated", "gm_last_incomplete", "gm_pigeon_blocks", "gm_pigeon_plan",
+    "gm_last_kernel_evaluated", "gm_last_incomplete", "gm_pigeon_blocks", "gm_pigeon_plan", "gm_set_param",
 ]
 
 
@@ -233,6 +235,10 @@ class Index:
 
     def set_variant(self, v):
         _check(lib().gm_set_variant(self._h, v))
+
+    def set_param(self, name, value):
+        """Named tuning knob (include/gmhip.h, gm_set_param); results do not depend on it."""
+        _check(lib().gm_set_param(self._h, name.encode("ascii"), int(value)))
 
     def timing_reserve(self, n):
         _check(lib().gm_timing_reserve(self._h, n))

@@ -79,18 +79,19 @@ struct gm_lk_args {
 GM_FOR_EACH_LEN(GM_DECL_LK)
 #undef GM_DECL_LK
 
-// K1P launchers, one per guide length (gm_inst_lk.hip): grid = upper bound of the chunk count
+// K1P launchers, one per guide length (gm_inst_lk.hip): grid = upper bound of the chunk count, a multiple of 128
 #define GM_DECL_PG(LEN)                                                                                      \
     int gm_launch_pg_L##LEN(gm_index* idx, const gm_pg_blocks* blocks, const gm_pg_chunk* chunks,             \
-                            const int* n_chunks, int64_t grid, int64_t n_q, int k, int thr0, int cap,          \
-                            int cap_x, uint32_t* hits, int32_t* n_hits, hipStream_t st);
+                            const int* n_chunks, int64_t grid, int64_t n_q, int k, int thr0, uint32_t* lists,  \
+                            hipStream_t st);
 GM_FOR_EACH_LEN(GM_DECL_PG)
 #undef GM_DECL_PG
 
 // K1P host side (gm_pigeon.hip).  gm_pg_plan: number of blocks B (0 = the plain scan is the better choice);
 // gm_pg_prepare: block-sorted pool copies for B; gm_pg_candidates: group the candidates in idx->d_q;
-// gm_pg_scan: the K1P launch; gm_pg_merge: slot lists -> top k; gm_pg_incomplete: rows whose merged list is not full (device list + count,
-// synchronises the stream); gm_pg_gather / gm_pg_scatter: move those rows to / from a compact query.
+// gm_pg_scan: the K1P launch; gm_pg_merge: hit lists -> top k + the list of rows that are not exact;
+// gm_pg_incomplete: how many such rows (synchronises the stream); gm_pg_gather / gm_pg_scatter: move those rows
+// to / from a compact query.
 int gm_pg_plan(int64_t n_db, int64_t n_q, int L, int k, double p_match, int max_len, int* expand, int* len0);
 int gm_pg_pool_stats(gm_index* idx, hipStream_t st, double* p_match);
 int gm_pg_prepare(gm_index* idx, int B, int expand, int len0, hipStream_t st);
@@ -98,8 +99,7 @@ int gm_pg_candidates(gm_index* idx, int64_t n_q, hipStream_t st);
 int gm_pg_scan(gm_index* idx, int64_t n_q, int k, hipStream_t st);
 int gm_pg_merge(gm_index* idx, int kcap, int64_t n_q, int k, int32_t* ids, int32_t* dists, int32_t* counts,
                 bool nearest, hipStream_t st);
-int gm_pg_incomplete(gm_index* idx, int64_t n_q, int need, const int32_t* counts, const int32_t* d1,
-                     int64_t* n_inc, int64_t* pairs_evaluated, hipStream_t st);
+int gm_pg_incomplete(gm_index* idx, int64_t* n_inc, int64_t* pairs_evaluated, hipStream_t st);
 int gm_pg_gather(gm_index* idx, int64_t n_inc, int k, bool nearest, const uint2** q2, int32_t** ids2,
                  int32_t** dists2, int32_t** counts2, hipStream_t st);
 int gm_pg_scatter(gm_index* idx, int64_t n_inc, int k, bool nearest, int32_t* ids, int32_t* dists, int32_t* counts,
@@ -108,6 +108,7 @@ int gm_pg_blocks_of(const gm_index* idx);
 int gm_pg_radius(const gm_index* idx);      // r of the layout in use: every pair within r is enumerated
 int gm_pg_count_incomplete(gm_index* idx, int64_t n, int need, const int32_t* counts, const int32_t* d1,
                            int64_t* n_bad, hipStream_t st);      // rows that are not full; synchronises
+int gm_pg_set_param(gm_index* idx, const char* name, int value);
 void gm_pg_free(gm_index* idx);
 
 // K2L launchers, one per guide length (gm_inst_lv.hip)

@@ -1,6 +1,7 @@
 // gm_inst_lk.hip -- instantiates the K1L look-up Hamming kernels for ONE guide length (-DGM_LEN=<L>).
 #include "gm_host.h"
 #include "gm_lookup.hip.h"
+#include "gm_pigeon_scan.hip.h"
 
 #ifndef GM_LEN
 #error "compile with -DGM_LEN=<guide length>"
@@ -49,11 +50,11 @@ int launch_lk(gm_index* idx, const gm_lk_args& a, hipStream_t st) {
 
 template <int L>
 int launch_pg_cfg(gm_index* idx, const gm_pg_blocks* blocks, const gm_pg_chunk* chunks, const int* n_chunks,
-                  int64_t grid, int64_t n_q, int k, int thr0, int cap, int cap_x, uint32_t* hits, int32_t* n_hits,
-                  hipStream_t st) {
-    const size_t lds = 2 * (size_t)gm::lk_tile_bytes(L);
+                  int64_t grid, int64_t n_q, int k, int thr0, uint32_t* lists, hipStream_t st) {
+    (void)idx;
+    const size_t lds = gm::pg_lds_bytes(L);
     hipLaunchKernelGGL((gm::k_hamming_scan_pg<L>), dim3((unsigned)grid), dim3(gm::WAVE), lds, st, *blocks, chunks,
-                       n_chunks, (int)idx->n_lk_tiles, idx->d_q, n_q, k, thr0, cap, cap_x, hits, n_hits);
+                       n_chunks, idx->d_q, n_q, k, thr0, lists);
     HIP_TRY(hipGetLastError());
     return GM_OK;
 }
@@ -68,7 +69,7 @@ int GM_CAT(gm_launch_lk_L, GM_LEN)(gm_index* idx, const gm_lk_args* a, hipStream
 }
 
 int GM_CAT(gm_launch_pg_L, GM_LEN)(gm_index* idx, const gm_pg_blocks* blocks, const gm_pg_chunk* chunks,
-                                   const int* n_chunks, int64_t grid, int64_t n_q, int k, int thr0, int cap,
-                                   int cap_x, uint32_t* hits, int32_t* n_hits, hipStream_t st) {
-    return launch_pg_cfg<GM_LEN>(idx, blocks, chunks, n_chunks, grid, n_q, k, thr0, cap, cap_x, hits, n_hits, st);
+                                   const int* n_chunks, int64_t grid, int64_t n_q, int k, int thr0, uint32_t* lists,
+                                   hipStream_t st) {
+    return launch_pg_cfg<GM_LEN>(idx, blocks, chunks, n_chunks, grid, n_q, k, thr0, lists, st);
 }

@@ -19,7 +19,6 @@
 #define GM_LK_W10 6     /* waves per SIMD asked for with a 5/10-key register list at L <= 20 */
 #endif
 #include "gm_bitslice.hip.h"
-#include "gm_pg_types.h"
 #include <type_traits>
 
 namespace gm {
@@ -328,210 +327,6 @@ __global__ __launch_bounds__(WAVE, lk_min_waves(L, KCAP)) void k_hamming_knn_lk(
         }
         list.store(k, qi, ids, dists, counts, NEAREST);
     }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// K1P -- pigeonhole-partitioned scan (exact for neighbours within r = B - 1 mismatches).
-// The guide is cut into B blocks of positions.  Two sequences with at most B - 1 mismatches agree
-// exactly on at least one block, so for block b it is enough to compare a candidate with the pool targets
-// that have the same bases on block b: the pool is stored B times, stable-sorted by the block's value
-// (ids ascend inside a bucket), with one one-hot table per copy; candidates are grouped by the same value
-// into chunks of <= 64 that never straddle a bucket.  Workgroup = one chunk: K1L's look-ups, adder trees
-// and comparator over the tiles that cover the bucket (rounded outwards; hits outside the bucket's own
-// range are ignored, they belong to another workgroup) with the bound fixed at d < B.
-// Inside a bucket hits are frequent (the pairs already share a block) and only one to three lanes of a wave
-// take part in each visit of the slow path, so it does the minimum: APPEND (distance << 27 | position) to the
-// lane's slot list hits[b][slot][candidate] in HBM -- no sorted register list, two counters instead of a
-// list for the bound, and one instantiation per guide length serves every k.  k_merge_hits (one thread per candidate, all lanes busy) translates positions
-// to pool ids, drops the pairs that were found under several blocks and selects the top k.  A candidate
-// whose merged list is full is exact (everything within r was enumerated); the others, and those whose slot
-// list overflowed, are re-scanned by the plain kernel (host side, gmhip.hip).
-// ---------------------------------------------------------------------------------------------------
-// The append path.  Both halves of the group go through ONE divergent loop (a lane rarely has more than one
-// hit, so the loop usually runs once for all hit lanes of the wave together); the slot address is a running
-// pointer; the distance is read back from the bit-sliced counter with bit-field extracts.
-// Bound tightening without a sorted list (positions ascend with the pool ids inside a bucket, so a later
-// target never wins a tie): once k hits were appended (all with d < thr0) nothing at distance thr0 - 1 can
-// enter the top k any more -> d < thr0 - 1; once k of them had d < thr0 - 1 -> d < thr0 - 2.  k == 1: the
-// bound simply follows the best distance so far.  (A hit flagged under an older, looser bound may still be
-// appended: harmless, the merge selects.)
-template <int L>
-__device__ __forceinline__ void pg_append_hits(uint32_t h0, uint32_t h1, const uint32_t (&c0)[5],
-                                               const uint32_t (&c1)[5], int id0, int lo, int hi, int k, int thr0,
-                                               int add, int cap, int64_t slot_stride, uint32_t*& wp, int& cnt,
-                                               int& cnt_lt, int& thr, uint32_t (&Tb)[5]) {
-    while ((h0 | h1) != 0u) {
-        const bool low = h0 != 0u;
-        const uint32_t w = low ? h0 : h1;
-        const int j = __builtin_ctz(w);
-        const uint32_t rest = w & (w - 1u);
-        h0 = low ? rest : h0;
-        h1 = low ? h1 : rest;
-        uint32_t m = 0;
-#pragma unroll
-        for (int i = 4; i >= 0; --i) m = (m << 1) | __builtin_amdgcn_ubfe(low ? c0[i] : c1[i], (uint32_t)j, 1u);
-        const int d = L - (int)m + add;      // + the mismatches known to sit on positions the table leaves out
-        const int pos = id0 + j + (low ? 0 : 32);
-        if (pos >= lo && pos < hi) {
-            if (cnt < cap) *wp = ((uint32_t)d << ID_BITS) | (uint32_t)pos;
-            wp += slot_stride;
-            ++cnt;
-            int nt;
-            if (k == 1) {
-                nt = d;
-            } else {
-                cnt_lt += d < thr0 - 1 ? 1 : 0;
-                nt = thr0 - (cnt >= k ? 1 : 0) - (cnt_lt >= k ? 1 : 0);
-            }
-            if (nt < thr) {
-                thr = nt;
-                lk_set_bound(Tb, L, thr - add);
-            }
-        }
-    }
-}
-
-template <int L>
-__device__ __forceinline__ void pg_process_group(const LkGroupRegs<L>& r, int id0, int lo, int hi, int k, int thr0,
-                                                 int add, int cap, int64_t slot_stride, uint32_t*& wp, int& cnt,
-                                                 int& cnt_lt, int& thr, uint32_t (&Tb)[5]) {
-    uint32_t c0[5], c1[5];
-    const uint32_t h0 = lk_eval_half<L>(r.m0, Tb, c0);
-    const uint32_t h1 = lk_eval_half<L>(r.m1, Tb, c1);
-    if (__builtin_amdgcn_ballot_w64((h0 | h1) != 0u) != 0ull)
-        pg_append_hits<L>(h0, h1, c0, c1, id0, lo, hi, k, thr0, add, cap, slot_stride, wp, cnt, cnt_lt, thr, Tb);
-}
-
-// hits: [B][cap][n_q] keys (distance << 27 | position in the copy) followed by [n_expand][cap_x][n_q] for the
-// neighbour lists; n_hits: [B + n_expand][n_q] (a count above the list's capacity = overflow)
-template <int L>
-__global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
-    gm_pg_blocks P, const gm_pg_chunk* __restrict__ chunks, const int* __restrict__ n_chunks, int n_tiles,
-    const uint2* __restrict__ q, int64_t n_q, int k, int thr0, int cap, int cap_x, uint32_t* __restrict__ hits,
-    int32_t* __restrict__ n_hits) {
-    extern __shared__ __align__(16) uint32_t smem[];
-    constexpr int TILE_W = lk_tile_bytes(L) / 4;
-    constexpr int GW = lk_group_words(L);
-    constexpr int TILE_IDS = LK_TG * LK_GROUP;
-    if ((int)blockIdx.x >= *n_chunks) return;
-    const gm_pg_chunk ch = chunks[blockIdx.x];
-    const uint32_t* __restrict__ table = P.table[ch.b];
-    uint32_t* tiles = smem;
-    const int lane = threadIdx.x;
-    const bool valid = lane < ch.cn;
-    const int64_t qi = valid ? (int64_t)P.cperm[ch.b][ch.c0 + lane] : 0;
-    const uint2 qv = valid ? q[qi] : make_uint2(0u, 0u);
-
-    // L = positions evaluated: the copy's table leaves out P.skip_len positions of its own block (all pairs
-    // of the bucket agree there), so table position p is sequence position p (+ skip_len behind the gap)
-    const int skip_start = P.skip[ch.b], skip_len = P.skip_len;
-    const uint32_t* ptr[L];
-#pragma unroll
-    for (int p = 0; p < L; ++p) {
-        const int sp = p >= skip_start ? p + skip_len : p;
-        uint32_t code = ((qv.x >> sp) & 1u) | (((qv.y >> sp) & 1u) << 1);
-        ptr[p] = tiles + p * 8 + (int)code * 2;
-    }
-    const int add = ch.add;
-    int thr = valid ? thr0 : 0;
-    uint32_t Tb[5];
-    lk_set_bound(Tb, L, thr - add);
-    // next free slot of this lane in list ch.lst (slot stride n_q)
-    const bool own = ch.lst < P.n_blocks;
-    const int my_cap = own ? cap : cap_x;
-    uint32_t* wp = hits + (own ? (int64_t)ch.lst * cap : (int64_t)P.n_blocks * cap + (int64_t)(ch.lst - P.n_blocks) * cap_x) * n_q + qi;
-    int cnt = 0, cnt_lt = 0;
-
-    // tiles covering the bucket's targets [lo, hi) in this copy, widened to an even tile range for the
-    // double-buffered staging; only the 64-target groups [g_lo, g_hi) that overlap the bucket are evaluated
-    const int lo = P.toff[ch.b][ch.v], hi = P.toff[ch.b][ch.v + 1];
-    int t0 = (lo / TILE_IDS) & ~1;
-    int t1 = ((hi + TILE_IDS - 1) / TILE_IDS + 1) & ~1;
-    if (t1 > n_tiles) t1 = n_tiles;
-    if (hi <= lo) t1 = t0;
-    const int g_lo = lo / LK_GROUP, g_hi = (hi + LK_GROUP - 1) / LK_GROUP;
-
-    if (t0 < t1) lk_stage<L>(table, t0, tiles, lane);
-    for (int t = t0; t < t1; t += 2) {
-        lk_stage_wait();
-        lk_stage<L>(table, t + 1, tiles + TILE_W, lane);
-#pragma unroll
-        for (int gl = 0; gl < LK_TG; ++gl) {
-            const int g = t * LK_TG + gl;
-            if (g < g_lo || g >= g_hi) continue;      // wave-uniform
-            LkGroupRegs<L> r;
-            if (gl == 0) lk_read_group<L, 0 * GW>(r, ptr);
-            if (gl == 1) lk_read_group<L, 1 * GW>(r, ptr);
-            if (gl == 2) lk_read_group<L, 2 * GW>(r, ptr);
-            if (gl == 3) lk_read_group<L, 3 * GW>(r, ptr);
-            pg_process_group<L>(r, g * LK_GROUP, lo, hi, k, thr0, add, my_cap, n_q, wp, cnt, cnt_lt, thr, Tb);
-        }
-        lk_stage_wait();
-        if (t + 2 < t1) lk_stage<L>(table, t + 2, tiles, lane);
-#pragma unroll
-        for (int gl = 0; gl < LK_TG; ++gl) {
-            const int g = (t + 1) * LK_TG + gl;
-            if (g < g_lo || g >= g_hi) continue;
-            LkGroupRegs<L> r;
-            if (gl == 0) lk_read_group<L, TILE_W + 0 * GW>(r, ptr);
-            if (gl == 1) lk_read_group<L, TILE_W + 1 * GW>(r, ptr);
-            if (gl == 2) lk_read_group<L, TILE_W + 2 * GW>(r, ptr);
-            if (gl == 3) lk_read_group<L, TILE_W + 3 * GW>(r, ptr);
-            pg_process_group<L>(r, g * LK_GROUP, lo, hi, k, thr0, add, my_cap, n_q, wp, cnt, cnt_lt, thr, Tb);
-        }
-    }
-    if (valid && cnt > 0) n_hits[(int64_t)ch.lst * n_q + qi] = cnt;      // (the counts are zeroed before the launch)
-}
-
-// K1P merge: one thread per candidate folds its slot lists into the top k (duplicates taken once).
-// A slot list that overflowed makes the row incomplete (count 0 / distance -1): the host re-scans it.
-constexpr int PG_MERGE_SPLIT = 4;      // threads per candidate in k_merge_hits
-
-// FOUR adjacent lanes per candidate, each folding every fourth slot list into its own register list (the
-// kernel is bound by the count -> key -> permutation load chains, so shorter chains on more lanes pay), then
-// lane 0 of the quad takes the other three lists over by shuffles and writes the row.
-template <int KCAP>
-__global__ void k_merge_hits(gm_pg_blocks P, int cap, int cap_x, const uint32_t* __restrict__ hits,
-                             const int32_t* __restrict__ n_hits, int64_t n_q, int k, int32_t* __restrict__ ids,
-                             int32_t* __restrict__ dists, int32_t* __restrict__ counts, int nearest) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int sub = (int)(t % PG_MERGE_SPLIT);
-    const int64_t qi_raw = t / PG_MERGE_SPLIT;
-    const bool valid = qi_raw < n_q;
-    const int64_t qi = valid ? qi_raw : n_q - 1;      // (whole quads stay in the shuffles)
-    RegList<KCAP> list;
-    list.init(k, nullptr, 0);
-    int overflow = 0;
-    const int n_lists = P.n_blocks + P.n_expand;
-    for (int l = sub; l < n_lists; l += PG_MERGE_SPLIT) {
-        const bool own = l < P.n_blocks;
-        const int lcap = own ? cap : cap_x;
-        int c = n_hits[(int64_t)l * n_q + qi];
-        if (c > lcap) {
-            overflow = 1;
-            c = lcap;
-        }
-        const int32_t* __restrict__ perm = P.perm[own ? l : (l - P.n_blocks) / P.xne];
-        const uint32_t* slot0 =
-            hits + (own ? (int64_t)l * cap : (int64_t)P.n_blocks * cap + (int64_t)(l - P.n_blocks) * cap_x) * n_q + qi;
-        for (int i = 0; i < c; ++i) {
-            const uint32_t key = slot0[(int64_t)i * n_q];
-            list.insert_unique((key & ~ID_MASK) | (uint32_t)perm[key & ID_MASK]);
-        }
-    }
-    // quad reduction: lane 0 of the quad inserts the entries of lanes 1..3
-#pragma unroll
-    for (int s = 1; s < PG_MERGE_SPLIT; ++s) {
-        overflow |= __shfl_down(overflow, s, PG_MERGE_SPLIT);
-#pragma unroll
-        for (int i = 0; i < KCAP; ++i) {
-            const uint32_t v = __shfl_down(list.v[i], s, PG_MERGE_SPLIT);
-            if (sub == 0 && v != 0u && v != RegList<KCAP>::EMPTY) list.insert_unique(v - 1u);
-        }
-    }
-    if (sub != 0 || !valid) return;
-    if (overflow) list.init(k, nullptr, 0);
-    list.store(k, qi, ids, dists, counts, nearest != 0);
 }
 
 // fold per-segment raw RegList<KCAP> lists [n_seg][n_q][KCAP] into the final top-k.  One thread per candidate.

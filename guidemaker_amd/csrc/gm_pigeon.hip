@@ -1,21 +1,22 @@
 // gm_pigeon.hip -- host side of K1P, the pigeonhole-partitioned Hamming scan (kernels: k_hamming_scan_pg and
-// k_merge_hits in gm_lookup.hip.h).  Exact k-NN without evaluating all pairs:
+// k_merge_hits in gm_pigeon_scan.hip.h).  Exact k-NN without evaluating all pairs:
 //
 //   two sequences with at most r mismatches agree exactly on at least one of r + 1 disjoint blocks of
 //   positions; with the one-substitution neighbour buckets of X of the blocks scanned as well, B blocks
 //   serve r = B + X - 1 (see gm_pg_plan).  Pool side (once per index and layout): for every block a stable
-//   sort of the pool by the block's value (ids ascend inside a bucket -> the kernels' strict test keeps the
-//   canonical (distance, id) order), the permutation, the bucket offsets and a one-hot table of the sorted
-//   copy.  Query side: the candidates are grouped by the same values and cut into chunks of <= 64 that do not
-//   straddle buckets; one workgroup scans one chunk against one bucket (its own, or a neighbour bucket of an
-//   expansion block) and appends its hits to the candidate's slot list; the lists of a candidate are merged
-//   (duplicates dropped).  Work on S1: 5.6 % of all pairs (L = 20, blocks 5,5,5,5, three of them expanded).
-//   A candidate whose merged list is full is exact: every target within r was enumerated.  The rest (the
-//   layout is chosen so that they are few) are re-scanned by the plain two-phase kernel (gmhip.hip).
+//   sort of the pool by the block's value (ids ascend inside a bucket), every bucket padded to a multiple of 128
+//   positions (one LDS-DMA unit of the scan; padding matches nothing), a record {planes, pool id} per position and
+//   a one-hot table of the copy.  Query side: the candidates are grouped by the same values and cut into chunks of
+//   <= 64 that do not straddle buckets; one workgroup scans one chunk against a run of target buckets (its own
+//   bucket and / or neighbour buckets of an expansion block) and appends its hits to the candidates' hit lists; the
+//   lists of a candidate are merged (duplicates dropped).  Work on S1: 5 % of all pairs (L = 20, blocks 5,5,5,5,
+//   three of them expanded).  A candidate whose merged list is full is exact: every target within r was
+//   enumerated.  The rest (the layout is chosen so that they are few) are re-scanned by the plain two-phase
+//   kernel (gmhip.hip).
 //
 // Everything here is integer bookkeeping on the device: block keys, a stable rocPRIM sort per pool copy, one
-// counting sort of the candidates for all blocks, a chunk table built by a count / scan / fill triple.  No
-// host round trip except the read-backs of the incomplete-row counts.
+// counting sort of the candidates for all blocks, a chunk table built by a count / scan / fill triple.  The only
+// host round trip per query is the read-back of the incomplete-row count.
 #include "gm_host.h"
 
 #include <cmath>
@@ -24,7 +25,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
-#include "gm_lookup.hip.h"      // k_to_onehot, tile geometry
+#include "gm_pigeon_scan.hip.h"      // kernels, geometry
 
 namespace {
 
@@ -32,24 +33,19 @@ struct PgLayoutArg {              // per-block geometry + offsets, by value
     int B;
     int ebase[GM_PG_MAXB + 1];    // first entry of block b in the flattened (block, bucket) list
     const int32_t* coff[GM_PG_MAXB];
-    const int32_t* toff[GM_PG_MAXB];
-    // expansion: after the ebase[B] (block, bucket) entries come, for each of the X expansion blocks (blocks
-    // 0 .. X-1, all of the same length), nbx * xne entries (bucket, neighbour)
-    int X;                        // expansion blocks, 0 = none
-    int nbx;                      // buckets of an expansion block
-    int xne;                      // neighbours per bucket = 3 x block length
-    int xskip;                    // leading block positions the copy's table leaves out
+    const int32_t* gcnt[GM_PG_MAXB];
+    int X;                        // expansion blocks (blocks 0 .. X-1), 0 = none
+    int xne;                      // neighbour buckets per bucket of an expansion block = 3 x block length
+    int S;                        // workgroups the 1 + xne target buckets of an expansion chunk are split over
+    int per;                      // target buckets per such workgroup
+    int skip_len;
     int n_entries;
-};
-
-struct PgEntry {
-    int b, vc, vt, lst, add;      // block, candidates' bucket, target bucket, slot list, known hidden mismatches
 };
 
 struct PgCounters {               // device-resident
     int n_chunks;
     int n_inc;
-    unsigned long long pairs;     // pairs the last K1P launch evaluates (chunks x 64 x scanned targets)
+    unsigned long long pairs;     // pairs the last K1P launch evaluates (chunks x 64 x scanned groups x 64)
     int n_bad;                    // re-scanned rows that did not fill under the guessed bound
     int pad;
 };
@@ -210,12 +206,38 @@ __global__ __launch_bounds__(1024) void k_cand_scatter(const uint2* __restrict__
     }
 }
 
-__global__ __launch_bounds__(256) void k_gather_planes(const uint2* __restrict__ planes, const uint32_t* __restrict__ perm,
-                                                       int64_t n, uint2* __restrict__ out, int32_t* __restrict__ perm_out) {
+// sorted position i (key v = keys[i], pool row rows[i]) -> position goff[v] * 64 + (i - raw_off[v]) of the padded copy
+__global__ __launch_bounds__(256) void k_scatter_recs(const uint2* __restrict__ planes, const uint32_t* __restrict__ keys,
+                                                      const uint32_t* __restrict__ rows, int64_t n,
+                                                      const int32_t* __restrict__ raw_off, const int32_t* __restrict__ goff,
+                                                      uint4* __restrict__ recs) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    out[i] = planes[perm[i]];
-    perm_out[i] = (int32_t)perm[i];
+    const uint32_t v = keys[i], row = rows[i];
+    const int64_t pos = (int64_t)goff[v] * gm::LK_GROUP + (i - raw_off[v]);
+    const uint2 e = planes[row];
+    recs[pos] = make_uint4(e.x, e.y, row, 0u);
+}
+
+// one-hot table of a padded copy (format of gm::k_to_onehot; padding positions -- id 0xffffffff -- set no bit, so
+// they match nothing); the table leaves out sequence positions [skip_start, skip_start + skip_len), L = positions kept
+__global__ __launch_bounds__(256) void k_onehot_recs(const uint4* __restrict__ recs, uint32_t* __restrict__ table,
+                                                     int64_t n_groups, int L, int skip_start, int skip_len) {
+    const int gw = gm::lk_group_words(L);
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_groups * gw) return;
+    const int64_t G = t / gw;
+    const int w = (int)(t % gw);
+    int p = w >> 3;
+    const int b = (w >> 1) & 3, h = w & 1;
+    if (p >= skip_start) p += skip_len;
+    uint32_t out = 0;
+    for (int j = 0; j < 32; ++j) {
+        const uint4 e = recs[G * gm::LK_GROUP + 32 * h + j];
+        const uint32_t code = ((e.x >> p) & 1u) | (((e.y >> p) & 1u) << 1);
+        out |= (uint32_t)(e.z != 0xffffffffu && code == (uint32_t)b) << j;
+    }
+    table[t] = out;
 }
 
 __device__ __forceinline__ void pg_entry(const PgLayoutArg& A, int e, int& b, int& v) {
@@ -224,39 +246,14 @@ __device__ __forceinline__ void pg_entry(const PgLayoutArg& A, int e, int& b, in
     v = e - A.ebase[b];
 }
 
-// entry -> (block, candidates' bucket, target bucket, list, add).  Neighbour e of bucket v replaces the base at
-// block position e / 3 by one of the three others; if that position is one the table leaves out, the scan
-// cannot see the mismatch and the chunk carries add = 1.
-__device__ __forceinline__ PgEntry pg_entry_ex(const PgLayoutArg& A, int e) {
-    PgEntry r;
-    if (e < A.ebase[A.B]) {
-        pg_entry(A, e, r.b, r.vc);
-        r.vt = r.vc;
-        r.lst = r.b;
-        r.add = 0;
-        return r;
-    }
-    const int rem = e - A.ebase[A.B], per = A.nbx * A.xne;
-    const int xb = rem / per, x = rem % per;
-    const int v = x / A.xne, ne = x % A.xne;
-    const int pidx = ne / 3, alt = ne % 3;
-    const int code = (v >> (2 * pidx)) & 3;
-    r.b = xb;
-    r.vc = v;
-    r.vt = (v & ~(3 << (2 * pidx))) | (((code + 1 + alt) & 3) << (2 * pidx));
-    r.lst = A.B + xb * A.xne + ne;
-    r.add = pidx < A.xskip ? 1 : 0;
-    return r;
-}
-
-// chunks per entry (none when either side of the entry is empty)
+// chunk-table entries of (block, bucket) entry e: one per chunk of <= 64 candidates and per run of target buckets
 __global__ __launch_bounds__(256) void k_chunk_count(PgLayoutArg A, int* __restrict__ nch) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= A.n_entries) return;
-    const PgEntry en = pg_entry_ex(A, e);
-    const int cnt = A.coff[en.b][en.vc + 1] - A.coff[en.b][en.vc];
-    const int tgt = A.toff[en.b][en.vt + 1] - A.toff[en.b][en.vt];
-    nch[e] = tgt > 0 ? (cnt + 63) / 64 : 0;
+    int b, v;
+    pg_entry(A, e, b, v);
+    const int cnt = A.coff[b][v + 1] - A.coff[b][v];
+    nch[e] = (cnt + 63) / 64 * (b < A.X ? A.S : 1);
 }
 
 // n_chunks = last exclusive offset + last count
@@ -264,32 +261,30 @@ __global__ void k_chunk_total(const int* __restrict__ nch, const int* __restrict
     if (threadIdx.x == 0 && blockIdx.x == 0) *total = n > 0 ? cbase[n - 1] + nch[n - 1] : 0;
 }
 
-__global__ __launch_bounds__(256) void k_fill_chunks(PgLayoutArg A, const int* __restrict__ cbase, int n_tiles,
+__global__ __launch_bounds__(256) void k_fill_chunks(PgLayoutArg A, const int* __restrict__ cbase,
                                                      gm_pg_chunk* __restrict__ chunks, PgCounters* __restrict__ ctr) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= A.n_entries) return;
-    const PgEntry en = pg_entry_ex(A, e);
-    const int c0 = A.coff[en.b][en.vc], c1 = A.coff[en.b][en.vc + 1];
-    const int lo = A.toff[en.b][en.vt], hi = A.toff[en.b][en.vt + 1];
-    if (c1 <= c0 || hi <= lo) return;
+    int b, v;
+    pg_entry(A, e, b, v);
+    const int c0 = A.coff[b][v], c1 = A.coff[b][v + 1];
+    if (c1 <= c0) return;
+    const bool ex = b < A.X;
+    const int n_bk = ex ? 1 + A.xne : 1, n_sub = ex ? A.S : 1, per = ex ? A.per : 1;
     int w = cbase[e];
-    for (int c = c0; c < c1; c += 64, ++w)
-        chunks[w] = gm_pg_chunk{en.b, en.vt, c, c1 - c < 64 ? c1 - c : 64, en.lst, en.add};
-    // the 64-target groups the kernel will evaluate for this bucket (same rounding as k_hamming_scan_pg)
-    (void)n_tiles;
-    const int g_lo = lo / gm::LK_GROUP, g_hi = (hi + gm::LK_GROUP - 1) / gm::LK_GROUP;
-    const unsigned long long pairs =
-        (unsigned long long)((c1 - c0 + 63) / 64) * 64ull * (unsigned long long)(g_hi - g_lo) * gm::LK_GROUP;
-    atomicAdd(&ctr->pairs, pairs);
-}
-
-__global__ __launch_bounds__(256) void k_collect_incomplete(const int32_t* __restrict__ counts, const int32_t* __restrict__ d1,
-                                                            int64_t n_q, int need, int32_t* __restrict__ inc,
-                                                            PgCounters* __restrict__ ctr) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_q) return;
-    const bool incomplete = counts != nullptr ? counts[i] < need : d1[i] < 0;
-    if (incomplete) inc[atomicAdd(&ctr->n_inc, 1)] = (int32_t)i;
+    for (int s = 0; s < n_sub; ++s) {
+        const int e_lo = s * per, e_hi = e_lo + per < n_bk ? e_lo + per : n_bk;
+        const int lst = ex ? b * A.S + s : A.X * A.S + (b - A.X);
+        for (int c = c0; c < c1; c += 64, ++w)
+            chunks[w] = gm_pg_chunk{b, v, c, c1 - c < 64 ? c1 - c : 64, e_lo, e_hi, lst, 0};
+    }
+    // the 64 x 64 groups the scan evaluates for this candidate bucket
+    unsigned long long groups = 0;
+    for (int t = 0; t < n_bk; ++t) {
+        int add;
+        groups += (unsigned long long)A.gcnt[b][gm::pg_target_bucket(v, t, A.skip_len, add)];
+    }
+    atomicAdd(&ctr->pairs, (unsigned long long)((c1 - c0 + 63) / 64) * 64ull * groups * gm::LK_GROUP);
 }
 
 __global__ __launch_bounds__(256) void k_count_incomplete(const int32_t* __restrict__ counts, const int32_t* __restrict__ d1,
@@ -342,15 +337,18 @@ struct gm_pigeon {
     int max_bucket[GM_PG_MAXB]{};      // largest bucket of every pool copy
     int expand = 0;                    // X: the neighbour buckets of blocks 0 .. X-1 are scanned too, B blocks then
                                        // serve radius r = B + X - 1
-    int cap_x = 0;                     // slots per neighbour list
     int skip_len = 0;                  // positions of its own block each copy's table leaves out
     int Lp = 0;                        // positions the scan evaluates = L - skip_len (>= 10)
+    int tune_sub = 4;                  // workgroups per expansion chunk (gm_set_param "pg_sub")
     int bstart[GM_PG_MAXB]{}, blen[GM_PG_MAXB]{};
     int ebase[GM_PG_MAXB + 1]{};
     // pool side
     uint32_t* table[GM_PG_MAXB]{};
-    int32_t* perm[GM_PG_MAXB]{};
-    int32_t* toff[GM_PG_MAXB]{};
+    uint4* recs[GM_PG_MAXB]{};
+    int32_t* goff[GM_PG_MAXB]{};
+    int32_t* gcnt[GM_PG_MAXB]{};
+    int32_t* raw_off = nullptr;        // build scratch: bucket offsets of the unpadded sorted order
+    int64_t raw_off_cap = 0;
     // query side (grow-only)
     uint32_t* cperm[GM_PG_MAXB]{};
     int64_t cperm_cap[GM_PG_MAXB]{};
@@ -365,14 +363,11 @@ struct gm_pigeon {
     int64_t chunks_cap = 0;
     PgCounters* ctr = nullptr;
     int64_t grid = 0;
-    uint32_t* keys = nullptr;     // slot lists [B][cap][n_q]
-    int64_t keys_cap = 0;
-    int32_t* n_hits = nullptr;    // [B][n_q]
-    int64_t n_hits_cap = 0;
-    int cap = 0;
-    int64_t cap_nq = -1;          // candidate count / expansion the capacities were sized for
-    int cap_x_for = -1;
-    bool cap_k1 = false;
+    uint32_t* lists = nullptr;    // hit lists (gm_pg_blocks::loff / lcap)
+    int64_t lists_cap = 0;
+    int64_t cap_nq = -1;          // candidate count / layout the list capacities were sized for
+    int cap_x_for = -1, cap_sub_for = -1;
+    double mem_limit = 0.0;
     gm_pg_blocks blocks{};
     int32_t* inc = nullptr;
     int64_t inc_cap = 0;
@@ -410,16 +405,18 @@ int ensure_sort_buffers(gm_pigeon* pg, int64_t n) {
 void free_pool_side(gm_pigeon* pg) {
     for (int b = 0; b < GM_PG_MAXB; ++b) {
         if (pg->table[b]) (void)hipFree(pg->table[b]);
-        if (pg->perm[b]) (void)hipFree(pg->perm[b]);
-        if (pg->toff[b]) (void)hipFree(pg->toff[b]);
+        if (pg->recs[b]) (void)hipFree(pg->recs[b]);
+        if (pg->goff[b]) (void)hipFree(pg->goff[b]);
+        if (pg->gcnt[b]) (void)hipFree(pg->gcnt[b]);
         if (pg->coff[b]) (void)hipFree(pg->coff[b]);
         pg->table[b] = nullptr;
-        pg->perm[b] = nullptr;
-        pg->toff[b] = nullptr;
+        pg->recs[b] = nullptr;
+        pg->goff[b] = nullptr;
+        pg->gcnt[b] = nullptr;
         pg->coff[b] = nullptr;
     }
     pg->B = 0;
-    pg->cap = 0;
+    pg->cap_nq = -1;
 }
 
 double log_choose(int n, int r) { return std::lgamma(n + 1.0) - std::lgamma(r + 1.0) - std::lgamma(n - r + 1.0); }
@@ -539,20 +536,31 @@ int gm_pg_pool_stats(gm_index* idx, hipStream_t st, double* p_match) {
 int gm_pg_blocks_of(const gm_index* idx) { return idx->pg ? idx->pg->B : 0; }
 int gm_pg_radius(const gm_index* idx) { return idx->pg ? idx->pg->B + idx->pg->expand - 1 : 0; }
 
+int gm_pg_set_param(gm_index* idx, const char* name, int value) {
+    if (!idx->pg) idx->pg = new gm_pigeon();
+    if (std::strcmp(name, "pg_sub") == 0) {
+        if (value < 1 || value > 19) return gm_fail(GM_ERR_ARG, "pg_sub: 1..19");
+        idx->pg->tune_sub = value;
+        return GM_OK;
+    }
+    return gm_fail(GM_ERR_ARG, std::string("unknown parameter ") + name);
+}
+
 void gm_pg_free(gm_index* idx) {
     gm_pigeon* pg = idx->pg;
     if (!pg) return;
     free_pool_side(pg);
     for (int b = 0; b < GM_PG_MAXB; ++b)
         if (pg->cperm[b]) (void)hipFree(pg->cperm[b]);
-    void* bufs[] = {pg->k0, pg->k1, pg->r0, pg->r1, pg->sort_tmp, pg->nch, pg->cbase, pg->hist, pg->cursor, pg->chunks, pg->ctr, pg->keys,
-                    pg->n_hits, pg->inc, pg->q2, pg->ids2, pg->dists2, pg->counts2};
+    void* bufs[] = {pg->k0, pg->k1, pg->r0, pg->r1, pg->sort_tmp, pg->nch, pg->cbase, pg->hist, pg->cursor, pg->chunks, pg->ctr,
+                    pg->lists, pg->raw_off, pg->inc, pg->q2, pg->ids2, pg->dists2, pg->counts2};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     delete pg;
     idx->pg = nullptr;
 }
 
+// Block-sorted, bucket-padded pool copies for the layout (B blocks, `expand` of them of len0 bases).
 int gm_pg_prepare(gm_index* idx, int B, int expand, int len0, hipStream_t st) {
     const int L = idx->L;
     int blen[GM_PG_MAXB];
@@ -583,41 +591,65 @@ int gm_pg_prepare(gm_index* idx, int B, int expand, int len0, hipStream_t st) {
     pg->skip_len = base;
     if (L - pg->skip_len < 10) pg->skip_len = L - 10;
     pg->Lp = L - pg->skip_len;
-    const int64_t n_groups = idx->n_lk_tiles * gm::LK_TG;
-    const int64_t words = n_groups * gm::lk_group_words(pg->Lp);
-    uint2* sorted_planes = nullptr;
-    if (hipMalloc(reinterpret_cast<void**>(&sorted_planes), sizeof(uint2) * (size_t)n) != hipSuccess)
-        return gm_fail(GM_ERR_ALLOC, "hipMalloc(sorted planes) failed");
+    constexpr int GPA = GM_PG_ALIGN / gm::LK_GROUP;      // groups per alignment unit
     for (int b = 0; b < B && rc == GM_OK; ++b) {
         const int nb = 1 << (2 * pg->blen[b]);
-        if (hipMalloc(reinterpret_cast<void**>(&pg->table[b]), sizeof(uint32_t) * (size_t)words) != hipSuccess ||
-            hipMalloc(reinterpret_cast<void**>(&pg->perm[b]), sizeof(int32_t) * (size_t)n) != hipSuccess ||
-            hipMalloc(reinterpret_cast<void**>(&pg->toff[b]), sizeof(int32_t) * (size_t)(nb + 1)) != hipSuccess ||
+        if ((rc = ensure(&pg->raw_off, &pg->raw_off_cap, nb + 1, "bucket offsets"))) break;
+        if (hipMalloc(reinterpret_cast<void**>(&pg->goff[b]), sizeof(int32_t) * (size_t)(nb + 1)) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&pg->gcnt[b]), sizeof(int32_t) * (size_t)(nb + 1)) != hipSuccess ||
             hipMalloc(reinterpret_cast<void**>(&pg->coff[b]), sizeof(int32_t) * (size_t)(nb + 1)) != hipSuccess) {
-            rc = gm_fail(GM_ERR_ALLOC, "hipMalloc(K1P pool copy) failed");
+            rc = gm_fail(GM_ERR_ALLOC, "hipMalloc(K1P bucket tables) failed");
             break;
         }
         hipLaunchKernelGGL(k_block_keys, grid_for(n), dim3(256), 0, st, idx->d_db, n, pg->bstart[b], pg->blen[b], pg->k0,
                            pg->r0);
         if ((rc = sort_pairs(pg, n, 2 * pg->blen[b], st))) break;
-        hipLaunchKernelGGL(k_bucket_offsets, grid_for(nb + 1), dim3(256), 0, st, pg->k1, n, nb, pg->toff[b]);
-        hipLaunchKernelGGL(k_gather_planes, grid_for(n), dim3(256), 0, st, idx->d_db, pg->r1, n, sorted_planes, pg->perm[b]);
-        hipLaunchKernelGGL(gm::k_to_onehot, grid_for(words), dim3(256), 0, st, sorted_planes, n, pg->table[b], n_groups,
-                           pg->Lp, pg->bstart[b], pg->skip_len);
-        if (hipGetLastError() != hipSuccess) rc = gm_fail(GM_ERR_DEVICE, "K1P pool-copy kernels failed to launch");
-    }
-    if (hipStreamSynchronize(st) != hipSuccess && rc == GM_OK) rc = gm_fail(GM_ERR_DEVICE, "K1P pool-copy build failed");
-    (void)hipFree(sorted_planes);
-    for (int b = 0; b < B && rc == GM_OK; ++b) {      // largest bucket per copy: sizes the slot lists
-        const int nb = 1 << (2 * pg->blen[b]);
-        std::vector<int32_t> off((size_t)nb + 1);
-        if (hipMemcpy(off.data(), pg->toff[b], sizeof(int32_t) * off.size(), hipMemcpyDeviceToHost) != hipSuccess) {
+        hipLaunchKernelGGL(k_bucket_offsets, grid_for(nb + 1), dim3(256), 0, st, pg->k1, n, nb, pg->raw_off);
+        // bucket geometry on the host: every bucket starts on a multiple of GM_PG_ALIGN positions
+        std::vector<int32_t> off((size_t)nb + 1), goff((size_t)nb + 1), gcnt((size_t)nb + 1);
+        if (hipMemcpyAsync(off.data(), pg->raw_off, sizeof(int32_t) * off.size(), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) {
             rc = gm_fail(GM_ERR_DEVICE, "K1P bucket offsets read-back failed");
             break;
         }
+        int64_t g = 0;
         int mx = 0;
-        for (int v = 0; v < nb; ++v) mx = off[v + 1] - off[v] > mx ? off[v + 1] - off[v] : mx;
+        for (int v = 0; v < nb; ++v) {
+            const int cnt = off[v + 1] - off[v];
+            mx = cnt > mx ? cnt : mx;
+            goff[v] = (int32_t)g;
+            gcnt[v] = (cnt + gm::LK_GROUP - 1) / gm::LK_GROUP;
+            g += (int64_t)((cnt + GM_PG_ALIGN - 1) / GM_PG_ALIGN) * GPA;
+        }
+        goff[nb] = (int32_t)g;
+        gcnt[nb] = 0;
         pg->max_bucket[b] = mx;
+        const int64_t n_groups = g > 0 ? g : GPA;
+        if (n_groups * gm::LK_GROUP >= ((int64_t)1 << 31)) {
+            rc = gm_fail(GM_ERR_ARG, "K1P: padded pool copy too large");
+            break;
+        }
+        const int64_t words = n_groups * gm::lk_group_words(pg->Lp);
+        if (hipMalloc(reinterpret_cast<void**>(&pg->recs[b]), sizeof(uint4) * (size_t)(n_groups * gm::LK_GROUP)) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&pg->table[b]), sizeof(uint32_t) * (size_t)words) != hipSuccess) {
+            rc = gm_fail(GM_ERR_ALLOC, "hipMalloc(K1P pool copy) failed");
+            break;
+        }
+        hipError_t e = hipMemcpyAsync(pg->goff[b], goff.data(), sizeof(int32_t) * goff.size(), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(pg->gcnt[b], gcnt.data(), sizeof(int32_t) * gcnt.size(), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemsetAsync(pg->recs[b], 0xff, sizeof(uint4) * (size_t)(n_groups * gm::LK_GROUP), st);
+        if (e != hipSuccess) {
+            rc = gm_fail(GM_ERR_DEVICE, std::string("K1P pool copy: ") + hipGetErrorString(e));
+            break;
+        }
+        hipLaunchKernelGGL(k_scatter_recs, grid_for(n), dim3(256), 0, st, idx->d_db, pg->k1, pg->r1, n, pg->raw_off, pg->goff[b],
+                           pg->recs[b]);
+        hipLaunchKernelGGL(k_onehot_recs, grid_for(words), dim3(256), 0, st, pg->recs[b], pg->table[b], n_groups, pg->Lp,
+                           pg->bstart[b], pg->skip_len);
+        if (hipGetLastError() != hipSuccess) rc = gm_fail(GM_ERR_DEVICE, "K1P pool-copy kernels failed to launch");
+        // (goff / gcnt host vectors are pageable: the copies above were staged by the runtime before returning)
+        if (hipStreamSynchronize(st) != hipSuccess && rc == GM_OK) rc = gm_fail(GM_ERR_DEVICE, "K1P pool-copy build failed");
     }
     if (rc != GM_OK) {
         free_pool_side(pg);
@@ -625,6 +657,20 @@ int gm_pg_prepare(gm_index* idx, int B, int expand, int len0, hipStream_t st) {
     }
     pg->B = B;
     return GM_OK;
+}
+
+// workgroups per expansion chunk and target buckets per workgroup for the current layout
+static void pg_sub_split(const gm_pigeon* pg, int* n_sub, int* per) {
+    if (!pg->expand) {
+        *n_sub = 1;
+        *per = 1;
+        return;
+    }
+    const int n_bk = 1 + 3 * pg->blen[0];
+    int S = pg->tune_sub;
+    while (S > 1 && pg->expand * S + (pg->B - pg->expand) > GM_PG_MAXLISTS) --S;
+    *per = (n_bk + S - 1) / S;
+    *n_sub = (n_bk + *per - 1) / *per;      // every workgroup of a chunk has at least one target bucket
 }
 
 // group the candidates in idx->d_q by every block's value and build the chunk table
@@ -640,6 +686,8 @@ int gm_pg_candidates(gm_index* idx, int64_t n_q, hipStream_t st) {
     A.B = pg->B;
     PgKeyArg K{};
     K.B = pg->B;
+    int n_sub = 1, per = 1;
+    pg_sub_split(pg, &n_sub, &per);
     int64_t grid = 0;
     for (int b = 0; b <= pg->B; ++b) A.ebase[b] = K.ebase[b] = pg->ebase[b];
     for (int b = 0; b < pg->B; ++b) {
@@ -649,8 +697,8 @@ int gm_pg_candidates(gm_index* idx, int64_t n_q, hipStream_t st) {
         K.coff[b] = pg->coff[b];
         K.cperm[b] = pg->cperm[b];
         A.coff[b] = pg->coff[b];
-        A.toff[b] = pg->toff[b];
-        grid += (n_q + 63) / 64 + (1 << (2 * pg->blen[b]));
+        A.gcnt[b] = pg->gcnt[b];
+        grid += ((n_q + 63) / 64 + (1 << (2 * pg->blen[b]))) * (b < pg->expand ? n_sub : 1);
     }
     // counting sort of the candidates by every block's value: histogram, per-block scan, scatter
     const int use_lds = n_entries <= 8192 ? 1 : 0;
@@ -660,19 +708,19 @@ int gm_pg_candidates(gm_index* idx, int64_t n_q, hipStream_t st) {
     hipLaunchKernelGGL(k_cand_offsets, dim3(pg->B), dim3(1024), 0, st, K, pg->hist, pg->cursor);
     hipLaunchKernelGGL(k_cand_scatter, grid_for(n_q, 1024), dim3(1024), lds, st, idx->d_q, n_q, K, pg->cursor, use_lds);
     HIP_TRY(hipGetLastError());
-    // chunk table: the own-bucket entries of every block, plus the neighbour buckets of the expansion blocks
+    // chunk table
     A.X = pg->expand;
-    A.xne = pg->expand ? 3 * pg->blen[0] : 1;
-    A.nbx = 1 << (2 * pg->blen[0]);
-    A.xskip = pg->skip_len;
-    A.n_entries = n_entries + pg->expand * A.nbx * A.xne;
-    grid += (int64_t)pg->expand * A.xne * ((n_q + 63) / 64 + A.nbx);
+    A.xne = pg->expand ? 3 * pg->blen[0] : 0;
+    A.S = n_sub;
+    A.per = per;
+    A.skip_len = pg->skip_len;
+    A.n_entries = n_entries;
     if ((rc = ensure(&pg->nch, &pg->nch_cap, A.n_entries, "chunk counts"))) return rc;
     if ((rc = ensure(&pg->cbase, &pg->cbase_cap, A.n_entries, "chunk offsets"))) return rc;
     if ((rc = ensure(&pg->chunks, &pg->chunks_cap, grid, "chunk table"))) return rc;
     HIP_TRY(hipMemsetAsync(pg->ctr, 0, sizeof(PgCounters), st));
     hipLaunchKernelGGL(k_chunk_count, grid_for(A.n_entries), dim3(256), 0, st, A, pg->nch);
-    {      // exclusive scan of the per-entry chunk counts (rocPRIM; up to ~50k entries)
+    {      // exclusive scan of the per-entry chunk counts (rocPRIM; a few thousand entries)
         size_t bytes = 0;
         HIP_TRY(rocprim::exclusive_scan(nullptr, bytes, pg->nch, pg->cbase, 0, (size_t)A.n_entries, rocprim::plus<int>(), st));
         if (bytes > pg->sort_tmp_cap || pg->sort_tmp == nullptr) {
@@ -687,113 +735,125 @@ int gm_pg_candidates(gm_index* idx, int64_t n_q, hipStream_t st) {
                                         rocprim::plus<int>(), st));
         hipLaunchKernelGGL(k_chunk_total, dim3(1), dim3(64), 0, st, pg->nch, pg->cbase, A.n_entries, &pg->ctr->n_chunks);
     }
-    hipLaunchKernelGGL(k_fill_chunks, grid_for(A.n_entries), dim3(256), 0, st, A, pg->cbase, (int)idx->n_lk_tiles,
-                       pg->chunks, pg->ctr);
+    hipLaunchKernelGGL(k_fill_chunks, grid_for(A.n_entries), dim3(256), 0, st, A, pg->cbase, pg->chunks, pg->ctr);
     HIP_TRY(hipGetLastError());
     pg->grid = grid;
     return GM_OK;
 }
 
-// slots per (candidate, list): 1.25 x (mean + 6 sigma) of the hits expected in the LARGEST bucket of any copy
-// under the independent-base model with the pool's own composition (own buckets: >= 16; neighbour buckets of
-// the expansion pass, where the pair already has one mismatch: >= 8).  A list that still overflows (repeat
-// families) only makes its row incomplete: the row is re-scanned by the plain kernel.
-static void pg_slot_capacity(const gm_index* idx, gm_pigeon* pg, int64_t n_q, int k) {
-    const int L = idx->L, r = pg->B + pg->expand - 1;
+// Words per candidate of every hit list (word 0 = count): mean + 4.5 sigma (+ 3) of the hits expected from the
+// list's target buckets under the independent-base model with the pool's own composition, taking every bucket as
+// large as the LARGEST bucket of its copy; a multiple of 4 (the merge reads 16 bytes at a time), at least 8.  A
+// list that still overflows (repeat families) only makes its row incomplete: the row is re-scanned by the plain
+// kernel.  All lists together stay within a quarter of the free device memory (at least 2 GiB).
+static void pg_list_capacity(const gm_index* idx, gm_pigeon* pg, int64_t n_q) {
+    const int L = idx->L, r = pg->B + pg->expand - 1, X = pg->expand;
     const double pm = pg->p_match >= 0.25 ? pg->p_match : 0.25;
-    double worst = 0.0;
+    int n_sub = 1, per = 1;
+    pg_sub_split(pg, &n_sub, &per);
+    gm_pg_blocks& P = pg->blocks;
+    P.n_lists = X * n_sub + (pg->B - X);
+    double mean[GM_PG_MAXLISTS];
     for (int b = 0; b < pg->B; ++b) {
-        const double h = (double)pg->max_bucket[b] * tail_within(L - pg->blen[b], r, pm) + 1.0;
-        if (h > worst) worst = h;
+        const double own = (double)pg->max_bucket[b] * tail_within(L - pg->blen[b], r, pm) + 1.0;
+        const double nbr = (double)pg->max_bucket[b] * tail_within(L - pg->blen[b], r - 1, pm);
+        if (b >= X) {
+            mean[X * n_sub + (b - X)] = own;
+            continue;
+        }
+        const int n_bk = 1 + 3 * pg->blen[0];
+        for (int s = 0; s < n_sub; ++s) {
+            const int e_lo = s * per, e_hi = e_lo + per < n_bk ? e_lo + per : n_bk;
+            mean[b * n_sub + s] = (e_lo == 0 ? own : nbr) + (double)(e_hi - e_lo - 1) * nbr;
+        }
     }
-    double cap = std::ceil(1.25 * (worst + 6.0 * std::sqrt(worst)) + 8.0);
-    if (cap < 16.0) cap = 16.0;
-    if (cap > 1024.0) cap = 1024.0;
-    double cap_x = 0.0;
-    const int n_x = pg->expand * 3 * pg->blen[0];
-    if (pg->expand) {
-        int mx = 0;
-        for (int b = 0; b < pg->expand; ++b) mx = pg->max_bucket[b] > mx ? pg->max_bucket[b] : mx;
-        const double h = (double)mx * tail_within(L - pg->blen[0], r - 1, pm);
-        cap_x = std::ceil(1.25 * (h + 6.0 * std::sqrt(h)) + 8.0);
-        if (cap_x > 512.0) cap_x = 512.0;
+    if (pg->mem_limit == 0.0) {      // (cached: hipMemGetInfo is not free)
+        size_t free_b = 0, total_b = 0;
+        pg->mem_limit = 2.0 * 1024 * 1024 * 1024;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)free_b / 4.0 > pg->mem_limit)
+            pg->mem_limit = (double)free_b / 4.0;
     }
-    if (k == 1) {      // nearest distance: the bound follows the best hit, a list only grows by improvements
-        cap = cap > 12.0 ? 12.0 : cap;
-        cap_x = cap_x > 6.0 ? 6.0 : cap_x;
+    double scale = 1.0;
+    for (;;) {
+        int64_t words = 0;
+        for (int l = 0; l < P.n_lists; ++l) {
+            double c = std::ceil(scale * (mean[l] + 4.5 * std::sqrt(mean[l]) + 3.0)) + 1.0;
+            if (c > 4096.0) c = 4096.0;
+            int cap = ((int)c + 3) / 4 * 4;
+            if (cap < 8) cap = 8;
+            P.lcap[l] = cap;
+            P.loff[l] = (int)words;
+            words += cap;
+        }
+        if ((double)words * (double)n_q * 4.0 <= pg->mem_limit || scale < 0.05) break;
+        scale *= 0.75;
     }
-    // keep the slot lists within a quarter of the free device memory (at least 2 GiB)
-    size_t free_b = 0, total_b = 0;
-    double limit = 2.0 * 1024 * 1024 * 1024;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)free_b / 4.0 > limit) limit = (double)free_b / 4.0;
-    while ((cap > 16.0 || cap_x > 8.0) && (cap * pg->B + cap_x * n_x) * (double)n_q * 4.0 > limit) {
-        cap = cap > 16.0 ? std::floor(cap * 0.75) : cap;
-        cap_x = cap_x > 8.0 ? std::floor(cap_x * 0.75) : cap_x;
-    }
-    pg->cap = (int)cap;
-    pg->cap_x = (int)cap_x;
+}
+
+int64_t gm_pg_list_words(const gm_pigeon* pg) {
+    const gm_pg_blocks& P = pg->blocks;
+    return P.n_lists > 0 ? (int64_t)P.loff[P.n_lists - 1] + P.lcap[P.n_lists - 1] : 0;
 }
 
 int gm_pg_scan(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
     gm_pigeon* pg = idx->pg;
     int rc;
-    if (pg->cap == 0 || pg->cap_nq != n_q || pg->cap_x_for != pg->expand || pg->cap_k1 != (k == 1)) {
-        pg_slot_capacity(idx, pg, n_q, k);      // (cached: hipMemGetInfo is not free)
+    if (pg->cap_nq != n_q || pg->cap_x_for != pg->expand || pg->cap_sub_for != pg->tune_sub) {
+        pg_list_capacity(idx, pg, n_q);
         pg->cap_nq = n_q;
         pg->cap_x_for = pg->expand;
-        pg->cap_k1 = k == 1;
+        pg->cap_sub_for = pg->tune_sub;
     }
-    const int n_x = pg->expand * 3 * pg->blen[0];
-    if ((rc = ensure(&pg->keys, &pg->keys_cap, ((int64_t)pg->B * pg->cap + (int64_t)n_x * pg->cap_x) * n_q,
-                     "K1P slot lists")))
-        return rc;
-    if ((rc = ensure(&pg->n_hits, &pg->n_hits_cap, (int64_t)(pg->B + n_x) * n_q, "K1P hit counts"))) return rc;
-    // a (list, candidate) pair whose target bucket is empty gets no workgroup: its count must read 0
-    HIP_TRY(hipMemsetAsync(pg->n_hits, 0, sizeof(int32_t) * (size_t)(pg->B + n_x) * (size_t)n_q, st));
+    if ((rc = ensure(&pg->lists, &pg->lists_cap, gm_pg_list_words(pg) * n_q, "K1P hit lists"))) return rc;
     gm_pg_blocks& blocks = pg->blocks;
+    int n_sub = 1, per = 1;
+    pg_sub_split(pg, &n_sub, &per);
     for (int b = 0; b < pg->B; ++b) {
         blocks.table[b] = pg->table[b];
-        blocks.perm[b] = pg->perm[b];
-        blocks.toff[b] = pg->toff[b];
+        blocks.recs[b] = pg->recs[b];
+        blocks.goff[b] = pg->goff[b];
+        blocks.gcnt[b] = pg->gcnt[b];
         blocks.cperm[b] = pg->cperm[b];
         blocks.skip[b] = pg->bstart[b];
     }
     blocks.skip_len = pg->skip_len;
     blocks.n_blocks = pg->B;
-    blocks.xne = pg->expand ? 3 * pg->blen[0] : 1;
-    blocks.n_expand = n_x;
+    blocks.n_expand = pg->expand;
+    blocks.xlen = pg->expand ? pg->blen[0] : 0;
+    blocks.n_sub = n_sub;
     const int thr0 = pg->B + pg->expand;      // accept d < thr0, i.e. d <= r = B + X - 1
+    const int64_t grid = (pg->grid + 8 * gm::PG_RUN - 1) / (8 * gm::PG_RUN) * (8 * gm::PG_RUN);
     switch (pg->Lp) {            // the kernel instantiated for the positions actually evaluated
 #define GM_CASE(LEN) \
-    case LEN: return gm_launch_pg_L##LEN(idx, &blocks, pg->chunks, &pg->ctr->n_chunks, pg->grid, n_q, k, thr0, pg->cap, pg->cap_x, pg->keys, pg->n_hits, st);
+    case LEN: return gm_launch_pg_L##LEN(idx, &blocks, pg->chunks, &pg->ctr->n_chunks, grid, n_q, k, thr0, pg->lists, st);
         GM_FOR_EACH_LEN(GM_CASE)
 #undef GM_CASE
         default: return gm_fail(GM_ERR_ARG, "pigeonhole kernel: guidelen out of range");
     }
 }
 
+// hit lists -> top k; rows that are not exact are listed in pg->inc (count in pg->ctr->n_inc)
 int gm_pg_merge(gm_index* idx, int kcap, int64_t n_q, int k, int32_t* ids, int32_t* dists, int32_t* counts,
                 bool nearest, hipStream_t st) {
     gm_pigeon* pg = idx->pg;
+    int rc;
+    if ((rc = ensure(&pg->inc, &pg->inc_cap, n_q, "incomplete rows"))) return rc;
     const dim3 grid = grid_for(n_q * gm::PG_MERGE_SPLIT), block(256);
     const int nr = nearest ? 1 : 0;
+    int* n_inc = &pg->ctr->n_inc;
     switch (kcap) {
-        case 1: hipLaunchKernelGGL(gm::k_merge_hits<1>, grid, block, 0, st, pg->blocks, pg->cap, pg->cap_x, pg->keys, pg->n_hits, n_q, k, ids, dists, counts, nr); break;
-        case 5: hipLaunchKernelGGL(gm::k_merge_hits<5>, grid, block, 0, st, pg->blocks, pg->cap, pg->cap_x, pg->keys, pg->n_hits, n_q, k, ids, dists, counts, nr); break;
-        case 10: hipLaunchKernelGGL(gm::k_merge_hits<10>, grid, block, 0, st, pg->blocks, pg->cap, pg->cap_x, pg->keys, pg->n_hits, n_q, k, ids, dists, counts, nr); break;
-        default: hipLaunchKernelGGL(gm::k_merge_hits<20>, grid, block, 0, st, pg->blocks, pg->cap, pg->cap_x, pg->keys, pg->n_hits, n_q, k, ids, dists, counts, nr); break;
+        case 1: hipLaunchKernelGGL(gm::k_merge_hits<1>, grid, block, 0, st, pg->blocks, pg->lists, n_q, k, ids, dists, counts, nr, pg->inc, n_inc); break;
+        case 5: hipLaunchKernelGGL(gm::k_merge_hits<5>, grid, block, 0, st, pg->blocks, pg->lists, n_q, k, ids, dists, counts, nr, pg->inc, n_inc); break;
+        case 10: hipLaunchKernelGGL(gm::k_merge_hits<10>, grid, block, 0, st, pg->blocks, pg->lists, n_q, k, ids, dists, counts, nr, pg->inc, n_inc); break;
+        default: hipLaunchKernelGGL(gm::k_merge_hits<20>, grid, block, 0, st, pg->blocks, pg->lists, n_q, k, ids, dists, counts, nr, pg->inc, n_inc); break;
     }
     HIP_TRY(hipGetLastError());
     return GM_OK;
 }
 
-int gm_pg_incomplete(gm_index* idx, int64_t n_q, int need, const int32_t* counts, const int32_t* d1, int64_t* n_inc,
-                     int64_t* pairs_evaluated, hipStream_t st) {
+// number of rows the merge listed as incomplete + the pairs the scan evaluated (one 32-byte read-back; synchronises)
+int gm_pg_incomplete(gm_index* idx, int64_t* n_inc, int64_t* pairs_evaluated, hipStream_t st) {
     gm_pigeon* pg = idx->pg;
-    int rc;
-    if ((rc = ensure(&pg->inc, &pg->inc_cap, n_q, "incomplete rows"))) return rc;
-    hipLaunchKernelGGL(k_collect_incomplete, grid_for(n_q), dim3(256), 0, st, counts, d1, n_q, need, pg->inc, pg->ctr);
-    HIP_TRY(hipGetLastError());
     PgCounters h{};
     HIP_TRY(hipMemcpyAsync(&h, pg->ctr, sizeof(PgCounters), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

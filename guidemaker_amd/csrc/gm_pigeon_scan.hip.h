@@ -1,0 +1,324 @@
+// gm_pigeon_scan.hip.h -- K1P: pigeonhole-partitioned exact Hamming k-NN scan for gfx950 (kernels; the host side
+// is gm_pigeon.hip).
+//
+// The guide is cut into B blocks of positions.  Two sequences with at most r mismatches agree exactly on at least
+// one of r + 1 disjoint blocks, so for block b it is enough to compare a candidate with the pool targets that carry
+// the same bases on block b (its bucket); with the one-substitution neighbour buckets of X of the blocks scanned
+// as well, B blocks serve r = B + X - 1 (gm_pigeon.hip, gm_pg_plan).  The pool is stored B times, stable-sorted by
+// the block's value (ids ascend inside a bucket), every bucket padded to whole LDS-DMA units, with one one-hot
+// table per copy; candidates are grouped by the same value into chunks of <= 64 that never straddle a bucket.
+//
+// Workgroup (one wave) = one chunk of candidates (lane = candidate) against a RUN of target buckets of one copy
+// (the chunk's own bucket and / or some of its neighbour buckets): K1L's per-lane LDS look-ups, carry-save adder
+// trees and bit-sliced comparator over the buckets' 64-target groups, streamed through a double-buffered LDS window
+// by global_load_lds DMA that runs across bucket boundaries.  Inside a bucket hits are frequent (the pairs already
+// share a block: about one per 64 x 64 group on an E. coli sized pool), so the hit path is built to cost the wave
+// as little as possible:
+//   * ENQUEUE (per group with a hit, ~12 instructions, no loop, no divergence beyond one predicated LDS write):
+//     every lane with a non-zero 64-bit hit word pushes (group, lane, hit word) into a ring in LDS at a position
+//     from the wave's ballot prefix;
+//   * FLUSH (when 64 entries are queued, and at the end): lane e takes entry e -- all 64 lanes busy -- , walks its
+//     hit bits (almost always one), gathers the 16-byte record of the target {planes, pool id} from the sorted
+//     copy, recomputes the distance with one xor / or / popcount, takes a slot in the candidate's hit list from a
+//     counter in LDS and stores (distance << 27 | pool id) to the list in HBM.  The lists of one workgroup are
+//     private to it and contiguous per candidate (word 0 = count), so the 4-byte stores of a list combine in the
+//     L2 of the workgroup's XCD and the merge reads whole lines.
+// Bound tightening needs no sorted list: per candidate the flush counts the hits closer than r and closer than
+// r - 1; once k of them are known nothing at distance r (r - 1) can enter the top k.  k = 1 follows the best distance.
+// k_merge_hits folds the lists of a candidate (duplicates -- pairs that share several blocks -- taken once) into
+// the top k; a candidate whose merged list is full is exact (every target within r was enumerated); the others,
+// and those with an overflowed list, are collected for the plain scan (gmhip.hip).
+#pragma once
+#include "gm_lookup.hip.h"
+#include "gm_pg_types.h"
+
+namespace gm {
+
+constexpr int PG_QCAP = 128;          // ring of queued hit words per wave (a flush takes 64, a group adds <= 64)
+constexpr int PG_RUN = 16;            // consecutive chunk-table entries executed on the same XCD
+constexpr int PG_MERGE_SPLIT = 4;     // threads per candidate in k_merge_hits
+
+// dynamic LDS of k_hamming_scan_pg<L>: two DMA buffers of two groups each, the ring, per-candidate state
+__host__ __device__ constexpr int pg_pair_words(int L) { return 2 * lk_group_words(L); }
+__host__ __device__ constexpr size_t pg_lds_bytes(int L) {
+    return sizeof(uint32_t) * (size_t)(2 * pg_pair_words(L) + PG_QCAP * 3 + WAVE * 2 + WAVE * 4);
+}
+
+// target bucket e of the chunk's run: 0 = the candidates' own bucket v; 1 + 3 p + a = v with the base at block
+// position p replaced by the a-th of the three other bases.  add = 1 when that position is one the copy's table
+// leaves out (the scan cannot see the mismatch; the comparator bound accounts for it).
+__device__ __forceinline__ int pg_target_bucket(int v, int e, int skip_len, int& add) {
+    add = 0;
+    if (e == 0) return v;
+    const int ne = e - 1, pidx = ne / 3, alt = ne % 3;
+    const int code = (v >> (2 * pidx)) & 3;
+    add = pidx < skip_len ? 1 : 0;
+    return (v & ~(3 << (2 * pidx))) | (((code + 1 + alt) & 3) << (2 * pidx));
+}
+
+// walks the 2-group DMA units ("pairs") of the non-empty target buckets of a chunk, in order
+struct PgIter {
+    int e, g0, gc, pi, add;
+};
+__device__ __forceinline__ bool pg_next(const gm_pg_blocks& P, const gm_pg_chunk& ch, PgIter& it, int& g, int& ng,
+                                        int& add) {
+    if (2 * (it.pi + 1) < it.gc) {
+        ++it.pi;
+    } else {
+        do {
+            if (++it.e >= ch.e_hi) return false;
+            const int vt = pg_target_bucket(ch.v, it.e, P.skip_len, it.add);
+            it.gc = P.gcnt[ch.b][vt];
+            it.g0 = P.goff[ch.b][vt];
+        } while (it.gc <= 0);
+        it.pi = 0;
+    }
+    g = it.g0 + 2 * it.pi;
+    ng = it.gc - 2 * it.pi < 2 ? it.gc - 2 * it.pi : 2;
+    add = it.add;
+    return true;
+}
+
+// one DMA unit = two consecutive groups of the table (64 L bytes), straight into LDS
+template <int L>
+__device__ __forceinline__ void pg_stage(const uint32_t* __restrict__ table, int g, uint32_t* dst, int lane) {
+    constexpr int UNITS = pg_pair_words(L) / 4;       // 16-byte units
+    constexpr int ROUNDS = (UNITS + WAVE - 1) / WAVE;
+    const uint32_t* src = table + (int64_t)g * lk_group_words(L);
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int u = r * WAVE + lane;
+        if (u < UNITS) __builtin_amdgcn_global_load_lds(src + u * 4, dst + r * WAVE * 4, 16, 0, 0);
+    }
+}
+
+struct PgQueue {
+    uint32_t* tag;      // [PG_QCAP]  group << 6 | candidate lane
+    uint2* mask;        // [PG_QCAP]  hit bits of the group's 64 targets
+    uint2* qpl;         // [WAVE]     candidate planes
+    int* qrow;          // [WAVE]     candidate rows
+    int* cnt;           // [WAVE]     hits appended so far
+    int* c1;            // [WAVE]     hits with d < thr0 - 1   (k == 1: best distance so far)
+    int* c2;            // [WAVE]     hits with d < thr0 - 2
+    int head, tail;     // wave-uniform ring positions (monotonic)
+};
+
+// FLUSH: n (<= 64, wave-uniform) queued hit words are turned into list entries, one per lane.
+__device__ __forceinline__ void pg_flush(PgQueue& Q, int n, int lane, const uint4* __restrict__ recs,
+                                         uint32_t* __restrict__ lists, int lcap, int k, int thr0) {
+    uint32_t tg = 0;
+    uint2 m = make_uint2(0u, 0u);
+    if (lane < n) {
+        const int s = (Q.head + lane) & (PG_QCAP - 1);
+        tg = Q.tag[s];
+        m = Q.mask[s];
+    }
+    Q.head += n;
+    const int cl = (int)(tg & 63u);
+    const int64_t pos0 = (int64_t)(tg >> 6) * LK_GROUP;
+    const uint2 cq = Q.qpl[cl];
+    const int64_t row = Q.qrow[cl];
+    uint64_t hm = ((uint64_t)m.y << 32) | (uint64_t)m.x;
+    while (hm != 0ull) {
+        const int j = __builtin_ctzll(hm);
+        hm &= hm - 1ull;
+        const uint4 t = recs[pos0 + j];
+        const int d = __popc((cq.x ^ t.x) | (cq.y ^ t.y));
+        if (k == 1) {
+            atomicMin(&Q.c1[cl], d);
+        } else {
+            if (d < thr0 - 1) atomicAdd(&Q.c1[cl], 1);
+            if (d < thr0 - 2) atomicAdd(&Q.c2[cl], 1);
+        }
+        const int slot = atomicAdd(&Q.cnt[cl], 1) + 1;      // word 0 of a list is its count
+        if (slot < lcap) lists[row * lcap + slot] = ((uint32_t)d << ID_BITS) | t.z;
+    }
+    __syncthreads();      // single-wave workgroup: orders the LDS atomics before the reads of the counters below
+}
+
+// bound of this lane's candidate from the counters the flushes keep
+__device__ __forceinline__ int pg_bound(const PgQueue& Q, int lane, int k, int thr0) {
+    if (k == 1) return Q.c1[lane];
+    return thr0 - (Q.c1[lane] >= k ? 1 : 0) - (Q.c2[lane] >= k ? 1 : 0);
+}
+
+// evaluate one 64-target group from LDS (word offset WOFF) and queue the lanes that have hits
+template <int L, int WOFF>
+__device__ __forceinline__ void pg_group(const uint32_t* const (&ptr)[L], const uint32_t (&Tb)[5], int g, int lane,
+                                         PgQueue& Q) {
+    LkGroupRegs<L> r;
+    lk_read_group<L, WOFF>(r, ptr);
+    uint32_t c0[5], c1[5];
+    const uint32_t h0 = lk_eval_half<L>(r.m0, Tb, c0);
+    const uint32_t h1 = lk_eval_half<L>(r.m1, Tb, c1);
+    const bool has = (h0 | h1) != 0u;
+    const uint64_t bal = __builtin_amdgcn_ballot_w64(has);
+    if (bal != 0ull) {
+        const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        if (has) {
+            const int s = (Q.tail + (int)before) & (PG_QCAP - 1);
+            Q.tag[s] = ((uint32_t)g << 6) | (uint32_t)lane;
+            Q.mask[s] = make_uint2(h0, h1);
+        }
+        Q.tail += __builtin_popcountll(bal);
+    }
+}
+
+// lists: the hit buffer (see gm_pg_blocks::loff / lcap)
+template <int L>
+__global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
+    gm_pg_blocks P, const gm_pg_chunk* __restrict__ chunks, const int* __restrict__ n_chunks,
+    const uint2* __restrict__ q, int64_t n_q, int k, int thr0, uint32_t* __restrict__ lists) {
+    extern __shared__ __align__(16) uint32_t smem[];
+    constexpr int GW = lk_group_words(L);
+    constexpr int PW = pg_pair_words(L);
+    // XCD-aware order: workgroups are dealt to the 8 XCDs round-robin; give every XCD runs of PG_RUN consecutive
+    // chunk-table entries (the chunks of one candidate bucket share their target buckets: same L2)
+    const int n = *n_chunks;
+    const int wg = (int)blockIdx.x, xcd = wg & 7, slot = wg >> 3;
+    const int entry = (slot / PG_RUN) * (8 * PG_RUN) + xcd * PG_RUN + (slot % PG_RUN);
+    if (entry >= n) return;
+    const gm_pg_chunk ch = chunks[entry];
+    const uint32_t* __restrict__ table = P.table[ch.b];
+    const uint4* __restrict__ recs = P.recs[ch.b];
+    uint32_t* tiles = smem;                                     // [2][PW]
+    PgQueue Q;
+    Q.tag = smem + 2 * PW;
+    Q.mask = reinterpret_cast<uint2*>(Q.tag + PG_QCAP);
+    Q.qpl = Q.mask + PG_QCAP;
+    Q.qrow = reinterpret_cast<int*>(Q.qpl + WAVE);
+    Q.cnt = Q.qrow + WAVE;
+    Q.c1 = Q.cnt + WAVE;
+    Q.c2 = Q.c1 + WAVE;
+    Q.head = Q.tail = 0;
+    const int lane = threadIdx.x;
+    const bool valid = lane < ch.cn;
+    const int64_t qi = valid ? (int64_t)P.cperm[ch.b][ch.c0 + lane] : 0;
+    const uint2 qv = valid ? q[qi] : make_uint2(0u, 0u);
+    Q.qpl[lane] = qv;
+    Q.qrow[lane] = (int)qi;
+    Q.cnt[lane] = 0;
+    Q.c1[lane] = k == 1 ? thr0 : 0;
+    Q.c2[lane] = 0;
+
+    // L = positions evaluated: the copy's table leaves out P.skip_len positions of its own block (all pairs of
+    // the bucket agree there, or differ on exactly one of them: `add`), so table position p is sequence position p
+    // (+ skip_len behind the gap)
+    const int skip_start = P.skip[ch.b], skip_len = P.skip_len;
+    const uint32_t* ptr[L];
+#pragma unroll
+    for (int p = 0; p < L; ++p) {
+        const int sp = p >= skip_start ? p + skip_len : p;
+        const uint32_t code = ((qv.x >> sp) & 1u) | (((qv.y >> sp) & 1u) << 1);
+        ptr[p] = tiles + p * 8 + (int)code * 2;
+    }
+    const int lcap = P.lcap[ch.lst];
+    uint32_t* __restrict__ mylists = lists + (int64_t)P.loff[ch.lst] * n_q;
+    int thr = valid ? thr0 : 0;                                 // accept d < thr
+    uint32_t Tb[5];
+
+    PgIter it{ch.e_lo - 1, 0, 0, 0, 0};
+    int gA = 0, ngA = 0, addA = 0, gB = 0, ngB = 0, addB = 0;
+    bool okA = pg_next(P, ch, it, gA, ngA, addA), okB = false;
+    if (okA) pg_stage<L>(table, gA, tiles, lane);
+    int add_cur = -1;
+    // flush when a full wave of entries is queued; afterwards the bounds may have tightened
+#define GM_PG_AFTER_GROUP(ADD)                                                    \
+    if (Q.tail - Q.head >= WAVE) {                                                \
+        pg_flush(Q, WAVE, lane, recs, mylists, lcap, k, thr0);                    \
+        const int nt = pg_bound(Q, lane, k, thr0);                                \
+        if (valid && nt < thr) thr = nt;                                          \
+        lk_set_bound(Tb, L, thr - (ADD));                                         \
+    }
+    while (okA) {
+        okB = pg_next(P, ch, it, gB, ngB, addB);
+        lk_stage_wait();                                        // unit A has landed in buffer 0
+        if (okB) pg_stage<L>(table, gB, tiles + PW, lane);
+        if (addA != add_cur) {
+            add_cur = addA;
+            lk_set_bound(Tb, L, thr - add_cur);
+        }
+        pg_group<L, 0>(ptr, Tb, gA, lane, Q);
+        GM_PG_AFTER_GROUP(add_cur)
+        if (ngA > 1) {
+            pg_group<L, GW>(ptr, Tb, gA + 1, lane, Q);
+            GM_PG_AFTER_GROUP(add_cur)
+        }
+        if (!okB) break;
+        okA = pg_next(P, ch, it, gA, ngA, addA);
+        lk_stage_wait();                                        // unit B has landed in buffer 1
+        if (okA) pg_stage<L>(table, gA, tiles, lane);
+        if (addB != add_cur) {
+            add_cur = addB;
+            lk_set_bound(Tb, L, thr - add_cur);
+        }
+        pg_group<L, PW>(ptr, Tb, gB, lane, Q);
+        GM_PG_AFTER_GROUP(add_cur)
+        if (ngB > 1) {
+            pg_group<L, PW + GW>(ptr, Tb, gB + 1, lane, Q);
+            GM_PG_AFTER_GROUP(add_cur)
+        }
+    }
+#undef GM_PG_AFTER_GROUP
+    while (Q.tail - Q.head > 0) {
+        const int n_take = Q.tail - Q.head < WAVE ? Q.tail - Q.head : WAVE;
+        pg_flush(Q, n_take, lane, recs, mylists, lcap, k, thr0);
+    }
+    if (valid) mylists[qi * lcap] = (uint32_t)Q.cnt[lane];      // every (list, candidate) pair has exactly one writer
+}
+
+// K1P merge: PG_MERGE_SPLIT adjacent lanes per candidate, each folding every PG_MERGE_SPLIT-th hit list into its
+// own register list (duplicates taken once), then lane 0 of the group takes the other lists over by shuffles and
+// writes the row.  A row that is not exact -- fewer than k entries, or a list that overflowed -- is written as
+// incomplete (count 0 / distance -1) and its index appended to `inc` (inc_count) for the plain scan.
+template <int KCAP>
+__global__ void k_merge_hits(gm_pg_blocks P, const uint32_t* __restrict__ lists, int64_t n_q, int k,
+                             int32_t* __restrict__ ids, int32_t* __restrict__ dists, int32_t* __restrict__ counts,
+                             int nearest, int32_t* __restrict__ inc, int* __restrict__ inc_count) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int sub = (int)(t % PG_MERGE_SPLIT);
+    const int64_t qi_raw = t / PG_MERGE_SPLIT;
+    const bool valid = qi_raw < n_q;
+    const int64_t qi = valid ? qi_raw : n_q - 1;      // (whole groups stay in the shuffles)
+    RegList<KCAP> list;
+    list.init(k, nullptr, 0);
+    int overflow = 0;
+    for (int l = sub; l < P.n_lists; l += PG_MERGE_SPLIT) {
+        const int lcap = P.lcap[l];                    // multiple of 4
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(lists + (int64_t)P.loff[l] * n_q + qi * lcap);
+        uint4 w = src[0];
+        int c = (int)w.x;
+        if (c > lcap - 1) {
+            overflow = 1;
+            c = lcap - 1;
+        }
+        // keys sit in words 1 .. c
+        for (int base = 0; base <= c; base += 4) {
+            if (base) w = src[base >> 2];
+            const uint32_t kk[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = base + j;
+                if (i >= 1 && i <= c && kk[j] + 1u < list.v[KCAP - 1]) list.insert_unique(kk[j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 1; s < PG_MERGE_SPLIT; ++s) {
+        overflow |= __shfl_down(overflow, s, PG_MERGE_SPLIT);
+#pragma unroll
+        for (int i = 0; i < KCAP; ++i) {
+            const uint32_t v = __shfl_down(list.v[i], s, PG_MERGE_SPLIT);
+            if (sub == 0 && v != 0u && v != RegList<KCAP>::EMPTY) list.insert_unique(v - 1u);
+        }
+    }
+    if (sub != 0 || !valid) return;
+    const bool full = list.v[KCAP - 1] != RegList<KCAP>::EMPTY;
+    if (overflow || !full) {
+        list.init(k, nullptr, 0);
+        inc[atomicAdd(inc_count, 1)] = (int32_t)qi;
+    }
+    list.store(k, qi, ids, dists, counts, nearest != 0);
+}
+
+}  // namespace gm

@@ -313,9 +313,7 @@ int run_hamming_pigeon(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
     if ((rc = timing_end(idx, st, n_q * idx->n_db))) return rc;
     if ((rc = gm_pg_merge(idx, kcap, n_q, keff, ids, dists, counts, nearest, st))) return rc;
     int64_t n_inc = 0, pairs = 0;
-    if ((rc = gm_pg_incomplete(idx, n_q, keff, nearest ? nullptr : counts, nearest ? dists : nullptr, &n_inc, &pairs,
-                               st)))
-        return rc;
+    if ((rc = gm_pg_incomplete(idx, &n_inc, &pairs, st))) return rc;
     idx->last_evaluated = pairs;
     idx->last_incomplete = n_inc;
     if (n_inc > 0) {
@@ -567,6 +565,12 @@ int gm_set_variant(gm_index* idx, int variant) {
     if (check_index(idx)) return GM_ERR_ARG;
     idx->variant = variant;
     return GM_OK;
+}
+
+int gm_set_param(gm_index* idx, const char* name, int value) {
+    if (check_index(idx)) return GM_ERR_ARG;
+    if (!name) return fail(GM_ERR_ARG, "gm_set_param: null name");
+    return gm_pg_set_param(idx, name, value);
 }
 
 static int knn_query_dev_impl(gm_index* idx, const void* d_q, int64_t n_q, int k, void* d_ids, void* d_dists,

@@ -169,6 +169,10 @@ int gm_timing_read(gm_index* idx, double* ms_out, int max_n);
  *                blocks; 600 + B / 700 + B two / three expansion blocks of even length.
  *   Levenshtein: 2 = per-pair Myers kernel K2L; 1 = plane-based kernel (also used for L < 10 and k > 20). */
 int gm_set_variant(gm_index* idx, int variant);
+/* Named tuning knobs (experiments; results are identical for every value).
+ *   "pg_sub" (1..19, default 4): workgroups the target buckets of one expansion chunk of the pigeonhole-partitioned
+ *   scan are split over (more = shorter work items and more hit lists per candidate). */
+int gm_set_param(gm_index* idx, const char* name, int value);
 
 #ifdef __cplusplus
 }
