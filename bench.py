@@ -30,7 +30,9 @@ import torch
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 B_ALG = {"hamming": 16, "leven": 16}     # algorithmic bytes per guide pair: two 8-byte packed operands
-VALU_LANE_OPS_PER_S = 256 * 128 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz
+VALU_LANE_OPS_PER_S = 256 * 128 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T int32 lane-ops/s
+LDS_CYCLES_PER_READ = 2.4        # measured ds_read_b64 issue cost per CU (profiles/r01/lds_rate_microbench.txt)
+COUNTERS_JSON = os.path.join(ROOT, "profiles", "counters.json")
 
 
 def lookup_ops_per_pair(L):
@@ -80,6 +82,75 @@ def bitsliced_leven_ops_per_pair(L):
     cells = L * L - (L - band - 1) * (L - band)
     per_word = 5.0 * cells + _tree_ops(L) + 5 + L / 2.0
     return per_word / 32.0
+
+
+def roofline_block(workload, pool, kname, kern_s, n_timed, query_ms, launch_pairs, evaluated_pairs, rescanned,
+                   pigeon_blocks, n_q, n_db):
+    """Roofline of the dominant scan kernel.  The scans are integer-VALU bound (O(N) bytes for O(N^2) pair work, all
+    of it on bit-sliced words in registers / LDS), so the roof is the int32 VALU issue rate: 256 CUs x 4 SIMD-32 x
+    2.4 GHz = 78.6 T lane-ops/s.
+      achieved = wave-level VALU instructions the kernel ISSUED per launch (SQ_INSTS_VALU from the rocprofv3 PMC pass
+                 registered in profiles/counters.json for this workload) x 64 lanes / HIP-event kernel time measured
+                 here -> frac <= 1 by construction;
+      useful   = the modelled adder-tree + comparator lane-ops of the pairs the launch EVALUATED / the same time;
+      traffic  = HBM-side bytes per launch from the FETCH_SIZE / WRITE_SIZE passes (gfx950 correction applied),
+                 next to the compulsory bytes 8 (N_q + N_db) + 8 k N_q."""
+    L, k, metric = pool["guidelen"], pool["k"], pool["metric"]
+    reg = {}
+    if os.path.exists(COUNTERS_JSON):
+        with open(COUNTERS_JSON) as fh:
+            reg = json.load(fh).get(workload, {})
+    if reg and not reg.get("kernel", "").startswith(kname.split("(")[0]):
+        reg = {}      # counters of another kernel: do not mix
+    ctr = reg.get("counters", {})
+    peak = VALU_LANE_OPS_PER_S / 1e12
+    if metric == "hamming":
+        L_eval = max(10, L - L // pigeon_blocks) if pigeon_blocks else L
+        useful_opp = lookup_ops_per_pair(L_eval)
+        model = "2 v_bitop3 per adder of the carry-save tree over %d match words + 5 comparator ops per 32 pairs + 1 v_cmp per 64" % L_eval
+    elif "knn_bs" in kname:
+        useful_opp = bitsliced_leven_ops_per_pair(L)
+        model = "5 ops per DP cell of the band per 32 pairs + diagonal count tree + comparator (banded path)"
+    else:
+        useful_opp = 11.0 * L + 12.0
+        model = "per-pair Myers: 11 ops per text position + tail"
+    useful = evaluated_pairs * useful_opp / kern_s / 1e12
+    roof = {"bound": "valu", "unit": "T lane-ops/s", "peak": peak, "kernel": kname, "kernel_ms_avg": kern_s * 1e3,
+            "launches_timed": int(n_timed), "query_device_ms": query_ms,
+            "pairs_per_launch": launch_pairs, "pairs_evaluated": evaluated_pairs,
+            "candidates_rescanned": int(rescanned)}
+    if pigeon_blocks:
+        roof["pigeon_blocks"] = pigeon_blocks
+    if "SQ_INSTS_VALU" in ctr:
+        issued = ctr["SQ_INSTS_VALU"] * 64.0 / kern_s / 1e12
+        roof["achieved"] = issued
+        roof["frac"] = issued / peak
+        roof["counters"] = {"source": reg.get("source"), "kernel": reg.get("kernel"),
+                            "SQ_INSTS_VALU_per_launch": ctr["SQ_INSTS_VALU"],
+                            "SQ_INSTS_LDS_per_launch": ctr.get("SQ_INSTS_LDS"),
+                            "SQ_WAVES_per_launch": ctr.get("SQ_WAVES"),
+                            "kernel_ms_in_pmc_pass": reg.get("mean_ns_in_pmc_passes", 0.0) / 1e6}
+        if ctr.get("SQ_INSTS_LDS"):
+            # LDS instructions are issued per CU: share of the kernel's CU-cycles the LDS pipe is busy issuing them
+            roof["lds_issue_frac"] = ctr["SQ_INSTS_LDS"] * LDS_CYCLES_PER_READ / (256 * 2.4e9 * kern_s)
+    else:
+        roof["achieved"] = useful
+        roof["frac"] = useful / peak
+        roof["counters"] = None
+        roof["note_counters"] = "no PMC pass registered for this workload/kernel: achieved = the modelled useful ops"
+    roof["useful"] = {"achieved": useful, "frac": useful / peak, "ops_per_pair": useful_opp, "model": model}
+    compulsory = 8.0 * (n_q + n_db) + 8.0 * k * n_q
+    traffic = reg.get("hbm_side_bytes_per_launch")
+    roof["traffic"] = traffic
+    roof["compulsory_bytes"] = compulsory
+    if traffic:
+        roof["traffic_over_compulsory"] = traffic / compulsory
+        roof["hbm_frac"] = traffic / kern_s / 1e9 / HBM_PEAK_GBS
+    roof["streaming_model_note"] = ("SURVEY.md 8(d)(i): %d operand bytes per resolved pair would be %.3g GB/s -- a "
+                                    "no-reuse figure the kernel never moves (operands are reused from LDS / registers); "
+                                    "reported for reference only, not a roofline fraction"
+                                    % (B_ALG[metric], launch_pairs * B_ALG[metric] / kern_s / 1e9))
+    return roof
 
 
 def parse():
@@ -194,16 +265,31 @@ def main():
     gather_b = [torch.empty((world * n_q, k), dtype=torch.int32, device=dev) for _ in range(nbuf)] if nbuf == 2 else []
     pending = [None] * nbuf
     gathered = [None, None, None]
-    ids, dists, counts = ids_b[0], dists_b[0], counts_b[0]
+    last_buf, gathered_buf = [0], [0]
     stream = torch.cuda.current_stream().cuda_stream
     idx = _lib.Index.from_device(d_db.data_ptr(), n_db, L, metric_code, local_rank, stream)
     step_no = [0]
-    use_async = [True]
+    # async collectives: decided ONCE, before any step, and agreed across the ranks (a rank-local fallback would
+    # make the ranks issue different collectives); any later RCCL error propagates
+    use_async = False
+    if world > 1 and backend == "nccl":
+        ok = 1
+        try:
+            probe_in = torch.zeros((8, k), dtype=torch.int32, device=dev)
+            probe_out = torch.empty((world * 8, k), dtype=torch.int32, device=dev)
+            dist.all_gather_into_tensor(probe_out, probe_in, async_op=True).wait()
+        except Exception as e:
+            print("bench: async all-gather unavailable on rank %d (%s)" % (rank, e), file=sys.stderr)
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        use_async = bool(flag.item())
 
     def drain(b):
         if pending[b] is not None:
             gathered[:] = pending[b].result()
             pending[b] = None
+            gathered_buf[0] = b
 
     def step():
         b = step_no[0] % nbuf
@@ -211,19 +297,16 @@ def main():
         drain(b)                          # the gather that last used this buffer pair
         idx.knn_dev(d_q.data_ptr(), n_q, k, ids_b[b].data_ptr(), dists_b[b].data_ptr(), counts_b[b].data_ptr(), stream)
         if world > 1:   # the one exchange of the path: per-shard neighbour lists over RCCL/xGMI
-            if backend == "nccl" and use_async[0]:
-                try:
-                    pending[b] = distributed.all_gather_neighbors_async(ids_b[b], dists_b[b], world * n_q,
-                                                                        out=gather_b[b])
-                except Exception as e:      # an RCCL build without async support: gather in line from now on
-                    print("bench: async all-gather unavailable (%s); using the blocking form" % e, file=sys.stderr)
-                    use_async[0] = False
-                    gathered[:] = distributed.all_gather_neighbors(ids_b[b], dists_b[b], counts_b[b], world * n_q)
+            if use_async:
+                pending[b] = distributed.all_gather_neighbors_async(ids_b[b], dists_b[b], world * n_q, out=gather_b[b])
             elif backend == "nccl":
                 gathered[:] = distributed.all_gather_neighbors(ids_b[b], dists_b[b], counts_b[b], world * n_q)
             else:
                 gathered[:] = distributed.all_gather_neighbors(ids_b[b].cpu(), dists_b[b].cpu(), counts_b[b].cpu(),
                                                                world * n_q)
+            if not use_async:
+                gathered_buf[0] = b
+        last_buf[0] = b
 
     def finish():
         for b in range(nbuf):
@@ -254,17 +337,24 @@ def main():
     kname = idx.last_kernel()[0]
     query_ms = idx.last_query_ms()
 
-    # sanity: every candidate of rank 0 is in the pool, so its nearest hit is itself at distance 0
-    if rank == 0:
-        c = counts.cpu().numpy()
-        d0 = dists[:, 0].cpu().numpy()
-        i0 = ids[:, 0].cpu().numpy()
-        assert (c == min(k, n_db)).all() and (d0 == 0).all(), "bench sanity check failed"
-        uniq_first = np.unique(q_np, return_index=True)[1]
-        assert (db_np[i0[uniq_first]] == q_np[uniq_first]).all(), "bench sanity check failed (ids)"
+    # sanity (every rank): every candidate is in the pool, so its nearest hit is itself at distance 0; and the
+    # gathered table holds this rank's rows at its shard offset (a double-buffer or gather regression shows here)
+    ids, dists, counts = ids_b[last_buf[0]], dists_b[last_buf[0]], counts_b[last_buf[0]]
+    c = counts.cpu().numpy()
+    d0 = dists[:, 0].cpu().numpy()
+    i0 = ids[:, 0].cpu().numpy()
+    assert (c == min(k, n_db)).all() and (d0 == 0).all(), "bench sanity check failed"
+    uniq_first = np.unique(q_np, return_index=True)[1]
+    assert (db_np[i0[uniq_first]] == q_np[uniq_first]).all(), "bench sanity check failed (ids)"
+    if world > 1:
+        g_ids, g_dists, g_counts = gathered
+        gb, lo = gathered_buf[0], rank * n_q
+        assert (g_ids[lo:lo + n_q].to(dev) == ids_b[gb]).all() and (g_dists[lo:lo + n_q].to(dev) == dists_b[gb]).all() \
+            and (g_counts[lo:lo + n_q].to(dev) == counts_b[gb]).all(), "gathered rows differ from the local result"
 
     if rank == 0:
-        pairs_per_step = float(world) * n_q * n_db
+        # weak: every rank scans n_q candidates; strong: the real candidate total (padding rows are not work)
+        pairs_per_step = (float(world) * n_q if args.scaling == "weak" else float(pool["packed_all"].shape[0])) * n_db
         value = pairs_per_step * args.steps / elapsed
         kern_s = float(np.mean(kernel_ms)) * 1e-3
         # pairs evaluated by ONE launch of the dominant kernel (the seeded phase of the two-phase scan
@@ -273,67 +363,25 @@ def main():
         # K1P resolves launch_pairs (all candidate x target pairs) but evaluates only those sharing a block
         evaluated_pairs, rescanned = idx.last_evaluated()
         evaluated_pairs = float(evaluated_pairs)
-        achieved = launch_pairs * B_ALG[pool["metric"]] / kern_s / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as fh:
-                traffic = json.load(fh).get(args.workload, {}).get("bytes_per_launch")
-        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,
-                "kernel_ms_avg": kern_s * 1e3, "launches_timed": int(len(kernel_ms)),
-                "query_device_ms": query_ms,
-                "algorithmic_bytes_per_pair": B_ALG[pool["metric"]], "pairs_per_launch": launch_pairs,
-                "note": "algorithmic (no-reuse) operand bytes / HIP-event kernel time; the scan is "
-                        "VALU-bound, not HBM-bound, so frac > 1 means LDS/register reuse beats the "
-                        "streaming model (SURVEY.md 8d)"}
-        if pool["metric"] != "hamming" and 10 <= L <= 27:
-            if "knn_bs" in kname:      # K2B: 5 ops per DP cell per 32 pairs + counts, compare, address bumps
-                band = (3 * L + 4) // 8
-                opp, reads = bitsliced_leven_ops_per_pair(L), (L * L - (L - band - 1) * (L - band)) / 32.0
-            else:                      # K2L: 11 VALU ops per text position + distance/threshold tail
-                opp, reads = 11.0 * L + 12.0, float(L)
-            ops = launch_pairs * opp / kern_s
-            roof["valu"] = {"achieved": ops / 1e12, "peak": VALU_LANE_OPS_PER_S / 1e12,
-                            "unit": "T lane-ops/s", "frac": ops / VALU_LANE_OPS_PER_S, "ops_per_pair": opp,
-                            "lds_reads_per_pair": reads,
-                            "note": "the binding roof for the Levenshtein scan: int32 VALU issue "
-                                    "(256 CUs x 128 lanes/clk x 2.4 GHz); the HBM figure above is not meaningful "
-                                    "for Levenshtein (SURVEY.md 8d)"}
-        if pool["metric"] == "hamming" and 10 <= L <= 27:
-            L_eval = L
-            if "scan_pg" in kname and idx.pigeon_blocks() > 0:      # K1P evaluates L - L // B positions
-                roof["pigeon_blocks"] = idx.pigeon_blocks()
-                L_eval = max(10, L - L // idx.pigeon_blocks())
-            opp = lookup_ops_per_pair(L_eval)
-            ops = evaluated_pairs * opp / kern_s
-            roof["pairs_evaluated"] = evaluated_pairs
-            roof["candidates_rescanned"] = int(rescanned)
-            roof["valu"] = {"achieved": ops / 1e12, "peak": VALU_LANE_OPS_PER_S / 1e12,
-                            "unit": "T lane-ops/s", "frac": ops / VALU_LANE_OPS_PER_S,
-                            "ops_per_pair": opp,
-                            "lds_reads_per_pair": L_eval / 64.0,
-                            "note": "the binding roofs: int32 VALU issue (256 CUs x 128 lanes/clk x 2.4 GHz) "
-                                    "and LDS read issue (L ds_read_b64 per 64 pairs per lane); computed on the "
-                                    "pairs the launch EVALUATED (pairs_evaluated; the pigeonhole-partitioned "
-                                    "scan resolves pairs_per_launch pairs by evaluating a fraction of them)"}
-        # the ALGORITHMIC op model (4 int32 ops per Hamming pair for the popcount form,
-        # 17 L per Levenshtein pair for per-pair Myers) against 256 CUs x 64 lanes/clk x 2.4 GHz; > 1 means
-        # the bit-sliced kernels need fewer instructions than that model assumes
-        alg_ops = 4.0 if pool["metric"] == "hamming" else 17.0 * L
-        roof["alg_valu"] = {"ops_per_pair": alg_ops, "achieved": launch_pairs * alg_ops / kern_s / 1e12,
-                            "peak": 39.3216, "unit": "T int32 ops/s",
-                            "frac": launch_pairs * alg_ops / kern_s / 39.3216e12}
+        roof = roofline_block(args.workload, pool, kname, kern_s, len(kernel_ms), query_ms, launch_pairs,
+                              evaluated_pairs, rescanned, idx.pigeon_blocks() if "scan_pg" in kname else 0, n_q, n_db)
         out = {
             "metric": "guide-pair distance comparisons/sec (whole node)",
             "value": value, "unit": "guide-pair comparisons/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
+            "value_note": "value = candidate x target pairs RESOLVED per second (every pair's membership in the exact "
+                          "k-NN answer is decided; BASELINE.md section 4's definition N_q x N_db / seconds); "
+                          "value_evaluated = distance evaluations actually EXECUTED per second (the pigeonhole "
+                          "partition proves the rest cannot be among the k nearest)",
+            "value_evaluated": float(world) * evaluated_pairs * args.steps / elapsed,      # (rank 0's count x ranks)
+            "rccl_world": (dist.get_world_size() if world > 1 else 1),
+            "collective_backend": (backend if world > 1 else None),
             "config": {"workload": pool["label"], "n_candidates_per_gpu": int(n_q), "n_targets": int(n_db),
                        "guidelen": L, "k": k, "distance": pool["metric"],
                        "parallelism": "candidate shards x%d, replicated pool, 1 RCCL all-gather per step"
-                                      "%s" % (world, " (overlapping the next step's scan)" if nbuf == 2 and use_async[0] else "")},
+                                      "%s" % (world, " (overlapping the next step's scan)" if nbuf == 2 and use_async else "")},
             "roofline": roof,
         }
         if world == 1:

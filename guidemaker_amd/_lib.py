@@ -138,7 +138,9 @@ def pack(seqs, guidelen):
     if n == 0:
         return out
     joined = "".join(seqs)
-    if len(joined) != n * guidelen or any(len(s) != guidelen for s in seqs[:1] + seqs[-1:]):
+    # every row must have the guide length (a mixed-length list whose lengths merely SUM to n * guidelen would
+    # otherwise be mis-framed silently)
+    if len(joined) != n * guidelen or not (np.fromiter(map(len, seqs), dtype=np.int64, count=n) == guidelen).all():
         raise ValueError("all sequences must have length %d" % guidelen)
     _check(lib().gm_pack(joined.encode("ascii"), n, guidelen, _ptr(out)))
     return out
@@ -286,9 +288,10 @@ def pam_scan(seq, pam, five_prime, guidelen, device=0):
     buf = seq.encode("ascii", "replace") if isinstance(seq, str) else bytes(seq)
     h = ctypes.c_void_p()
     nf, nr = ctypes.c_int64(), ctypes.c_int64()
-    _check(lib().gm_pam_count(buf, len(buf), pam.encode("ascii"), len(pam), 1 if five_prime else 0, guidelen,
-                              device, ctypes.byref(h), ctypes.byref(nf), ctypes.byref(nr)))
     try:
+        # (inside the try: gm_pam_count may fail after it has handed out the scan handle)
+        _check(lib().gm_pam_count(buf, len(buf), pam.encode("ascii"), len(pam), 1 if five_prime else 0, guidelen,
+                                  device, ctypes.byref(h), ctypes.byref(nf), ctypes.byref(nr)))
         n = nf.value + nr.value
         packed = np.empty((n,), np.uint64)
         tstart = np.empty((n,), np.int64)
@@ -296,7 +299,8 @@ def pam_scan(seq, pam, five_prime, guidelen, device=0):
         if n:
             _check(lib().gm_pam_emit(h, _ptr(packed), _ptr(tstart), _ptr(mstart)))
     finally:
-        lib().gm_pam_free(h)
+        if h.value:
+            lib().gm_pam_free(h)
     return packed, tstart, mstart, int(nf.value)
 
 
@@ -334,4 +338,9 @@ def unpack_keys_dev(keys_ptr, n_q, k, ids_ptr, dists_ptr, counts_ptr, stream=Non
 
 
 def device_count():
-    return lib().gm_device_count()
+    """GPUs visible to libgmhip; 0 when the library has not been built (the host-side numpy scanner and pandas filters
+    of core.py stay usable without it -- every SEARCH entry point still fails loudly)."""
+    try:
+        return lib().gm_device_count()
+    except (ImportError, OSError):
+        return 0

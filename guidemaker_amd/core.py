@@ -13,6 +13,8 @@ against this module; the work happens in libgmhip.so on an MI355X.  Mirrored sym
   TargetProcessor.export_bed                             reference core.py:525-543
   TargetProcessor.get_control_seqs                       reference core.py:545-633 -> gm_nearest_dist
   cfd_score(df)                                          reference core.py:1129-1148 -> gm_cfd_batch
+  format_neighbor_columns(tl, guides)                    reference core.py:913-931 (the two apply() closures of
+                                                         Annotation._format_guide_table), vectorised
 
 Deliberate, documented differences (DESIGN.md "Parity contract"):
   * the search is exact, not HNSW: the NMSLIB block of the config is read and ignored;
@@ -25,8 +27,10 @@ Deliberate, documented differences (DESIGN.md "Parity contract"):
 import hashlib
 import itertools
 import json
+import logging
 import os
 import statistics
+import time
 from collections.abc import Mapping
 from copy import deepcopy
 from itertools import product
@@ -37,6 +41,8 @@ import pandas as pd
 import yaml
 
 from . import _lib
+
+logger = logging.getLogger("guidemaker")      # the reference's logger name (cli.py:20-22)
 
 _DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 CONFIG_PATH = os.path.join(_DATA, "config_default.yaml")
@@ -185,6 +191,7 @@ class PamTarget:
         """All targets next to the PAM on both strands, as the reference's dataframe."""
         five = self.pam_orientation == "5prime"
         frames = []
+        packed_parts = []
         # the PAM scan runs on the GPU when one is visible (and the guide fits the packed format);
         # the numpy scanner is the host implementation of the same step
         on_gpu = target_len <= _lib.MAX_GUIDELEN and len(self.pam) <= 16 and _lib.device_count() > 0
@@ -215,6 +222,8 @@ class PamTarget:
             df["seqid"] = record.id
             # per strand block the reference casts separately; the concatenation below matches it
             frames.append(df)
+            if target_len <= _lib.MAX_GUIDELEN:
+                packed_parts.append(res["packed"] if on_gpu else pack_codes(res["codes"]))
         if not frames:
             raise ValueError("No objects to concatenate")   # what pd.concat([]) raises in the reference
         df_targets = pd.concat(frames, ignore_index=True)
@@ -225,6 +234,11 @@ class PamTarget:
         df_targets = df_targets.astype({"seedseq": "str", "isseedduplicated": "bool"})
         df_targets = df_targets.assign(dtype=self.dtype)
         df_targets = df_targets.astype({"dtype": "category"})
+        if packed_parts:
+            # side-car for TargetProcessor: the 2-bit packed form of the 'target' column (the boundary format of
+            # include/gmhip.h), so that the filters, create_index and get_neighbors do not re-encode the strings
+            df_targets.attrs["gm_packed"] = np.concatenate(packed_parts)
+            df_targets.attrs["gm_guidelen"] = int(target_len)
         return df_targets
 
 
@@ -292,7 +306,7 @@ class TargetProcessor:
     """A set of guide RNA targets and its MI355X-resident neighbour index."""
 
     def __init__(self, targets: pd.DataFrame, lsr: int, editdist: int = 2, knum: int = 2,
-                 device: int = 0) -> None:
+                 device: int = 0, shard_candidates: bool = None) -> None:
         self.targets = targets
         self.lsr: int = lsr
         self.editdist: int = editdist
@@ -305,7 +319,14 @@ class TargetProcessor:
         self.genomesize: float = None
         self.pam_orientation: bool = targets['pam_orientation'].iat[0]
         self.device = device
+        # multi-GPU: one process per GPU, every process holds the SAME targets frame; opt in with
+        # shard_candidates=True (or GM_SHARD_CANDIDATES=1) -- an initialised process group alone does not switch it
+        # on, because ranks that work on different genomes must not enter a collective together
+        if shard_candidates is None:
+            shard_candidates = os.environ.get("GM_SHARD_CANDIDATES", "0") not in ("", "0")
+        self.shard_candidates = bool(shard_candidates)
         self._db_targets = None               # index id -> sequence
+        self._packed_cache = None             # ((id(frame), rows), (packed, L) or None): see _packed_targets
         self._guidelen = None
         self.last_knn = None                  # (ids, dists, counts) of the last get_neighbors
 
@@ -319,19 +340,42 @@ class TargetProcessor:
         # anything but "hamming" selects Levenshtein (reference core.py:448,496,509)
         return self.targets['dtype'].iat[0] == "hamming"
 
-    def _packed_for_filters(self):
-        """(packed uint64, guide length) of the frame's targets when the GPU filters apply (a GPU is
-        visible, one common length <= 27, ACGT only), else None -> host (pandas) form of the same filter."""
+    def _packed_targets(self):
+        """(packed uint64 [len(targets)], guide length) of the frame's 'target' column, encoded ONCE per frame: taken
+        from the side-car find_targets attaches (frame.attrs['gm_packed'], checked against the strings on a few
+        rows), else packed here; cached until the column object or its length changes.  None when the targets have no
+        common length <= 27 or contain non-ACGT letters."""
         t = self.targets['target']
-        if len(t) == 0 or _lib.device_count() <= 0:
+        n = len(t)
+        key = (id(self.targets), n)
+        if self._packed_cache is not None and self._packed_cache[0] == key:
+            return self._packed_cache[1]
+        out = None
+        if n:
+            L = len(t.iat[0])
+            side = self.targets.attrs.get("gm_packed")
+            if (side is not None and self.targets.attrs.get("gm_guidelen") == L and len(side) == n
+                    and 1 <= L <= _lib.MAX_GUIDELEN):
+                probe = sorted({0, n // 3, n // 2, n - 1})
+                try:
+                    if (_lib.pack([t.iat[i] for i in probe], L) == side[probe]).all():
+                        out = (np.ascontiguousarray(side, dtype=np.uint64), L)
+                except ValueError:
+                    out = None
+            if out is None and 1 <= L <= _lib.MAX_GUIDELEN:
+                try:
+                    out = (_lib.pack(t.tolist(), L), L)
+                except ValueError:
+                    out = None
+        self._packed_cache = (key, out)
+        return out
+
+    def _packed_for_filters(self):
+        """The packed targets when the GPU filters apply (a GPU is visible, one common length <= 27, ACGT only), else
+        None -> host (pandas) form of the same filter."""
+        if len(self.targets) == 0 or _lib.device_count() <= 0:
             return None
-        L = len(t.iat[0])
-        if L < 1 or L > _lib.MAX_GUIDELEN:
-            return None
-        try:
-            return _lib.pack(t.tolist(), L), L
-        except ValueError:
-            return None
+        return self._packed_targets()
 
     def check_restriction_enzymes(self, restriction_enzyme_list: list = []) -> None:
         """Flag targets containing a restriction site or its reverse complement (reference
@@ -367,7 +411,9 @@ class TargetProcessor:
     def find_unique_near_pam(self) -> None:
         """Flag targets whose PAM-proximal seed (length lsr) already occurred earlier in the frame
         (reference core.py:388-416).  On the GPU: gm_seed_duplicated on the packed words."""
+        cached = self._packed_targets()       # (the copy below holds the same rows: carry the encoded column over)
         self.targets = deepcopy(self.targets)
+        self._packed_cache = ((id(self.targets), len(self.targets)), cached)
         t = self.targets['target']
         if self.lsr == 0:
             seed = t
@@ -398,16 +444,30 @@ class TargetProcessor:
             config = yaml.safe_load(cf)
         # read for interface compatibility; an exact scan has no M / efC / post
         _ = config['NMSLIB']['M'], config['NMSLIB']['efc'], config['NMSLIB']['post']
-        notduplicated = pd.unique(self.targets['target'])       # first-occurrence order
-        self._db_targets = np.asarray(notduplicated, dtype=object)
+        pk = self._packed_targets()
+        if pk is not None:
+            # de-duplicate on the packed words: first-occurrence order (the reference's list(set(...)) order is
+            # arbitrary, core.py:446)
+            _, first = np.unique(pk[0], return_index=True)
+            first.sort()
+            packed = pk[0][first]
+            self._db_targets = self.targets['target'].to_numpy(dtype=object)[first]
+        else:
+            self._db_targets = np.asarray(pd.unique(self.targets['target']), dtype=object)
+            packed = None
         self._guidelen = len(self._db_targets[0])
         if self._guidelen > _lib.MAX_GUIDELEN:
             raise ValueError("guide length %d exceeds %d" % (self._guidelen, _lib.MAX_GUIDELEN))
         metric = _lib.METRIC_HAMMING if self._is_hamming() else _lib.METRIC_LEVEN
-        packed = _lib.pack(self._db_targets.tolist(), self._guidelen)
+        if packed is None:
+            packed = _lib.pack(self._db_targets.tolist(), self._guidelen)
         if self.nmslib_index is not None:
             self.nmslib_index.close()
+        t0 = time.perf_counter()
         self.nmslib_index = _lib.Index(packed, self._guidelen, metric, self.device)
+        logger.info("create_index: N_db=%d unique targets of %d (guide length %d, %s) resident on GPU %d in %.3f s",
+                    len(self._db_targets), len(self.targets), self._guidelen,
+                    "hamming" if metric == _lib.METRIC_HAMMING else "leven", self.device, time.perf_counter() - t0)
 
     def _query_targets(self) -> list:
         # the OR is the reference's (core.py:495)
@@ -422,14 +482,26 @@ class TargetProcessor:
         with open(configpath) as cf:
             config = yaml.safe_load(cf)
         _ = config['NMSLIB']['ef']
-        unique_targets = self._query_targets()
-        qpacked = _lib.pack(unique_targets, self._guidelen)
-        from . import distributed
-        if distributed.is_distributed():
-            # one process per GPU: scan this rank's shard of the candidates, one all-gather of the lists
-            ids, dists, counts = distributed.sharded_knn(self.nmslib_index.knn, qpacked, self.knum)
+        t = self.targets
+        qmask = ((t['isseedduplicated'] == False) | (t['hasrestrictionsite'] == False)).to_numpy()      # core.py:495
+        unique_targets = t['target'].to_numpy(dtype=object)[qmask].tolist()
+        pk = self._packed_targets()
+        qpacked = pk[0][qmask] if pk is not None else _lib.pack(unique_targets, self._guidelen)
+        t0 = time.perf_counter()
+        sharded = False
+        if self.shard_candidates:
+            from . import distributed
+            sharded = distributed.is_distributed()
+        if sharded:
+            # one process per GPU: scan this rank's shard of the candidates on the device, one all-gather of the lists
+            ids, dists, counts = distributed.sharded_knn_index(self.nmslib_index, qpacked, self.knum, self.device)
         else:
             ids, dists, counts = self.nmslib_index.knn(qpacked, self.knum)
+        dt = time.perf_counter() - t0
+        n_q, n_db = len(unique_targets), len(self._db_targets)
+        logger.info("get_neighbors: N_q=%d candidates x N_db=%d targets, k=%d, %s: %.3f s (%.3e guide pairs/s)%s",
+                    n_q, n_db, self.knum, "hamming" if self._is_hamming() else "leven", dt,
+                    n_q * n_db / max(dt, 1e-9), " [sharded]" if sharded else "")
         self.last_knn = (ids, dists, counts)
         if len(unique_targets) and (self.knum < 2 or int(counts.min()) < 2):
             raise IndexError("list index out of range")      # editdist[1] in the reference (core.py:512)
@@ -487,13 +559,29 @@ class TargetProcessor:
         self.gc_percent = gc * 100
         self.genomesize = totlen / (1024 * 1024)
 
+        if self.nmslib_index is None:
+            raise ValueError("get_control_seqs: no index -- call create_index() first")
+        if length != self._guidelen:
+            # (the kernels compare equal-length sequences; nmslib's leven would accept other lengths)
+            raise ValueError("get_control_seqs: length=%d differs from the indexed guide length %d"
+                             % (length, self._guidelen))
         minimum_hmdist = 0
         sm_count = 0
         search_mult = 0
+        n_searched = 0
+        t0 = time.perf_counter()
         hamming = self._is_hamming()
         try:
             # loop condition (and its walk off the end of the list) as in the reference, core.py:586
             while minimum_hmdist < MINIMUM_HMDIST or search_mult == MAX_CONTROL_SEARCH_MULTIPLE:
+                if sm_count >= len(CONTROL_SEARCH_MULTIPLE):
+                    # the reference's CONTROL_SEARCH_MULTIPLE[sm_count] raises a bare "list index out of range" here
+                    # (core.py:587, re-raised at :619-620); same exception type, with the cause spelled out
+                    raise IndexError(
+                        "list index out of range: no %d control sequences at distance >= CONTROL.MINIMUM_HMDIST=%s "
+                        "from every target after CONTROL.CONTROL_SEARCH_MULTIPLE=%s x n draws (best minimum %d over "
+                        "%d targets; the search is exact, so on large genomes lower MINIMUM_HMDIST in the config)"
+                        % (n, MINIMUM_HMDIST, CONTROL_SEARCH_MULTIPLE, minimum_hmdist, len(self._db_targets)))
                 search_mult = CONTROL_SEARCH_MULTIPLE[sm_count]
                 # candidates stay numeric (codes -> packed words) until the n winners are known: at the
                 # largest multiple this is 10^4 * n sequences
@@ -508,8 +596,13 @@ class TargetProcessor:
                     sort_dist = [int(d1[i]) for i in order.tolist()]
                 minimum_hmdist = int(min(sort_dist))
                 sm_count += 1
+                n_searched += n * search_mult
         except IndexError as e:
             raise e
+        dt = time.perf_counter() - t0
+        logger.info("get_control_seqs: %d random %d-mers x N_db=%d targets in %.3f s (%.3e guide pairs/s), minimum "
+                    "distance %s", n_searched, length, len(self._db_targets), dt,
+                    n_searched * len(self._db_targets) / max(dt, 1e-9), min(sort_dist))
 
         total_ncontrolsearched = search_mult * n
         self.ncontrolsearched = total_ncontrolsearched
@@ -520,6 +613,85 @@ class TargetProcessor:
         randomdf['name'] = randomdf["Sequences"].apply(create_name)
         randomdf = randomdf[["name", "Sequences", "Hamming distance"]]
         return (min(sort_dist), statistics.median(sort_dist), randomdf)
+
+
+# ------------------------------------------------------------------------------------------------
+# neighbors -> output-table columns
+# ------------------------------------------------------------------------------------------------
+def _join_rows_fixed(mat: np.ndarray) -> List[str]:
+    """(n, w) uint8 -> list of n str (one C-level conversion)."""
+    if mat.shape[0] == 0:
+        return []
+    return np.ascontiguousarray(mat).view("S%d" % mat.shape[1]).ravel().astype(str).tolist()
+
+
+def format_neighbor_columns(targetprocessor_object, guide_sequences):
+    """The two neighbour columns of the reference's output table, without its per-row Python closures.
+
+    Reference: Annotation._format_guide_table (core.py:913-931) builds, for every row of the guide table,
+        'Similar guides'          = ";".join(tl.neighbors[seq]["neighbors"]["seqs"])
+        'Similar guide distances' = ";".join(str(i) for i in tl.neighbors[seq]["neighbors"]["dist"])
+    with two DataFrame.apply calls that go through the neighbors dict row by row.  Here both columns come straight
+    from the k-NN result arrays: one id -> sequence take, one fixed-width byte matrix for the sequences (every row
+    with k hits has the same width) and one ragged byte buffer for the distances (one or two digits each).
+    Returns (similar_guides, similar_guide_distances), lists aligned with guide_sequences, byte-identical to the
+    reference's strings.  A sequence that is not a key of .neighbors raises KeyError, as the dict lookup would.
+    """
+    nb = targetprocessor_object.neighbors
+    guides = list(guide_sequences)
+    if not isinstance(nb, NeighborMap):      # a plain dict (e.g. filled by hand): the reference's own loops
+        return ([";".join(nb[g]["neighbors"]["seqs"]) for g in guides],
+                [";".join(str(i) for i in nb[g]["neighbors"]["dist"]) for g in guides])
+    n = len(guides)
+    if n == 0:
+        return [], []
+    rowmap = nb._rows()
+    rows = np.fromiter((rowmap[g] for g in guides), dtype=np.int64, count=n)
+    ids, dists, counts = nb.ids[rows], nb.dists[rows], nb.counts[rows]
+    k = ids.shape[1]
+    db = nb._db
+    L = len(db[0]) if len(db) else 0
+    full = counts == k
+    sim = np.empty(n, dtype=object)
+    dst = np.empty(n, dtype=object)
+    if full.any():
+        fi = np.flatnonzero(full)
+        # sequences: k fields of L bytes with ';' between them -- one fixed-width byte matrix
+        db_bytes = np.frombuffer("".join(db.tolist()).encode("ascii"), dtype=np.uint8).reshape(-1, L)
+        mat = np.full((fi.size, k * (L + 1)), ord(";"), dtype=np.uint8)
+        mat.reshape(fi.size, k, L + 1)[:, :, :L] = db_bytes[ids[fi]]
+        sim[fi] = _join_rows_fixed(mat[:, :k * (L + 1) - 1])
+        # distances: [tens digit][ones digit][';'] per hit, tens digit only for d >= 10, no ';' after the last hit
+        d = dists[fi].astype(np.int64)
+        parts = np.empty((fi.size, k, 3), dtype=np.uint8)
+        parts[:, :, 0] = ord("0") + d // 10
+        parts[:, :, 1] = ord("0") + d % 10
+        parts[:, :, 2] = ord(";")
+        use = np.ones((fi.size, k, 3), dtype=bool)
+        use[:, :, 0] = d >= 10
+        use[:, k - 1, 2] = False
+        if (d >= 100).any():                 # (cannot happen for guides of <= 27 bases; keep the general path honest)
+            full_rows = fi.tolist()
+            dst[fi] = [";".join(str(int(x)) for x in dists[r]) for r in full_rows]
+        else:
+            flat = parts[use].tobytes().decode("ascii")
+            ends = np.cumsum(use.sum(axis=(1, 2)))
+            starts = ends - use.sum(axis=(1, 2))
+            dst[fi] = [flat[a:b] for a, b in zip(starts.tolist(), ends.tolist())]
+    for r in np.flatnonzero(~full).tolist():          # rows with fewer than k hits (index smaller than k)
+        c = int(counts[r])
+        sim[r] = ";".join(db[ids[r, :c]].tolist())
+        dst[r] = ";".join(str(int(x)) for x in dists[r, :c])
+    return sim.tolist(), dst.tolist()
+
+
+def neighbor_table(targetprocessor_object) -> pd.DataFrame:
+    """Frame with one row per retained guide (the keys of .neighbors, first-seen order) and the columns
+    'Guide sequence', 'Similar guides', 'Similar guide distances' -- what _format_guide_table (core.py:925-931) adds to
+    the guide table, ready for cfd_score()."""
+    keys = list(targetprocessor_object.neighbors.keys())
+    sim, dst = format_neighbor_columns(targetprocessor_object, keys)
+    return pd.DataFrame({"Guide sequence": keys, "Similar guides": sim, "Similar guide distances": dst})
 
 
 # ------------------------------------------------------------------------------------------------

@@ -24,9 +24,11 @@ struct gm_pg_blocks {
     int n_sub;                           // S: the 1 + 3 * xlen target buckets of an expansion block's chunk are split
                                          // over S workgroups; list of (b < X, s) = b * S + s, of b >= X: X * S + b - X
     int n_lists;
-    int lcap[GM_PG_MAXLISTS];            // words per candidate of list l (word 0 = hit count, then the keys)
+    int run;                             // consecutive chunk-table entries executed on the same XCD
+    int row_words;                       // words of all lists of one candidate: its lists are contiguous in the hit buffer
+    int lcap[GM_PG_MAXLISTS];            // words of list l (word 0 = hit count, then the keys); a multiple of 4
     int loff[GM_PG_MAXLISTS];            // sum of lcap over the lists before l: list l of candidate q starts at word
-                                         // loff[l] * n_q + q * lcap[l] of the hit buffer
+                                         // q * row_words + loff[l] of the hit buffer
 };
 
 // one workgroup's work: cn (<= 64) candidates starting at sorted position c0 of block b's candidate order, all

@@ -339,7 +339,8 @@ struct gm_pigeon {
                                        // serve radius r = B + X - 1
     int skip_len = 0;                  // positions of its own block each copy's table leaves out
     int Lp = 0;                        // positions the scan evaluates = L - skip_len (>= 10)
-    int tune_sub = 4;                  // workgroups per expansion chunk (gm_set_param "pg_sub")
+    int tune_sub = 2;                  // workgroups per expansion chunk (gm_set_param "pg_sub")
+    int tune_run = 128;                // chunk-table entries per XCD run (gm_set_param "pg_run")
     int bstart[GM_PG_MAXB]{}, blen[GM_PG_MAXB]{};
     int ebase[GM_PG_MAXB + 1]{};
     // pool side
@@ -541,6 +542,11 @@ int gm_pg_set_param(gm_index* idx, const char* name, int value) {
     if (std::strcmp(name, "pg_sub") == 0) {
         if (value < 1 || value > 19) return gm_fail(GM_ERR_ARG, "pg_sub: 1..19");
         idx->pg->tune_sub = value;
+        return GM_OK;
+    }
+    if (std::strcmp(name, "pg_run") == 0) {
+        if (value < 1 || value > 65536) return gm_fail(GM_ERR_ARG, "pg_run: 1..65536");
+        idx->pg->tune_run = value;
         return GM_OK;
     }
     return gm_fail(GM_ERR_ARG, std::string("unknown parameter ") + name);
@@ -785,15 +791,13 @@ static void pg_list_capacity(const gm_index* idx, gm_pigeon* pg, int64_t n_q) {
             P.loff[l] = (int)words;
             words += cap;
         }
+        P.row_words = (int)words;
         if ((double)words * (double)n_q * 4.0 <= pg->mem_limit || scale < 0.05) break;
         scale *= 0.75;
     }
 }
 
-int64_t gm_pg_list_words(const gm_pigeon* pg) {
-    const gm_pg_blocks& P = pg->blocks;
-    return P.n_lists > 0 ? (int64_t)P.loff[P.n_lists - 1] + P.lcap[P.n_lists - 1] : 0;
-}
+int64_t gm_pg_list_words(const gm_pigeon* pg) { return pg->blocks.row_words; }
 
 int gm_pg_scan(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
     gm_pigeon* pg = idx->pg;
@@ -822,7 +826,9 @@ int gm_pg_scan(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
     blocks.xlen = pg->expand ? pg->blen[0] : 0;
     blocks.n_sub = n_sub;
     const int thr0 = pg->B + pg->expand;      // accept d < thr0, i.e. d <= r = B + X - 1
-    const int64_t grid = (pg->grid + 8 * gm::PG_RUN - 1) / (8 * gm::PG_RUN) * (8 * gm::PG_RUN);
+    blocks.run = pg->tune_run;
+    const int64_t unit = 8 * (int64_t)blocks.run;      // the kernel's entry mapping permutes whole units
+    const int64_t grid = (pg->grid + unit - 1) / unit * unit;
     switch (pg->Lp) {            // the kernel instantiated for the positions actually evaluated
 #define GM_CASE(LEN) \
     case LEN: return gm_launch_pg_L##LEN(idx, &blocks, pg->chunks, &pg->ctr->n_chunks, grid, n_q, k, thr0, pg->lists, st);

@@ -20,9 +20,9 @@
 //   * FLUSH (when 64 entries are queued, and at the end): lane e takes entry e -- all 64 lanes busy -- , walks its
 //     hit bits (almost always one), gathers the 16-byte record of the target {planes, pool id} from the sorted
 //     copy, recomputes the distance with one xor / or / popcount, takes a slot in the candidate's hit list from a
-//     counter in LDS and stores (distance << 27 | pool id) to the list in HBM.  The lists of one workgroup are
-//     private to it and contiguous per candidate (word 0 = count), so the 4-byte stores of a list combine in the
-//     L2 of the workgroup's XCD and the merge reads whole lines.
+//     counter in LDS and stores (distance << 27 | pool id) to the list in HBM.  A list has one writer (this
+//     workgroup) and all lists of a candidate are contiguous (word 0 of each = count), so the 4-byte stores of a
+//     list combine in the L2 of the workgroup's XCD and the merge reads one contiguous run per candidate.
 // Bound tightening needs no sorted list: per candidate the flush counts the hits closer than r and closer than
 // r - 1; once k of them are known nothing at distance r (r - 1) can enter the top k.  k = 1 follows the best distance.
 // k_merge_hits folds the lists of a candidate (duplicates -- pairs that share several blocks -- taken once) into
@@ -35,7 +35,6 @@
 namespace gm {
 
 constexpr int PG_QCAP = 128;          // ring of queued hit words per wave (a flush takes 64, a group adds <= 64)
-constexpr int PG_RUN = 16;            // consecutive chunk-table entries executed on the same XCD
 constexpr int PG_MERGE_SPLIT = 4;     // threads per candidate in k_merge_hits
 
 // dynamic LDS of k_hamming_scan_pg<L>: two DMA buffers of two groups each, the ring, per-candidate state
@@ -105,7 +104,7 @@ struct PgQueue {
 
 // FLUSH: n (<= 64, wave-uniform) queued hit words are turned into list entries, one per lane.
 __device__ __forceinline__ void pg_flush(PgQueue& Q, int n, int lane, const uint4* __restrict__ recs,
-                                         uint32_t* __restrict__ lists, int lcap, int k, int thr0) {
+                                         uint32_t* __restrict__ lists, int lcap, int row_words, int k, int thr0) {
     uint32_t tg = 0;
     uint2 m = make_uint2(0u, 0u);
     if (lane < n) {
@@ -131,7 +130,7 @@ __device__ __forceinline__ void pg_flush(PgQueue& Q, int n, int lane, const uint
             if (d < thr0 - 2) atomicAdd(&Q.c2[cl], 1);
         }
         const int slot = atomicAdd(&Q.cnt[cl], 1) + 1;      // word 0 of a list is its count
-        if (slot < lcap) lists[row * lcap + slot] = ((uint32_t)d << ID_BITS) | t.z;
+        if (slot < lcap) lists[row * row_words + slot] = ((uint32_t)d << ID_BITS) | t.z;
     }
     __syncthreads();      // single-wave workgroup: orders the LDS atomics before the reads of the counters below
 }
@@ -172,11 +171,11 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
     extern __shared__ __align__(16) uint32_t smem[];
     constexpr int GW = lk_group_words(L);
     constexpr int PW = pg_pair_words(L);
-    // XCD-aware order: workgroups are dealt to the 8 XCDs round-robin; give every XCD runs of PG_RUN consecutive
+    // XCD-aware order: workgroups are dealt to the 8 XCDs round-robin; give every XCD runs of P.run consecutive
     // chunk-table entries (the chunks of one candidate bucket share their target buckets: same L2)
     const int n = *n_chunks;
     const int wg = (int)blockIdx.x, xcd = wg & 7, slot = wg >> 3;
-    const int entry = (slot / PG_RUN) * (8 * PG_RUN) + xcd * PG_RUN + (slot % PG_RUN);
+    const int entry = (slot / P.run) * (8 * P.run) + xcd * P.run + (slot % P.run);
     if (entry >= n) return;
     const gm_pg_chunk ch = chunks[entry];
     const uint32_t* __restrict__ table = P.table[ch.b];
@@ -212,8 +211,8 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
         const uint32_t code = ((qv.x >> sp) & 1u) | (((qv.y >> sp) & 1u) << 1);
         ptr[p] = tiles + p * 8 + (int)code * 2;
     }
-    const int lcap = P.lcap[ch.lst];
-    uint32_t* __restrict__ mylists = lists + (int64_t)P.loff[ch.lst] * n_q;
+    const int lcap = P.lcap[ch.lst], row_words = P.row_words;
+    uint32_t* __restrict__ mylists = lists + P.loff[ch.lst];     // list of candidate row: mylists + row * row_words
     int thr = valid ? thr0 : 0;                                 // accept d < thr
     uint32_t Tb[5];
 
@@ -225,7 +224,7 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
     // flush when a full wave of entries is queued; afterwards the bounds may have tightened
 #define GM_PG_AFTER_GROUP(ADD)                                                    \
     if (Q.tail - Q.head >= WAVE) {                                                \
-        pg_flush(Q, WAVE, lane, recs, mylists, lcap, k, thr0);                    \
+        pg_flush(Q, WAVE, lane, recs, mylists, lcap, row_words, k, thr0);                    \
         const int nt = pg_bound(Q, lane, k, thr0);                                \
         if (valid && nt < thr) thr = nt;                                          \
         lk_set_bound(Tb, L, thr - (ADD));                                         \
@@ -262,9 +261,9 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
 #undef GM_PG_AFTER_GROUP
     while (Q.tail - Q.head > 0) {
         const int n_take = Q.tail - Q.head < WAVE ? Q.tail - Q.head : WAVE;
-        pg_flush(Q, n_take, lane, recs, mylists, lcap, k, thr0);
+        pg_flush(Q, n_take, lane, recs, mylists, lcap, row_words, k, thr0);
     }
-    if (valid) mylists[qi * lcap] = (uint32_t)Q.cnt[lane];      // every (list, candidate) pair has exactly one writer
+    if (valid) mylists[qi * row_words] = (uint32_t)Q.cnt[lane];      // every (list, candidate) pair has exactly one writer
 }
 
 // K1P merge: PG_MERGE_SPLIT adjacent lanes per candidate, each folding every PG_MERGE_SPLIT-th hit list into its
@@ -285,7 +284,7 @@ __global__ void k_merge_hits(gm_pg_blocks P, const uint32_t* __restrict__ lists,
     int overflow = 0;
     for (int l = sub; l < P.n_lists; l += PG_MERGE_SPLIT) {
         const int lcap = P.lcap[l];                    // multiple of 4
-        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(lists + (int64_t)P.loff[l] * n_q + qi * lcap);
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(lists + qi * P.row_words + P.loff[l]);
         uint4 w = src[0];
         int c = (int)w.x;
         if (c > lcap - 1) {

@@ -139,3 +139,48 @@ def sharded_knn(local_knn, q_packed, k, device=None, group=None):
     t = [torch.from_numpy(a).to(device) for a in (ids, dists, counts)]
     g = all_gather_neighbors(t[0], t[1], t[2], n, group)
     return tuple(x.cpu().numpy() for x in g)
+
+
+def _check_same_candidates(q_packed, device, group=None):
+    """Every rank must hold the same candidate array: compare (n, xor, sum) fingerprints across the ranks BEFORE the
+    shapes of the collective depend on them (ranks working on different frames would hang or mix results)."""
+    import torch
+    dist = _dist()
+    q = np.ascontiguousarray(q_packed, dtype=np.uint64)
+    fp = np.array([q.shape[0], int(np.bitwise_xor.reduce(q)) & 0x7FFFFFFFFFFFFFFF if q.size else 0,
+                   int(q.sum(dtype=np.uint64)) & 0x7FFFFFFFFFFFFFFF if q.size else 0], dtype=np.int64)
+    mine = torch.from_numpy(fp).to(device)
+    world = dist.get_world_size(group)
+    allfp = torch.empty((world, 3), dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(allfp, mine.reshape(1, 3), group=group)
+    if not bool((allfp == mine.reshape(1, 3)).all().item()):
+        raise RuntimeError("sharded_knn: the ranks hold different candidate sets (n / fingerprint per rank: %s); "
+                           "sharding needs the same targets frame on every rank" % allfp.cpu().tolist())
+
+
+def sharded_knn_index(index, q_packed, k, device_ordinal=0, group=None):
+    """k-NN of all candidates with the work split over the ranks; `index` is this rank's guidemaker_amd._lib.Index.
+    On the RCCL backend the shard's query, its neighbour lists and the gathered table stay on the GPU from the scan
+    (Index.knn_dev) through the all-gather; only the final table comes back to the host.  Other backends (gloo, CPU
+    rehearsal) go through host arrays."""
+    import torch
+    dist = _dist()
+    if dist.get_backend(group) != "nccl":
+        _check_same_candidates(q_packed, "cpu", group)
+        return sharded_knn(index.knn, q_packed, k, device="cpu", group=group)
+    dev = torch.device("cuda", device_ordinal)
+    _check_same_candidates(q_packed, dev, group)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    q_packed = np.ascontiguousarray(q_packed, dtype=np.uint64)
+    n = int(q_packed.shape[0])
+    lo, hi, per = shard_range(n, world, rank)
+    with torch.cuda.device(dev):
+        ids = torch.full((per, k), -1, dtype=torch.int32, device=dev)
+        dists = torch.full((per, k), -1, dtype=torch.int32, device=dev)
+        counts = torch.zeros((per,), dtype=torch.int32, device=dev)
+        if hi > lo:
+            d_q = torch.from_numpy(q_packed[lo:hi].view(np.int64)).to(dev)
+            st = torch.cuda.current_stream(dev).cuda_stream
+            index.knn_dev(d_q.data_ptr(), hi - lo, k, ids.data_ptr(), dists.data_ptr(), counts.data_ptr(), st)
+        g = all_gather_neighbors(ids, dists, counts, n, group)
+        return tuple(x.cpu().numpy() for x in g)

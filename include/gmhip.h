@@ -170,8 +170,9 @@ int gm_timing_read(gm_index* idx, double* ms_out, int max_n);
  *   Levenshtein: 2 = per-pair Myers kernel K2L; 1 = plane-based kernel (also used for L < 10 and k > 20). */
 int gm_set_variant(gm_index* idx, int variant);
 /* Named tuning knobs (experiments; results are identical for every value).
- *   "pg_sub" (1..19, default 4): workgroups the target buckets of one expansion chunk of the pigeonhole-partitioned
- *   scan are split over (more = shorter work items and more hit lists per candidate). */
+ *   "pg_sub" (1..19, default 2): workgroups the target buckets of one expansion chunk of the pigeonhole-partitioned
+ *   scan are split over (more = shorter work items and more hit lists per candidate);
+ *   "pg_run" (default 128): consecutive chunk-table entries of that scan executed on the same XCD. */
 int gm_set_param(gm_index* idx, const char* name, int value);
 
 #ifdef __cplusplus

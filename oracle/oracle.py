@@ -247,6 +247,19 @@ class OracleTargetProcessor:
         return min(sort_dist), statistics.median(sort_dist)
 
 
+def format_neighbor_columns(neighbors, guides):
+    """Annotation._format_guide_table's two closures restated (reference core.py:913-921, applied at :930-931):
+    get_off_target_seqs -> ";".join(seqs), get_off_target_score -> ";".join(str(i) for i in dist).
+    neighbors: the dict get_neighbors builds.  -> (similar guides list, similar guide distances list)"""
+    sims, dsts = [], []
+    for seq in guides:
+        slist = neighbors[seq]["neighbors"]["seqs"]
+        sims.append(";".join(slist))
+        dlist = neighbors[seq]["neighbors"]["dist"]
+        dsts.append(";".join([str(i) for i in dlist]))
+    return sims, dsts
+
+
 def cfd_score_rows(guides, similar_guides, mm):
     """core.py:1129-1148 on plain lists: returns (list of list[str], list of max)."""
     out, mx = [], []

@@ -16,16 +16,13 @@ from guidemaker_amd import _lib  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--seconds", type=float, default=60.0)
-    ap.add_argument("--seed", type=int, default=1)
-    a = ap.parse_args()
+def run(seconds, seed, max_cases=None):
+    """Runs random cases for `seconds` (or max_cases); returns (cases run, description of the first mismatch or None)."""
     orc.build()
-    rng = random.Random(a.seed)
-    t_end = time.time() + a.seconds
+    rng = random.Random(seed)
+    t_end = time.time() + seconds
     n_cases = 0
-    while time.time() < t_end:
+    while time.time() < t_end and (max_cases is None or n_cases < max_cases):
         L = rng.randint(10, 27)
         metric = rng.choice(["hamming", "hamming", "leven"])
         n_db = rng.choice([1, 2, 63, 64, 65, 255, 256, 257, 511, 513, rng.randint(3, 3000), rng.randint(3000, 9000)])
@@ -46,7 +43,7 @@ def main():
         variant = 0
         if metric == "hamming":
             B = rng.randint(2, 8)
-            variant = rng.choice([0, 8, 100 + B, 200 + B, 300 + B])
+            variant = rng.choice([0, 8, 100 + B, 200 + B, 300 + B, 400 + B, 600 + B, 700 + B])
         idx = _lib.Index(_lib.pack(db, L), L, _lib.METRIC_HAMMING if metric == "hamming" else _lib.METRIC_LEVEN)
         idx.set_variant(variant)
         qp = _lib.pack(q, L)
@@ -59,10 +56,21 @@ def main():
             od = np.where(od >= 0, od // 2, -1)
         ok = (ids == oi).all() and (dists == od).all() and (counts == oc).all() and (d1 == od[:, 0]).all()
         if not ok:
-            print("MISMATCH: L=%d metric=%s n_db=%d n_q=%d k=%d variant=%d kernel=%s seed=%d case=%d"
-                  % (L, metric, len(db), n_q, k, variant, kern, a.seed, n_cases))
-            sys.exit(1)
+            return n_cases, ("MISMATCH: L=%d metric=%s n_db=%d n_q=%d k=%d variant=%d kernel=%s seed=%d case=%d"
+                             % (L, metric, len(db), n_q, k, variant, kern, seed, n_cases))
         n_cases += 1
+    return n_cases, None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=60.0)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    n_cases, bad = run(a.seconds, a.seed)
+    if bad:
+        print(bad)
+        sys.exit(1)
     print("fuzz: %d cases ok (seed %d)" % (n_cases, a.seed))
 
 

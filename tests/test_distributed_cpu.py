@@ -97,3 +97,68 @@ def test_key_packing_roundtrip_cpu():
         [0xFFFFFFFF] * 3]
     i2, d2, c2 = distributed.unpack_keys(keys)
     assert (i2 == ids).all() and (d2 == dists).all() and c2.tolist() == [2, 3, 0]
+
+
+class _OracleIndex:
+    """Stand-in for guidemaker_amd._lib.Index on a rank without a GPU: .knn through the oracle."""
+
+    def __init__(self, db, L):
+        self.db, self.L = db, L
+
+    def knn(self, q_shard, kk):
+        from oracle import oracle as orc
+        ids, dists, counts = orc.knn(self.db, _lib.unpack(q_shard, self.L), self.L, "hamming", kk)
+        return ids, np.where(dists >= 0, dists // 2, -1), counts
+
+
+def _worker_index(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        L, k = 20, 5
+        db = list(dict.fromkeys(random_pool(500, L, seed=8)))
+        q = _lib.pack(db[:301], L)
+        index = _OracleIndex(db, L)
+        # the entry point TargetProcessor.get_neighbors uses when shard_candidates is set: same frame on all ranks
+        got = distributed.sharded_knn_index(index, q, k)
+        want = index.knn(q, k)
+        for g, w in zip(got, want):
+            assert (g == w).all()
+        # strong scaling as bench.py --scaling strong shards it: every rank scans ceil(n / world) rows (the last
+        # shard padded with copies of its last row), the gathered table trimmed to n equals the unsharded result
+        shard = -(-q.shape[0] // world)
+        mine = q[rank * shard:(rank + 1) * shard]
+        if mine.shape[0] < shard:
+            mine = np.concatenate([mine, np.tile(mine[-1:], shard - mine.shape[0])])
+        i, d, c = index.knn(mine, k)
+        gi, gd, gc = distributed.all_gather_neighbors(torch.from_numpy(i), torch.from_numpy(d.astype(np.int32)),
+                                                      torch.from_numpy(c), q.shape[0])
+        assert (gi.numpy() == want[0]).all() and (gd.numpy() == want[1]).all() and (gc.numpy() == want[2]).all()
+        # ranks that hold DIFFERENT candidate sets must fail loudly on every rank instead of entering the gather
+        other = q if rank == 0 else q[:-3]
+        with pytest.raises(RuntimeError, match="different candidate sets"):
+            distributed.sharded_knn_index(index, other, k)
+        np.save(os.path.join(out_dir, "ok_%d.npy" % rank), np.array([1]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_knn_index_and_strong_scaling_world2(tmp_path):
+    from oracle import oracle as orc
+    orc.build()
+    world = 2
+    mp.spawn(_worker_index, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / ("ok_%d.npy" % r)) for r in range(world))
+
+
+def test_target_processor_does_not_shard_unless_asked(monkeypatch):
+    """an initialised process group alone must not switch get_neighbors to the sharded path."""
+    import pandas as pd
+    from helpers import targets_frame
+    from guidemaker_amd import core
+    tp = core.TargetProcessor(targets_frame(["ACGTACGTACGTACGTACGT"]), lsr=0)
+    assert tp.shard_candidates is False
+    monkeypatch.setenv("GM_SHARD_CANDIDATES", "1")
+    assert core.TargetProcessor(targets_frame(["ACGTACGTACGTACGTACGT"]), lsr=0).shard_candidates is True
+    assert core.TargetProcessor(targets_frame(["ACGTACGTACGTACGTACGT"]), lsr=0, shard_candidates=False).shard_candidates is False

@@ -601,3 +601,88 @@ def test_filters_full_size_properties():
             ok &= ((packed >> np.uint64(2 * (o + j))) & np.uint64(3)) == c
         want |= ok
     assert (_lib.site_flags(packed, L, ["GAATTC"]) == want).all() and want.any()
+
+
+# ------------------------------------------------------------------ output-table columns
+@pytest.mark.parametrize("dtype", ["hamming", "leven"])
+def test_output_columns_byte_identical(oracle, cfd_table, dtype):
+    """'Similar guides' / 'Similar guide distances' (reference core.py:913-931) and the CFD columns built on them
+    (core.py:1129-1148) on Carsonella: the vectorised host path over the GPU result against the oracle's restatement
+    of the reference's per-row closures -- byte-identical strings."""
+    cols = load_carsonella("NGG5p")
+    df = core.PamTarget("NGG", "5prime", dtype).find_targets(carsonella(), 20)
+    tl = core.TargetProcessor(targets=df, lsr=10, editdist=2, knum=10)
+    tl.check_restriction_enzymes(["NRAGCA"])
+    tl.find_unique_near_pam()
+    tl.create_index(configpath=CONFIG)
+    tl.get_neighbors(configpath=CONFIG)
+    otp = oracle.OracleTargetProcessor(cols["target"], dtype, 2, 10, cols["isseedduplicated"],
+                                       cols["hasrestrictionsite"])
+    otp.create_index()
+    otp.get_neighbors()
+    guides = list(otp.neighbors.keys())
+    want_s, want_d = oracle.format_neighbor_columns(otp.neighbors, guides)
+    got_s, got_d = core.format_neighbor_columns(tl, guides)
+    assert got_s == want_s and got_d == want_d
+    tab = core.neighbor_table(tl)
+    assert set(tab["Guide sequence"]) == set(guides)
+    if dtype == "hamming":
+        out = core.cfd_score(tab)
+        want_lists, want_max = oracle.cfd_score_rows(tab["Guide sequence"].tolist(), tab["Similar guides"].tolist(),
+                                                     cfd_table)
+        assert out["CFD Similar Guides"].tolist() == want_lists          # lists of str(float)
+        assert out["Max CFD"].tolist() == want_max
+
+
+# ------------------------------------------------------------------ controls at genome scale (a6)
+def test_get_control_seqs_at_genome_scale(tmp_path):
+    """reference core.py:586-620 on an E. coli sized pool (workload S1).  The search is exact, so the shipped
+    CONTROL.MINIMUM_HMDIST = 7 cannot be met (a random 20-mer has ~18 targets within 6 mismatches): the mirrored loop
+    walks off CONTROL_SEARCH_MULTIPLE after the 10 000 x draw and raises IndexError, as the reference's does, with
+    the config key named.  With a reachable minimum the call returns the (n, 3) table; the nearest distances behind
+    it are the same from the pigeonhole-partitioned scan and from the plain scan."""
+    import yaml
+    from guidemaker_amd import workloads
+    pool = workloads.make_pool("s1")
+    L = pool["guidelen"]
+    tl = core.TargetProcessor(targets=targets_frame(_lib.unpack(pool["packed_db"][:5], L)), lsr=10, editdist=2, knum=10)
+    tl._db_targets = np.asarray(["N"] * pool["packed_db"].shape[0], dtype=object)      # (only its length is used)
+    tl._guidelen = L
+    tl.nmslib_index = _lib.Index(pool["packed_db"], L, _lib.METRIC_HAMMING)
+    genome = [Rec("ACGT" * 5000 + "GC" * 160, "g")]                                    # GC content 0.508
+    np.random.seed(7)
+    with pytest.raises(IndexError, match="MINIMUM_HMDIST"):
+        tl.get_control_seqs(genome, configpath=CONFIG, length=L, n=10)
+    with open(CONFIG) as fh:
+        cfg = yaml.safe_load(fh)
+    cfg["CONTROL"]["MINIMUM_HMDIST"] = 5
+    cfg_path = tmp_path / "cfg.yaml"
+    cfg_path.write_text(yaml.safe_dump(cfg))
+    np.random.seed(7)
+    mn, med, table = tl.get_control_seqs(genome, configpath=str(cfg_path), length=L, n=100)
+    assert table.shape == (100, 3) and mn >= 5 and list(table.columns) == ["name", "Sequences", "Hamming distance"]
+    assert tl.ncontrolsearched in (1000, 10000, 100000, 1000000)
+    tl.nmslib_index.set_variant(8)
+    np.random.seed(7)
+    mn8, med8, table8 = tl.get_control_seqs(genome, configpath=str(cfg_path), length=L, n=100)
+    assert (mn8, med8) == (mn, med) and table8.equals(table)
+    # nearest-distance histogram of 200 000 random controls: pigeonhole-partitioned scan == plain scan
+    probe = core.pack_codes(np.random.default_rng(3).integers(0, 4, size=(200_000, L), dtype=np.uint8))
+    d_plain = tl.nmslib_index.nearest(probe)
+    tl.nmslib_index.set_variant(0)
+    d_pg = tl.nmslib_index.nearest(probe)
+    assert tl.nmslib_index.last_kernel()[0] == "k_hamming_scan_pg"
+    assert (np.bincount(d_pg, minlength=21) == np.bincount(d_plain, minlength=21)).all() and (d_pg == d_plain).all()
+    with pytest.raises(ValueError):
+        tl.get_control_seqs(genome, configpath=str(cfg_path), length=L + 1, n=10)
+    tl.nmslib_index.close()
+
+
+# ------------------------------------------------------------------ randomised differential test (time-boxed)
+def test_fuzz_against_oracle_time_boxed(oracle):
+    """random guide length 10..27, metric, k, ragged pool / candidate sizes, duplicate
+    rate, base skew and (Hamming) a random forced pigeonhole layout, each case compared with the oracle."""
+    import fuzz_parity
+    n_cases, bad = fuzz_parity.run(seconds=25.0, seed=2)
+    assert bad is None, bad
+    assert n_cases >= 20

@@ -183,3 +183,66 @@ def test_pigeonhole_planner_choices():
     def radius(code):
         return code % 100 + code % 1000 // 100 - 1
     assert radius(_lib.pigeon_plan(20_000_000, 20, 10)) <= radius(_lib.pigeon_plan(600_000, 20, 10))
+
+
+def test_format_neighbor_columns_matches_reference_closures(oracle):
+    """the vectorised 'Similar guides' / 'Similar guide distances' columns are byte-identical to
+    the reference's per-row closures (core.py:913-931, restated in the oracle), including rows with fewer than k
+    hits, two-digit distances and duplicate candidate strings (the last occurrence's row wins, as with the dict)."""
+    from helpers import random_pool
+    L = 20
+    db = list(dict.fromkeys(random_pool(300, L, seed=3)))
+    q = db[:150] + db[:7]
+    for k, pool in ((2, db), (10, db), (20, db), (10, db[:6])):      # the last: k larger than the index
+        ids, d, c = oracle.knn(pool, q, L, "hamming", k)
+        d = np.where(d >= 0, d // 2, -1)
+        keep = np.flatnonzero(d[:, 1] >= 2)
+        nm = core.NeighborMap(q, keep, ids, d, c, np.asarray(pool, dtype=object))
+
+        class TL:
+            neighbors = nm
+        keys = list(nm.keys())
+        got = core.format_neighbor_columns(TL, keys + keys[:3])
+        want = oracle.format_neighbor_columns({kk: nm[kk] for kk in keys}, keys + keys[:3])
+        assert got[0] == want[0] and got[1] == want[1]
+        tab = core.neighbor_table(TL)
+        assert tab["Guide sequence"].tolist() == keys and tab["Similar guides"].tolist() == want[0][:len(keys)]
+    with pytest.raises(KeyError):
+        core.format_neighbor_columns(TL, ["A" * L])
+    # a plain dict goes through the reference's own loops
+    class TD:
+        neighbors = {"ACGT": {"target": "ACGT", "neighbors": {"seqs": ["ACGT", "ACGA"], "dist": [0, 1]}}}
+    assert core.format_neighbor_columns(TD, ["ACGT"]) == (["ACGT;ACGA"], ["0;1"])
+
+
+def test_pack_rejects_mixed_lengths_that_sum_right():
+    # ADVICE r1: lengths 19 + 21 sum to 2 * 20 and first / last rows alone would not always catch it
+    with pytest.raises(ValueError):
+        _lib.pack(["A" * 20, "C" * 19, "G" * 21, "T" * 20], 20)
+    assert _lib.pack(["ACGT" * 5, "TTTT" * 5], 20).shape == (2,)
+
+
+def test_packed_side_car_travels_with_the_frame():
+    """find_targets attaches the 2-bit packed 'target' column (frame.attrs['gm_packed']); TargetProcessor uses it
+    instead of re-encoding the strings, checks it against the strings, and falls back when it does not fit."""
+    recs = carsonella()
+    df = core.PamTarget("NGG", "5prime", "hamming").find_targets(recs, 20)
+    side = df.attrs["gm_packed"]
+    assert df.attrs["gm_guidelen"] == 20 and side.dtype == np.uint64 and len(side) == len(df)
+    assert (side == _lib.pack(df["target"].tolist(), 20)).all()
+    tp = core.TargetProcessor(df, lsr=10)
+    pk = tp._packed_targets()
+    assert pk[1] == 20 and (pk[0] == side).all()
+    assert tp._packed_targets() is pk                                  # cached
+    tp.find_unique_near_pam()                                          # deep-copies the frame: cache carried over
+    assert tp._packed_targets()[0] is pk[0]
+    # a frame whose rows were filtered loses the alignment: the side-car is ignored, the strings are packed
+    sub = df[df["strand"]].reset_index(drop=True)
+    sub.attrs["gm_packed"] = side                                      # stale on purpose
+    tp2 = core.TargetProcessor(sub, lsr=10)
+    assert (tp2._packed_targets()[0] == _lib.pack(sub["target"].tolist(), 20)).all()
+    # same length but different content: caught by the probe rows
+    wrong = df.copy()
+    wrong.attrs["gm_packed"] = side[::-1].copy()
+    tp3 = core.TargetProcessor(wrong, lsr=10)
+    assert (tp3._packed_targets()[0] == side).all()

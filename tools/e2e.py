@@ -53,11 +53,10 @@ def main():
     print("targets %d, unique %d, queries %d, retained %d" % (len(df), len(tp._db_targets), len(tp.last_knn[2]),
                                                            len(tp.neighbors)))
     print("scan kernel %s: %.2f ms for %.3e pairs" % (name, ms, pairs))
+    t0 = time.perf_counter()
+    frame = core.neighbor_table(tp)      # 'Similar guides' / 'Similar guide distances' (reference core.py:913-931)
+    t["output columns(%d rows)" % len(frame)] = time.perf_counter() - t0
     if a.cfd:
-        import pandas as pd
-        keys = list(tp.neighbors.keys())
-        frame = pd.DataFrame({"Guide sequence": keys,
-                              "Similar guides": [";".join(tp.neighbors[k]["neighbors"]["seqs"]) for k in keys]})
         t0 = time.perf_counter()
         core.cfd_score(frame)
         t["cfd_score(%d rows)" % len(frame)] = time.perf_counter() - t0

@@ -24,6 +24,9 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--nearest", action="store_true")
     ap.add_argument("--check", action="store_true", help="compare every variant's output with variant 0")
+    ap.add_argument("--params", default="", help="gm_set_param sweeps, e.g. pg_sub=2:4:8,pg_run=16:256 (all "
+                    "combinations, each with variant 0)")
+    ap.add_argument("--workload", default="", help="use guidemaker_amd.workloads.make_pool(NAME) instead of a random pool")
     ap.add_argument("--planted", type=float, default=0.0,
                     help="fraction of pool entries replaced by near-duplicates (1-3 substitutions) of others")
     a = ap.parse_args()
@@ -39,15 +42,32 @@ def main():
     db = np.unique(core.pack_codes(codes))
     rng.shuffle(db)
     q = db if a.nq == 0 else db[:a.nq]
+    if a.workload:
+        from guidemaker_amd import workloads
+        pool = workloads.make_pool(a.workload)
+        db, q, a.L, a.k, a.metric = pool["packed_db"], pool["packed_all"], pool["guidelen"], pool["k"], pool["metric"]
     idx = _lib.Index(db, a.L, _lib.METRIC_HAMMING if a.metric == "hamming" else _lib.METRIC_LEVEN)
     variants = [int(v) for v in a.variants.split(",")]
+    if a.params:      # parameter sweep: label = index into the list of combinations
+        import itertools
+        keys, vals = [], []
+        for item in a.params.split(","):
+            kname, vs = item.split("=")
+            keys.append(kname)
+            vals.append([int(x) for x in vs.split(":")])
+        combos = list(itertools.product(*vals))
+        variants = list(range(len(combos)))
     times = {v: [] for v in variants}
     ktimes = {v: [] for v in variants}
     names = {}
     ref = None
     for r in range(a.rounds + 1):
         for v in variants:
-            idx.set_variant(v)
+            if a.params:
+                for kname, val in zip(keys, combos[v]):
+                    idx.set_param(kname, val)
+            else:
+                idx.set_variant(v)
             if a.nearest:
                 out = (idx.nearest(q),)
             else:
@@ -64,6 +84,8 @@ def main():
                 else:
                     assert all((x == y).all() for x, y in zip(ref, out)), "variant %d differs" % v
     for v in variants:
+        if a.params:
+            names[v] += " " + " ".join("%s=%d" % kv for kv in zip(keys, combos[v]))
         t = np.array(times[v])
         print("variant %3d %-40s n_db=%d n_q=%d k=%d: query median %.3f ms min %.3f ms (dominant kernel %.3f ms)"
               "  -> %.3e pairs/s"

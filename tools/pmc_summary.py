@@ -2,7 +2,7 @@
 """Condense rocprofv3 output (tools/profile.sh) into the per-kernel tables committed under profiles/.
 
   python tools/pmc_summary.py gpurun_out/TAG --out profiles/r02/TAG_pmc.json [--stats-out profiles/r02/TAG_kernel_stats.csv]
-                              [--traffic-key s1 --traffic-json profiles/hbm_traffic.json --kernel k_hamming_scan_pg]
+                              [--register s1 --kernel k_hamming_scan_pg [--counters-json profiles/counters.json]]
 
 Reads every *_counter_collection.csv below the directory (one row per dispatch x counter), groups the
 dispatches by kernel (template arguments kept, argument lists dropped) and writes, per kernel and counter, the
@@ -78,9 +78,11 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--stats-out")
     ap.add_argument("--min-ns", type=float, default=0.0, help="drop kernels whose mean dispatch is shorter")
-    ap.add_argument("--traffic-json")
-    ap.add_argument("--traffic-key")
-    ap.add_argument("--kernel", help="substring of the dominant kernel's short name (for --traffic-json)")
+    ap.add_argument("--counters-json", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                            "profiles", "counters.json"))
+    ap.add_argument("--register", help="workload key: record the dominant kernel's counters in --counters-json, where "
+                                       "bench.py looks them up for its roofline block")
+    ap.add_argument("--kernel", help="substring of the dominant kernel's short name (for --register)")
     a = ap.parse_args()
     table = collect(a.root)
     table = {k: v for k, v in table.items() if v["mean_ns_in_pmc_passes"] >= a.min_ns}
@@ -93,22 +95,25 @@ def main():
         if cand:
             shutil.copyfile(cand[0], a.stats_out)
             print("wrote", a.stats_out)
-    if a.traffic_json and a.traffic_key and a.kernel:
-        hits = [k for k in table if a.kernel in k and "hbm_side_bytes_per_launch" in table[k]]
+    if a.register and a.kernel:
+        hits = [k for k in table if a.kernel in k]
         if hits:
             k = max(hits, key=lambda x: table[x]["mean_ns_in_pmc_passes"])
             data = {}
-            if os.path.exists(a.traffic_json):
-                with open(a.traffic_json) as fh:
+            if os.path.exists(a.counters_json):
+                with open(a.counters_json) as fh:
                     data = json.load(fh)
-            data[a.traffic_key] = {"kernel": k, "bytes_per_launch": table[k]["hbm_side_bytes_per_launch"],
-                                   "fetch_size_kib_raw": table[k]["counters"].get("FETCH_SIZE", {}).get("mean_per_launch"),
-                                   "write_size_kib_raw": table[k]["counters"].get("WRITE_SIZE", {}).get("mean_per_launch"),
-                                   "counters": {c: v["mean_per_launch"] for c, v in table[k]["counters"].items()},
-                                   "source": a.out}
-            with open(a.traffic_json, "w") as fh:
-                json.dump(data, fh, indent=1)
-            print("updated", a.traffic_json, a.traffic_key, k)
+            data["_comment"] = ("per workload: PMC counters of bench.py's dominant kernel, mean per launch, from rocprofv3 "
+                                "passes (tools/profile.sh + tools/pmc_summary.py --register).  FETCH_SIZE / WRITE_SIZE in "
+                                "KiB; hbm_side_bytes_per_launch = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction, "
+                                "MI355X_MICROARCH.md HBM section; includes Infinity-Cache hits).")
+            data[a.register] = {"kernel": k, "source": a.out, "resources": table[k]["resources"],
+                                "mean_ns_in_pmc_passes": table[k]["mean_ns_in_pmc_passes"],
+                                "hbm_side_bytes_per_launch": table[k].get("hbm_side_bytes_per_launch"),
+                                "counters": {c: v["mean_per_launch"] for c, v in table[k]["counters"].items()}}
+            with open(a.counters_json, "w") as fh:
+                json.dump(data, fh, indent=1, sort_keys=True)
+            print("registered", a.register, k, "in", a.counters_json)
 
 
 if __name__ == "__main__":
