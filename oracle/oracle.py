@@ -33,8 +33,8 @@ _LIB = None
 
 
 def build():
-    """Compile liboracle.so (gcc, OpenMP)."""
-    subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+    """Compile liboracle.so (gcc, OpenMP) and the HNSW baseline (g++, OpenMP)."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so", "libhnsw_baseline.so"])
 
 
 def lib():
@@ -316,3 +316,72 @@ def seed_duplicated(targets, lsr, five_prime):
         flags.append(seed in seen)
         seen.add(seed)
     return seeds, flags
+
+
+# ------------------------------------------------------------------------------------------------
+# Reference-ALGORITHM CPU baseline: HNSW with the shipped parameters (hnsw_baseline.cpp; not the parity oracle)
+# ------------------------------------------------------------------------------------------------
+_HNSW = None
+
+
+def _hnsw_lib():
+    global _HNSW
+    if _HNSW is None:
+        path = os.path.join(_HERE, "libhnsw_baseline.so")
+        if not os.path.exists(path):
+            build()
+        H = ctypes.CDLL(path)
+        H.hb_build.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                               ctypes.c_int, ctypes.c_int, ctypes.c_uint64]
+        H.hb_build.restype = ctypes.c_void_p
+        H.hb_query.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                               ctypes.c_void_p, ctypes.c_void_p]
+        H.hb_query.restype = ctypes.c_int
+        H.hb_free.argtypes = [ctypes.c_void_p]
+        H.hb_free.restype = None
+        H.hb_max_threads.restype = ctypes.c_int
+        _HNSW = H
+    return _HNSW
+
+
+class HnswBaseline:
+    """HNSW index over 2-bit packed targets with the reference's nmslib parameters (config_default.yaml:3-6):
+    M 16, efConstruction 10, post 1; query beam max(ef 9, k).  packed: uint64, base p in bits [2p, 2p+1]."""
+
+    def __init__(self, packed, L, metric="hamming", M=16, efc=10, post=1, threads=0, seed=1):
+        self.packed = np.ascontiguousarray(packed, dtype=np.uint64)
+        self._h = _hnsw_lib().hb_build(self.packed.ctypes.data, self.packed.shape[0], L,
+                                       0 if metric == "hamming" else 1, M, efc, post, threads, seed)
+        if not self._h:
+            raise ValueError("hnsw baseline: bad arguments")
+
+    def query(self, q_packed, k, ef=9, threads=0):
+        """-> (ids [nq,k] int32, dists [nq,k] int32 in TRUE units), -1 padded, rows ordered by (distance, id)."""
+        q = np.ascontiguousarray(q_packed, dtype=np.uint64)
+        ids = np.empty((q.shape[0], k), np.int32)
+        dists = np.empty((q.shape[0], k), np.int32)
+        rc = _hnsw_lib().hb_query(self._h, q.ctypes.data, q.shape[0], k, ef, threads, ids.ctypes.data, dists.ctypes.data)
+        if rc != 0:
+            raise ValueError("hnsw baseline: bad query")
+        return ids, dists
+
+    def close(self):
+        if self._h:
+            _hnsw_lib().hb_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def top2_distance_recall(result_dists, truth_dists):
+    """The reference's own quality measure (tests/GridOptimization.ipynb:175-190, `recall`): the fraction of queries
+    whose first two k-NN DISTANCES equal the exact search's first two ("we really care that the algorithm estimates
+    the correct distance not the exact value of the neighbor")."""
+    r = np.asarray(result_dists)[:, 0:2]
+    t = np.asarray(truth_dists)[:, 0:2]
+    assert r.shape == t.shape
+    return float((r == t).all(axis=1).mean()) if r.shape[0] else 1.0

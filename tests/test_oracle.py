@@ -130,3 +130,40 @@ def test_filter_restatements_match_reference_flags(oracle, tag, five_prime):
     assert oracle.restriction_flags(cols["target"], ["NRAGCA"]) == cols["hasrestrictionsite"]
     assert oracle.seed_duplicated(cols["target"], 10, five_prime)[1] == cols["isseedduplicated"]
     assert any(cols["hasrestrictionsite"]) and not all(cols["hasrestrictionsite"])
+
+
+def test_hnsw_baseline_properties(oracle):
+    """The reference-ALGORITHM baseline (oracle/hnsw_baseline.cpp: HNSW with the shipped M 16 / efConstruction 10 /
+    post 1 / ef 9) is approximate by nature; what must hold: reported distances are the true distances of the
+    reported ids, rows are sorted, a wide beam converges to the exact answer, and the notebook's recall measure
+    (tests/GridOptimization.ipynb:175-190) is computed as defined there."""
+    from guidemaker_amd import core
+    L, k = 20, 3
+    rng = np.random.default_rng(4)
+    packed = np.unique(core.pack_codes(rng.integers(0, 4, size=(6000, L), dtype=np.uint8)))
+    shifts = (2 * np.arange(L, dtype=np.uint64))[None, :]
+    asc = np.frombuffer(b"ACGT", np.uint8)
+    chars = np.ascontiguousarray(asc[((packed[:, None] >> shifts) & np.uint64(3)).astype(np.uint8)])
+    h = oracle.HnswBaseline(packed, L, "hamming", M=16, efc=10, post=1, threads=2, seed=1)
+    q = packed[:800]
+    ids, d = h.query(q, k, ef=9, threads=2)
+    oi, od, oc = oracle.knn(chars, chars[:800], L, "hamming", k)
+    od = od // 2
+    assert ids.shape == (800, k) and (ids >= 0).all()
+    true_d = (chars[:800, None, :] != chars[ids]).sum(axis=2)
+    assert (true_d == d).all()                                  # distances belong to the ids
+    assert (np.diff(d, axis=1) >= 0).all()                      # sorted
+    assert (d >= od).all()                                      # never better than the exact search, column by column
+    r9 = oracle.top2_distance_recall(d, od)
+    ids2, d2 = h.query(q, k, ef=400, threads=2)
+    r400 = oracle.top2_distance_recall(d2, od)
+    assert 0.3 < r9 <= r400 and r400 > 0.97
+    assert oracle.top2_distance_recall(od, od) == 1.0
+    assert oracle.top2_distance_recall(np.array([[0, 1, 5], [0, 2, 5]]), np.array([[0, 1, 9], [0, 3, 5]])) == 0.5
+    h.close()
+    # Levenshtein space
+    hl = oracle.HnswBaseline(packed[:1500], L, "leven", threads=2)
+    il, dl = hl.query(packed[:50], 2, ef=200, threads=2)
+    ol, odl, _ = oracle.knn(chars[:1500], chars[:50], L, "leven", 2)
+    assert (dl[:, 0] == 0).all() and (dl >= odl).all() and oracle.top2_distance_recall(dl, odl) > 0.9
+    hl.close()
