@@ -73,14 +73,14 @@ def _tree_ops(L):
 
 
 def bitsliced_leven_ops_per_pair(L):
-    """VALU lane-ops per guide pair of K2B (gm_leven_bs.hip.h) on its BANDED path (every lane's bound within
-    the band, the common case once the bounds are seeded): per 32-target word 5 ops per DP cell of the band
-    |i - j| <= (3L + 4) // 8, one count tree over the diagonal, the 5-op threshold compare and one address
-    bump per row per group.  Groups that take the full-matrix path execute more (5 L^2 + two trees), so the
-    fraction derived from this figure is a lower bound."""
-    band = (3 * L + 4) // 8
-    cells = L * L - (L - band - 1) * (L - band)
-    per_word = 5.0 * cells + _tree_ops(L) + 5 + L / 2.0
+    """USEFUL VALU lane-ops per guide pair of K2B (gm_leven_bs.hip.h) on its banded path (every lane's bound within
+    2 BAND + 2, the common case once the bounds are seeded): per 32-target word 5 ops per DP cell of the band
+    |i - j| <= BAND = ((3L + 4) // 8) // 2, one count tree over the diagonal and the 5-op threshold compare.  Groups
+    that take the full-matrix path execute more, groups on the narrower band fewer; the counter-derived figure
+    (roofline.achieved) is the one that is measured."""
+    band = ((3 * L + 4) // 8) // 2
+    cells = L * (2 * band + 1) - band * (band + 1)
+    per_word = 5.0 * cells + _tree_ops(L) + 5
     return per_word / 32.0
 
 

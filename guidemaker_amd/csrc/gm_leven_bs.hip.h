@@ -18,6 +18,9 @@
 //   the K1L threshold comparator / hit walk / register k-lists (s plays the role of "matches").
 // Same tiles (LDS-DMA, double buffered), Hamming-seeded bounds, chunks x segments grid and merge as K2L.
 #pragma once
+#ifndef GM_LVB_WAVES
+#define GM_LVB_WAVES 3     /* waves per SIMD asked of the allocator for k_leven_knn_bs (the full-matrix path needs ~150 VGPRs) */
+#endif
 #include "gm_leven.hip.h"
 
 #include <utility>
@@ -110,23 +113,29 @@ __device__ __forceinline__ void lvb_eval_half(uint32_t (&adr)[L], uint32_t (&c)[
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Banded evaluation.  A pair can only be a hit if its distance is below the lane's bound, and an alignment of
-// cost <= BAND never leaves the diagonal band |i - j| <= BAND, so while every lane of the wave has a bound
-// <= BAND + 1 only the band's cells are evaluated.  Outside cells are replaced by upper bounds that cost
-// nothing: a column starts at the top of its band with the horizontal delta +1 (exact in row 0, an upper
-// bound below it), and a row enters the band from below with the vertical delta it was initialised with
-// (+1).  All values computed this way are >= the true ones and exact along every path inside the band, so
-// the result is the true distance when that is <= BAND and something larger (never a false hit) otherwise.
+// Banded evaluation.  A pair can only be a hit if its distance is below the lane's bound thr, i.e. <= t = thr - 1.
+// Candidate and target have the SAME length, so an alignment uses as many insertions as deletions: a path that
+// reaches diagonal |i - j| = g has spent g indels getting there and needs g more to come back to (L, L), so a path of
+// cost <= t never leaves the band |i - j| <= floor(t / 2) (Ukkonen's cut-off for equal lengths -- half of the
+// obvious band t).  While every lane of the wave has thr <= 2 BAND + 2 only the band's cells are evaluated.  Outside
+// cells are replaced by upper bounds that cost nothing: a column starts at the top of its band with the horizontal
+// delta +1 (exact in row 0, an upper bound below it), and a row enters the band from below with the vertical delta
+// it was initialised with (+1).  All values computed this way are >= the true ones and exact along every path
+// inside the band, so the result is the true distance when that is <= 2 BAND + 1 and something >= the true distance
+// (never a false hit) otherwise.
 // The last column is no longer complete, so the distance is read off the DIAGONAL instead: it grows by
 // 0 or 1 per step and D0(i, i) says which, i.e. s = L - distance = popcount over i of D0(i, i): one
 // carry-save tree.  Columns are fully unrolled (row ranges and read offsets are compile-time); the delta
 // registers of rows above the band die and those below it are still constants, so the banded code also needs
-// fewer VGPRs.  L = 23, BAND = 9: 347 of 529 cells.  (While a lane's bound is above BAND + 1 -- unseeded
-// candidates, k-th neighbours far away -- the wave takes the full evaluation above.)
+// fewer VGPRs.  L = 23, BAND = 4: 187 of 529 cells (the round-1 band |i - j| <= 9 had 347).  Two band widths are
+// instantiated: BAND for the seeded bounds and BAND - 1 for waves whose lists have tightened further.  (While a
+// lane's bound is above 2 BAND + 2 -- unseeded candidates, k-th neighbours far away -- the wave takes the full
+// evaluation above.)
 // ---------------------------------------------------------------------------------------------------
-// band width per guide length: about 3/8 of it -- the k-th Hamming distance that seeds the bounds sits near
-// L / 3 for pools of 10^5 .. 10^6 random targets (L = 20: 8, 23: 9, 27: 10)
-__host__ __device__ constexpr int lvb_band(int L) { return (3 * L + 4) / 8; }
+// band half-width per guide length: the k-th Hamming distance that seeds the bounds sits near L / 3 for pools of
+// 10^5 .. 10^6 random targets (thr around 9 / 10 / 11 for L = 20 / 23 / 27); 2 BAND + 2 covers it: BAND = 4, 4, 5
+__host__ __device__ constexpr int lvb_band(int L) { return ((3 * L + 4) / 8) / 2; }
+__host__ __device__ constexpr int lvb_band_cells(int L, int band) { return L * (2 * band + 1) - band * (band + 1); }
 
 template <int L, int HB, int BAND, int J>
 __device__ __forceinline__ void lvb_column_banded(const uint32_t (&adr)[L], uint32_t (&Pv)[L], uint32_t (&Mv)[L],
@@ -181,7 +190,7 @@ __device__ __forceinline__ void lvb_eval_half_banded(const uint32_t (&adr)[L], u
 // Dynamic LDS: 2 tiles.  seed_*: Hamming k-NN of the same candidates (lev <= hamming).
 // keys: [n_seg][n_q][KCAP] raw RegList contents, folded by k_merge_lists.
 template <int L, int KCAP>
-__global__ __launch_bounds__(WAVE, 3) void k_leven_knn_bs(const uint32_t* __restrict__ table, int n_db, int n_tiles,
+__global__ __launch_bounds__(WAVE, GM_LVB_WAVES) void k_leven_knn_bs(const uint32_t* __restrict__ table, int n_db, int n_tiles,
                                                        int tiles_per_seg, const uint2* __restrict__ q,
                                                        int64_t n_q, int k, const int32_t* __restrict__ seed_dists,
                                                        const int32_t* __restrict__ seed_counts, int seed_k,
@@ -226,15 +235,19 @@ __global__ __launch_bounds__(WAVE, 3) void k_leven_knn_bs(const uint32_t* __rest
         }
         for (int gl = 0; gl < LK_TG; ++gl) {
             uint32_t c0[5], c1[5];
-            constexpr int BAND = lvb_band(L);
-            const bool banded = __builtin_amdgcn_ballot_w64(thr > BAND + 1) == 0ull;
-            if (banded) {
-                {
-                    lvb_eval_half_banded<L, 0, BAND>(adr, c0);
-                    lvb_eval_half_banded<L, 4, BAND>(adr, c1);
+            constexpr int BAND = lvb_band(L), NARROW = BAND - 1;
+            const bool banded = __builtin_amdgcn_ballot_w64(thr > 2 * BAND + 2) == 0ull;
+            const bool narrow = NARROW >= 2 && __builtin_amdgcn_ballot_w64(thr > 2 * NARROW + 2) == 0ull;
+            if (narrow) {
+                lvb_eval_half_banded<L, 0, (NARROW >= 2 ? NARROW : 2)>(adr, c0);
+                lvb_eval_half_banded<L, 4, (NARROW >= 2 ? NARROW : 2)>(adr, c1);
 #pragma unroll
-                    for (int i = 0; i < L; ++i) asm volatile("v_add_u32 %0, %1, %0" : "+v"(adr[i]) : "n"(GW * 4));
-                }
+                for (int i = 0; i < L; ++i) asm volatile("v_add_u32 %0, %1, %0" : "+v"(adr[i]) : "n"(GW * 4));
+            } else if (banded) {
+                lvb_eval_half_banded<L, 0, BAND>(adr, c0);
+                lvb_eval_half_banded<L, 4, BAND>(adr, c1);
+#pragma unroll
+                for (int i = 0; i < L; ++i) asm volatile("v_add_u32 %0, %1, %0" : "+v"(adr[i]) : "n"(GW * 4));
             } else {
                 lvb_eval_half<L, 0>(adr, c0);                              // adr: -> next group
 #pragma unroll
