@@ -402,7 +402,7 @@ def main():
             "value": value, "unit": "guide-pair comparisons/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "u32", "data": "synthetic",
+            "dtype": "u32", "data": "real genome" if pool.get("real_genome") else "synthetic",
             "value_note": "value = candidate x target pairs RESOLVED per second (every pair's membership in the exact "
                           "k-NN answer is decided; BASELINE.md section 4's definition N_q x N_db / seconds); "
                           "value_evaluated = distance evaluations actually EXECUTED per second (the pigeonhole "

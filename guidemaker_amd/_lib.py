@@ -79,6 +79,18 @@ def lib():
     L.gm_set_variant.argtypes = [vp, i32]
     L.gm_set_param.argtypes = [vp, c.c_char_p, i32]
     L.gm_set_param.restype = i32
+    L.gm_multi_create.argtypes = [vp, i64, i32, i32, c.POINTER(i32), i32, c.POINTER(vp)]
+    L.gm_multi_create.restype = i32
+    L.gm_multi_knn_query.argtypes = [vp, vp, i64, i32, vp, vp, vp]
+    L.gm_multi_knn_query.restype = i32
+    L.gm_multi_devices.argtypes = [vp]
+    L.gm_multi_devices.restype = i32
+    L.gm_multi_has_comm.argtypes = [vp]
+    L.gm_multi_has_comm.restype = i32
+    L.gm_multi_index.argtypes = [vp, i32]
+    L.gm_multi_index.restype = vp
+    L.gm_multi_free.argtypes = [vp]
+    L.gm_multi_free.restype = None
     L.gm_timing_reserve.argtypes = [vp, i32]
     L.gm_timing_reserve.restype = i32
     L.gm_timing_read.argtypes = [vp, vp, i32]
@@ -115,6 +127,7 @@ EXPORTS = [
     "gm_set_variant", "gm_timing_reserve", "gm_timing_read", "gm_pam_count", "gm_pam_emit", "gm_pam_free",
     "gm_pack_keys_dev", "gm_unpack_keys_dev", "gm_site_flags", "gm_seed_duplicated",
     "gm_last_kernel_evaluated", "gm_last_incomplete", "gm_pigeon_blocks", "gm_pigeon_plan", "gm_set_param",
+    "gm_multi_create", "gm_multi_knn_query", "gm_multi_devices", "gm_multi_has_comm", "gm_multi_index", "gm_multi_free",
 ]
 
 
@@ -268,6 +281,45 @@ class Index:
     def pigeon_blocks(self):
         """Blocks of the pigeonhole layout built for this index (0: the plain scan is in use)."""
         return int(lib().gm_pigeon_blocks(self._h))
+
+
+class MultiIndex:
+    """The pool replicated on several GPUs of one node, candidates sharded across them, one RCCL all-gather per query
+    (gm_multi_* of include/gmhip.h): same results as Index.knn on one device."""
+
+    def __init__(self, packed, guidelen, metric, devices):
+        packed = np.ascontiguousarray(packed, dtype=np.uint64)
+        devs = (ctypes.c_int * len(devices))(*devices)
+        self._h = ctypes.c_void_p()
+        self.n = int(packed.shape[0])
+        _check(lib().gm_multi_create(_ptr(packed), self.n, guidelen, metric, devs, len(devices), ctypes.byref(self._h)))
+
+    def devices(self):
+        return int(lib().gm_multi_devices(self._h))
+
+    def has_comm(self):
+        return bool(lib().gm_multi_has_comm(self._h))
+
+    def knn(self, q_packed, k):
+        q = np.ascontiguousarray(q_packed, dtype=np.uint64)
+        nq = int(q.shape[0])
+        ids = np.full((nq, k), -1, np.int32)
+        dists = np.full((nq, k), -1, np.int32)
+        counts = np.zeros((nq,), np.int32)
+        if nq:
+            _check(lib().gm_multi_knn_query(self._h, _ptr(q), nq, k, _ptr(ids), _ptr(dists), _ptr(counts)))
+        return ids, dists, counts
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().gm_multi_free(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def cfd_batch(guides_packed, offs_packed, guidelen, mm, device=0):

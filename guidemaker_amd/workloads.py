@@ -1,5 +1,8 @@
 """Synthetic workloads of SURVEY.md section 8(d): i.i.d. genomes with a given GC content, scanned with
 the package's own PAM scanner (no real E. coli / B. subtilis / yeast genome exists offline)."""
+import gzip
+import os
+
 import numpy as np
 
 from . import core
@@ -44,17 +47,74 @@ def scan_codes(codes, pam, orientation, L):
     return core.scan_targets(seq, pam, orientation, L)["codes"]
 
 
+def read_genome(path):
+    """Records of a FASTA or GenBank file (plain or gzipped) as a list of (id, upper-case sequence) -- the input
+    step of the reference (core.py:1065-1090 `get_fastas`: Bio.SeqIO.parse + upper()), restated without Biopython:
+    FASTA = '>' header lines + sequence lines; GenBank = LOCUS / VERSION headers and the ORIGIN ... // blocks."""
+    with open(path, "rb") as fh:
+        gz = fh.read(2) == b"\x1f\x8b"
+    opener = gzip.open if gz else open
+    recs, rid, chunks, in_origin, fmt = [], None, [], False, None
+    with opener(path, "rt") as fh:
+        for line in fh:
+            if fmt is None:
+                if not line.strip():
+                    continue
+                fmt = "fasta" if line.startswith(">") else "genbank"
+            if fmt == "fasta":
+                if line.startswith(">"):
+                    if rid is not None:
+                        recs.append((rid, "".join(chunks).upper()))
+                    rid, chunks = (line[1:].split() or ["record%d" % len(recs)])[0], []
+                else:
+                    chunks.append(line.strip())
+            else:
+                if line.startswith("LOCUS"):
+                    rid, chunks, in_origin = line.split()[1], [], False
+                elif line.startswith("VERSION") and len(line.split()) > 1:
+                    rid = line.split()[1]
+                elif line.startswith("ORIGIN"):
+                    in_origin = True
+                elif line.startswith("//"):
+                    if rid is not None:
+                        recs.append((rid, "".join(chunks).upper()))
+                    rid, chunks, in_origin = None, [], False
+                elif in_origin:
+                    chunks.append("".join(line.split()[1:]))
+    if fmt == "fasta" and rid is not None:
+        recs.append((rid, "".join(chunks).upper()))
+    return recs
+
+
+def real_genome_path(name):
+    """Path of a real genome for workload `name`, if the box has one: environment variable GM_GENOME_<NAME>
+    (e.g. GM_GENOME_S1=/data/ecoli_k12_mg1655.gbk.gz).  SURVEY.md 8(d): real E. coli / B. subtilis / yeast files are
+    used iff present on the GPU box; otherwise the synthetic stand-ins are, and the bench line says which."""
+    p = os.environ.get("GM_GENOME_" + name.upper(), "")
+    return p if p and os.path.exists(p) else None
+
+
 def make_pool(name, seed_offset=0):
     """-> dict(packed_all uint64 [N_q] in frame order, packed_db uint64 [N_db] first-occurrence unique,
     guidelen, metric, k, label).  With no restriction enzymes every row is a query (core.py:495)."""
     w = WORKLOADS[name]
     rng = np.random.Generator(np.random.PCG64(w["seed"] + seed_offset))
     parts = []
-    for rec_len in w["records"]:
-        codes = synth_genome(rec_len, w["gc"], rng)
-        parts.append(core.pack_codes(scan_codes(codes, w["pam"], w["orientation"], w["guidelen"])))
+    label = w["label"]
+    real = real_genome_path(name) if seed_offset == 0 else None
+    if real:
+        total = 0
+        for _, seq in read_genome(real):
+            total += len(seq)
+            parts.append(core.pack_codes(core.scan_targets(seq, w["pam"], w["orientation"], w["guidelen"])["codes"]))
+        label = "%s: REAL genome %s (%d bp), %s %s, L=%d, %s, k=%d" % (
+            name.upper(), os.path.basename(real), total, w["pam"], w["orientation"], w["guidelen"], w["metric"], w["k"])
+    else:
+        for rec_len in w["records"]:
+            codes = synth_genome(rec_len, w["gc"], rng)
+            parts.append(core.pack_codes(scan_codes(codes, w["pam"], w["orientation"], w["guidelen"])))
     packed_all = np.concatenate(parts)
     _, first = np.unique(packed_all, return_index=True)
     packed_db = packed_all[np.sort(first)]
     return dict(packed_all=packed_all, packed_db=packed_db, guidelen=w["guidelen"], metric=w["metric"],
-                k=w["k"], editdist=w["editdist"], label=w["label"], name=name)
+                k=w["k"], editdist=w["editdist"], label=label, name=name, real_genome=real)

@@ -103,6 +103,23 @@ int gm_pack_keys_dev(const void* d_ids, const void* d_dists, int64_t n_q, int k,
 int gm_unpack_keys_dev(const void* d_keys, int64_t n_q, int k, void* d_ids, void* d_dists, void* d_counts,
                        void* stream);
 
+/* Multi-GPU, ONE process, the devices of one node (replaces nmslib's num_threads fan-out of
+ * knnQueryBatch, guidemaker/core.py:501-503, by a fan-out over GPUs).  gm_multi_create replicates the packed pool on
+ * every listed device (ordinals must be distinct) and creates one RCCL communicator over them (ncclCommInitAll;
+ * librccl.so is loaded on first use).  gm_multi_knn_query cuts the candidates into n contiguous, equally long shards,
+ * device g scans shard g (gm_knn_query_dev on its own stream, driven by its own host thread), ONE ncclAllGather
+ * exchanges the neighbour lists as 32-bit keys, and the table gathered on the first device is returned: the result
+ * is identical to gm_knn_query on one device.  Host pointers; blocking.  (One process per GPU over an existing
+ * communicator -- torch.distributed -- is the other supported form: INTEGRATION.md.) */
+typedef struct gm_multi gm_multi;
+int gm_multi_create(const uint64_t* packed, int64_t n_db, int guidelen, int metric, const int* devices, int n_devices,
+                    gm_multi** out);
+int gm_multi_knn_query(gm_multi* m, const uint64_t* q, int64_t n_q, int k, int32_t* ids, int32_t* dists, int32_t* counts);
+int gm_multi_devices(const gm_multi* m);
+int gm_multi_has_comm(const gm_multi* m);          /* 1: an RCCL communicator exists and the all-gather goes through it */
+gm_index* gm_multi_index(gm_multi* m, int i);      /* the i-th device's handle (measurement hooks, gm_set_variant) */
+void gm_multi_free(gm_multi* m);
+
 /* PAM scan + target extraction (replaces the regex loops of PamTarget.find_targets,
  * guidemaker/core.py:142-246).  seq: n upper-case ASCII bases of ONE record; pam: IUPAC string;
  * five_prime: 1 = 5'-[pam][target]-3', 0 = 5'-[target][pam]-3'.  gm_pam_count uploads the record, finds

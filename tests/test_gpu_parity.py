@@ -686,3 +686,24 @@ def test_fuzz_against_oracle_time_boxed(oracle):
     n_cases, bad = fuzz_parity.run(seconds=25.0, seed=2)
     assert bad is None, bad
     assert n_cases >= 20
+
+
+# ------------------------------------------------------------------ in-library multi-device entry
+def test_multi_device_entry_matches_single_device(oracle):
+    """gm_multi_* (one process, n GPUs, ncclCommInitAll + one ncclAllGather of the keys): on this box the device list
+    has one entry, which still runs the whole sequence -- shard, scan, key packing, RCCL all-gather, unpack."""
+    L, k = 20, 10
+    db = list(dict.fromkeys(random_pool(6000, L, seed=71)))
+    q = db[::2] + random_pool(333, L, seed=72)
+    m = _lib.MultiIndex(_lib.pack(db, L), L, _lib.METRIC_HAMMING, [0])
+    assert m.devices() == 1 and m.has_comm()          # librccl.so loaded, communicator created
+    ids, dists, counts = m.knn(_lib.pack(q, L), k)
+    oi, od, oc = _oracle_true_units(oracle, db, q, L, "hamming", k)
+    assert (ids == oi).all() and (dists == od).all() and (counts == oc).all()
+    e_ids, _, _ = m.knn(np.empty((0,), np.uint64), k)
+    assert e_ids.shape == (0, k)
+    m.close()
+    with pytest.raises(_lib.GmHipError):
+        _lib.MultiIndex(_lib.pack(db, L), L, _lib.METRIC_HAMMING, [0, 0])      # duplicate ordinal
+    with pytest.raises(_lib.GmHipError):
+        _lib.MultiIndex(_lib.pack(db, L), L, _lib.METRIC_HAMMING, [99])        # no such device

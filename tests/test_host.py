@@ -246,3 +246,38 @@ def test_packed_side_car_travels_with_the_frame():
     wrong.attrs["gm_packed"] = side[::-1].copy()
     tp3 = core.TargetProcessor(wrong, lsr=10)
     assert (tp3._packed_targets()[0] == side).all()
+
+
+def test_real_genome_hook(tmp_path, monkeypatch):
+    """a real genome file named by GM_GENOME_<WORKLOAD> replaces the synthetic stand-in.  The reader
+    restates the reference's input step (core.py:1065-1090: FASTA or GenBank, plain or gzipped, upper-cased)."""
+    import gzip
+    from guidemaker_amd import workloads
+    recs = carsonella()
+    fasta = tmp_path / "g.fasta.gz"
+    with gzip.open(fasta, "wt") as fh:
+        for r in recs:
+            fh.write(">%s some description\n" % r.id)
+            s = str(r.seq).lower()
+            for i in range(0, len(s), 70):
+                fh.write(s[i:i + 70] + "\n")
+    got = workloads.read_genome(str(fasta))
+    assert [g[0] for g in got] == [r.id for r in recs] and [g[1] for g in got] == [str(r.seq).upper() for r in recs]
+    gbk = tmp_path / "g.gbk"
+    with open(gbk, "w") as fh:
+        for r in recs:
+            s = str(r.seq).lower()
+            fh.write("LOCUS       %s %d bp DNA\nVERSION     %s.1\nFEATURES             Location/Qualifiers\nORIGIN\n" % (r.id, len(s), r.id))
+            for i in range(0, len(s), 60):
+                row = s[i:i + 60]
+                fh.write("%9d %s\n" % (i + 1, " ".join(row[j:j + 10] for j in range(0, len(row), 10))))
+            fh.write("//\n")
+    got2 = workloads.read_genome(str(gbk))
+    assert [g[1] for g in got2] == [g[1] for g in got] and got2[0][0] == recs[0].id + ".1"
+    monkeypatch.setenv("GM_GENOME_TINY", str(fasta))
+    pool = workloads.make_pool("tiny")
+    assert pool["real_genome"] == str(fasta) and "REAL genome" in pool["label"]
+    df = core.PamTarget("NGG", "3prime", "hamming").find_targets(recs, 20)
+    assert (pool["packed_all"] == _lib.pack(df["target"].tolist(), 20)).all()
+    monkeypatch.delenv("GM_GENOME_TINY")
+    assert workloads.make_pool("tiny")["real_genome"] is None
