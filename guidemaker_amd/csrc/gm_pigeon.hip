@@ -261,30 +261,32 @@ __global__ void k_chunk_total(const int* __restrict__ nch, const int* __restrict
     if (threadIdx.x == 0 && blockIdx.x == 0) *total = n > 0 ? cbase[n - 1] + nch[n - 1] : 0;
 }
 
+// one thread per ((block, bucket) entry, run of target buckets)
 __global__ __launch_bounds__(256) void k_fill_chunks(PgLayoutArg A, const int* __restrict__ cbase,
                                                      gm_pg_chunk* __restrict__ chunks, PgCounters* __restrict__ ctr) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = t / A.S, s = t % A.S;
     if (e >= A.n_entries) return;
     int b, v;
     pg_entry(A, e, b, v);
     const int c0 = A.coff[b][v], c1 = A.coff[b][v + 1];
     if (c1 <= c0) return;
     const bool ex = b < A.X;
-    const int n_bk = ex ? 1 + A.xne : 1, n_sub = ex ? A.S : 1, per = ex ? A.per : 1;
-    int w = cbase[e];
-    for (int s = 0; s < n_sub; ++s) {
-        const int e_lo = s * per, e_hi = e_lo + per < n_bk ? e_lo + per : n_bk;
-        const int lst = ex ? b * A.S + s : A.X * A.S + (b - A.X);
-        for (int c = c0; c < c1; c += 64, ++w)
-            chunks[w] = gm_pg_chunk{b, v, c, c1 - c < 64 ? c1 - c : 64, e_lo, e_hi, lst, 0};
-    }
-    // the 64 x 64 groups the scan evaluates for this candidate bucket
+    if (!ex && s > 0) return;
+    const int n_bk = ex ? 1 + A.xne : 1, per = ex ? A.per : 1;
+    const int n_ch = (c1 - c0 + 63) / 64;
+    const int e_lo = s * per, e_hi = e_lo + per < n_bk ? e_lo + per : n_bk;
+    const int lst = ex ? b * A.S + s : A.X * A.S + (b - A.X);
+    int w = cbase[e] + s * n_ch;
+    for (int c = c0; c < c1; c += 64, ++w)
+        chunks[w] = gm_pg_chunk{b, v, c, c1 - c < 64 ? c1 - c : 64, e_lo, e_hi, lst, 0};
+    // the 64 x 64 groups the scan evaluates for this run
     unsigned long long groups = 0;
-    for (int t = 0; t < n_bk; ++t) {
+    for (int u = e_lo; u < e_hi; ++u) {
         int add;
-        groups += (unsigned long long)A.gcnt[b][gm::pg_target_bucket(v, t, A.skip_len, add)];
+        groups += (unsigned long long)A.gcnt[b][gm::pg_target_bucket(v, u, A.skip_len, add)];
     }
-    atomicAdd(&ctr->pairs, (unsigned long long)((c1 - c0 + 63) / 64) * 64ull * groups * gm::LK_GROUP);
+    atomicAdd(&ctr->pairs, (unsigned long long)n_ch * 64ull * groups * gm::LK_GROUP);
 }
 
 __global__ __launch_bounds__(256) void k_count_incomplete(const int32_t* __restrict__ counts, const int32_t* __restrict__ d1,
@@ -741,13 +743,13 @@ int gm_pg_candidates(gm_index* idx, int64_t n_q, hipStream_t st) {
                                         rocprim::plus<int>(), st));
         hipLaunchKernelGGL(k_chunk_total, dim3(1), dim3(64), 0, st, pg->nch, pg->cbase, A.n_entries, &pg->ctr->n_chunks);
     }
-    hipLaunchKernelGGL(k_fill_chunks, grid_for(A.n_entries), dim3(256), 0, st, A, pg->cbase, pg->chunks, pg->ctr);
+    hipLaunchKernelGGL(k_fill_chunks, grid_for((int64_t)A.n_entries * A.S), dim3(256), 0, st, A, pg->cbase, pg->chunks, pg->ctr);
     HIP_TRY(hipGetLastError());
     pg->grid = grid;
     return GM_OK;
 }
 
-// Words per candidate of every hit list (word 0 = count): mean + 4.5 sigma (+ 3) of the hits expected from the
+// Words per candidate of every hit list (word 0 = count): mean + 4 sigma (+ 2) of the hits expected from the
 // list's target buckets under the independent-base model with the pool's own composition, taking every bucket as
 // large as the LARGEST bucket of its copy; a multiple of 4 (the merge reads 16 bytes at a time), at least 8.  A
 // list that still overflows (repeat families) only makes its row incomplete: the row is re-scanned by the plain
@@ -783,7 +785,7 @@ static void pg_list_capacity(const gm_index* idx, gm_pigeon* pg, int64_t n_q) {
     for (;;) {
         int64_t words = 0;
         for (int l = 0; l < P.n_lists; ++l) {
-            double c = std::ceil(scale * (mean[l] + 4.5 * std::sqrt(mean[l]) + 3.0)) + 1.0;
+            double c = std::ceil(scale * (mean[l] + 4.0 * std::sqrt(mean[l]) + 2.0)) + 1.0;
             if (c > 4096.0) c = 4096.0;
             int cap = ((int)c + 3) / 4 * 4;
             if (cap < 8) cap = 8;

@@ -41,7 +41,7 @@ def short_name(name):
     return s[:120]
 
 
-def collect(root):
+def collect(root, dispatch_min_ns=0.0):
     per = collections.defaultdict(lambda: collections.defaultdict(list))
     dur = collections.defaultdict(list)
     regs = {}
@@ -49,6 +49,8 @@ def collect(root):
         seen = set()
         with open(path, newline="") as fh:
             for row in csv.DictReader(fh):
+                if int(row["End_Timestamp"]) - int(row["Start_Timestamp"]) < dispatch_min_ns:
+                    continue      # e.g. one-pair spot-check launches of the same kernel
                 k = short_name(row["Kernel_Name"])
                 per[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
                 regs[k] = {"vgpr": int(row["VGPR_Count"]), "sgpr": int(row["SGPR_Count"]),
@@ -78,13 +80,14 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--stats-out")
     ap.add_argument("--min-ns", type=float, default=0.0, help="drop kernels whose mean dispatch is shorter")
+    ap.add_argument("--dispatch-min-ns", type=float, default=0.0, help="ignore single dispatches shorter than this")
     ap.add_argument("--counters-json", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                                             "profiles", "counters.json"))
     ap.add_argument("--register", help="workload key: record the dominant kernel's counters in --counters-json, where "
                                        "bench.py looks them up for its roofline block")
     ap.add_argument("--kernel", help="substring of the dominant kernel's short name (for --register)")
     a = ap.parse_args()
-    table = collect(a.root)
+    table = collect(a.root, a.dispatch_min_ns)
     table = {k: v for k, v in table.items() if v["mean_ns_in_pmc_passes"] >= a.min_ns}
     with open(a.out, "w") as fh:
         json.dump({"_source": a.root, "_note": __doc__.split("\n\n")[2].replace("\n", " "), "kernels": table},

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/profile.sh TAG WORKLOAD [bench.py args...]  -- run ON THE GPU BOX (through gpurun).
+# tools/profile.sh TAG WORKLOAD|cfd [args...]  -- run ON THE GPU BOX (through gpurun).
 # One rocprofv3 --kernel-trace --stats pass and three PMC passes (SQ+GRBM counters; FETCH_SIZE; WRITE_SIZE --
 # FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950, MI355X_MICROARCH.md "rocprofv3 PMC slots") of
 #   python3 bench.py --workload WORKLOAD --steps 5 --warmup 2 --no-cpu-baseline [args]
@@ -9,7 +9,11 @@ TAG=$1; WL=$2; shift 2
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python3 bench.py --workload $WL --steps 5 --warmup 2 --no-cpu-baseline $*"
+if [ "$WL" = "cfd" ]; then      # the CFD kernel: tools/cfd_bench.py (50 M device-resident pairs)
+  CMD="python3 tools/cfd_bench.py --rounds 5 --no-cpu $*"
+else
+  CMD="python3 bench.py --workload $WL --steps 5 --warmup 2 --no-cpu-baseline $*"
+fi
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o p --output-format csv -- $CMD > $OUT/stats.log 2>&1
 echo "[$TAG] stats pass done"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -d $OUT/pmc_sq -o p --output-format csv -- $CMD > $OUT/pmc_sq.log 2>&1
