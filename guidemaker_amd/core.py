@@ -137,25 +137,27 @@ for _a, _b in zip(b"ACGTMRWSYKVHDBXNacgtmrwsykvhdbxn", b"TGCAKYWSRMBDHVXNtgcakyw
     _RC_BYTES[_a] = _b
 
 
-def _cut_windows(seq: str, lo: np.ndarray, width: int, forward: np.ndarray) -> List[str]:
-    """seq[lo:lo+width] per row (reverse-complemented where forward is False) as a list of str.
-    Windows inside the record are gathered in one numpy pass; the few that are not fall back to
-    python slicing so that its wrap/clip behaviour is reproduced exactly."""
+def _cut_windows(seq: str, rc: str, lo: np.ndarray, width: int, forward: np.ndarray) -> List[str]:
+    """seq[lo:lo+width] per row (reverse-complemented where forward is False) as a list of str.  rc = the reverse
+    complement of the whole record: a reverse row's window is a plain slice of it.  Rows are slices of two Python
+    strings (no per-row array work); a forward window that leaves the record keeps python slice semantics (negative
+    start wraps, end clips), a reverse one is cut from the forward strand and complemented, as the reference does."""
     n = len(seq)
-    buf = np.frombuffer(seq.encode("ascii", "replace"), dtype=np.uint8)
-    inside = (lo >= 0) & (lo + width <= n)
-    out = np.empty(lo.shape, dtype=object)
-    if inside.any():
-        idx = lo[inside][:, None] + np.arange(width)[None, :]
-        win = buf[idx]
-        rev = ~forward[inside]
-        win[rev] = _RC_BYTES[win[rev]][:, ::-1]
-        out[inside] = np.ascontiguousarray(win).view("S%d" % width).ravel().astype(str)
-    for i in np.flatnonzero(~inside).tolist():
-        a = int(lo[i])
-        piece = seq[a:a + width]
-        out[i] = piece if forward[i] else reverse_complement(piece)
-    return out.tolist()
+    fw = np.flatnonzero(forward)
+    rv = np.flatnonzero(~forward)
+    out = [None] * lo.shape[0]
+    a_fw = lo[fw].tolist()
+    for i, a in zip(fw.tolist(), a_fw):
+        out[i] = seq[a:a + width]
+    lo_rv = lo[rv]
+    inside = (lo_rv >= 0) & (lo_rv + width <= n)
+    if inside.all():
+        for i, a in zip(rv.tolist(), (n - lo_rv - width).tolist()):
+            out[i] = rc[a:a + width]
+    else:
+        for i, a, ok in zip(rv.tolist(), lo_rv.tolist(), inside.tolist()):
+            out[i] = rc[n - a - width:n - a] if ok else reverse_complement(seq[a:a + width])
+    return out
 
 
 def codes_to_strings(codes: np.ndarray) -> List[str]:
@@ -188,13 +190,16 @@ class PamTarget:
         return "A PAM object: {self.pam}".format(self=self)
 
     def find_targets(self, seq_record_iter: object, target_len: int) -> pd.DataFrame:
-        """All targets next to the PAM on both strands, as the reference's dataframe."""
+        """All targets next to the PAM on both strands, as the reference's dataframe (core.py:83-292): same rows,
+        row order, columns and dtypes.  The strings of the frame (target, exact PAM, 30-mer context) are cut as slices
+        of the record and of its reverse complement; the columns are assembled once, in their final dtypes."""
         five = self.pam_orientation == "5prime"
-        frames = []
-        packed_parts = []
+        plen = len(self.pam)
+        cols = {k: [] for k in ("target", "exact_pam", "start", "stop", "strand", "target_seq30", "seqcode")}
+        packed_parts, seqids = [], []
         # the PAM scan runs on the GPU when one is visible (and the guide fits the packed format);
         # the numpy scanner is the host implementation of the same step
-        on_gpu = target_len <= _lib.MAX_GUIDELEN and len(self.pam) <= 16 and _lib.device_count() > 0
+        on_gpu = target_len <= _lib.MAX_GUIDELEN and plen <= 16 and _lib.device_count() > 0
         for record in seq_record_iter:
             seq = str(record.seq)
             if on_gpu:
@@ -204,36 +209,43 @@ class PamTarget:
             if res["start"].size == 0:
                 continue
             strand = res["strand"]
-            ms, me = res["mstart"], res["mend"]
-            # 30-mer context and exact PAM, cut out of the record as byte windows; rows whose window
-            # leaves the record keep python slice semantics (a negative start wraps, the end clips:
-            # core.py:156,184,211,237)
+            ms, me, ts = res["mstart"], res["mend"], res["start"]
+            # 30-mer context: rows whose window leaves the record keep python slice semantics (a negative start
+            # wraps, the end clips: core.py:156,184,211,237)
             lo = np.where(strand == five, ms - 3, me - 27)
-            seq30 = _cut_windows(seq, lo, 30, strand)
-            pams = _cut_windows(seq, ms, len(self.pam), strand)
-            df = pd.DataFrame({
-                "target": (_lib.unpack(res["packed"], target_len) if on_gpu
-                           else codes_to_strings(res["codes"])),
-                "exact_pam": pams,
-                "start": res["start"], "stop": res["stop"], "strand": strand,
-                "pam_orientation": np.full(strand.shape, five, dtype=bool),
-                "target_seq30": seq30,
-            })
-            df["seqid"] = record.id
-            # per strand block the reference casts separately; the concatenation below matches it
-            frames.append(df)
+            rc = reverse_complement(seq)
+            cols["target_seq30"] += _cut_windows(seq, rc, lo, 30, strand)
+            cols["exact_pam"] += _cut_windows(seq, rc, ms, plen, strand)
+            cols["target"] += _cut_windows(seq, rc, ts, target_len, strand)
+            cols["start"].append(ts)
+            cols["stop"].append(res["stop"])
+            cols["strand"].append(strand)
+            cols["seqcode"].append(np.full(strand.shape, len(seqids), dtype=np.int32))
+            seqids.append(record.id)
             if target_len <= _lib.MAX_GUIDELEN:
                 packed_parts.append(res["packed"] if on_gpu else pack_codes(res["codes"]))
-        if not frames:
+        if not seqids:
             raise ValueError("No objects to concatenate")   # what pd.concat([]) raises in the reference
-        df_targets = pd.concat(frames, ignore_index=True)
-        df_targets = df_targets.astype({"target": "str", "exact_pam": "category", "start": "uint32",
-                                        "stop": "uint32", "strand": "bool", "pam_orientation": "bool",
-                                        "seqid": "category"})
-        df_targets = df_targets.assign(seedseq=np.nan, hasrestrictionsite=np.nan, isseedduplicated=np.nan)
-        df_targets = df_targets.astype({"seedseq": "str", "isseedduplicated": "bool"})
-        df_targets = df_targets.assign(dtype=self.dtype)
-        df_targets = df_targets.astype({"dtype": "category"})
+        n = len(cols["target"])
+        strand = np.concatenate(cols["strand"])
+        # 'seqid' as a category: categories sorted and unique, as astype("category") makes them
+        cats = sorted(set(seqids))
+        code_of = np.array([cats.index(x) for x in seqids], dtype=np.int32)
+        df_targets = pd.DataFrame({
+            "target": pd.Series(cols["target"], dtype=object),
+            "exact_pam": pd.Categorical(cols["exact_pam"]),
+            "start": np.concatenate(cols["start"]).astype(np.uint32),
+            "stop": np.concatenate(cols["stop"]).astype(np.uint32),
+            "strand": strand.astype(bool),
+            "pam_orientation": np.full(n, five, dtype=bool),
+            "target_seq30": pd.Series(cols["target_seq30"], dtype=object),
+            "seqid": pd.Categorical.from_codes(code_of[np.concatenate(cols["seqcode"])], categories=cats),
+            # the reference assigns NaN and casts: seedseq -> the string 'nan', isseedduplicated -> True (core.py:287-289)
+            "seedseq": pd.Series(np.full(n, "nan", dtype=object), dtype=object),
+            "hasrestrictionsite": np.full(n, np.nan),
+            "isseedduplicated": np.ones(n, dtype=bool),
+            "dtype": pd.Categorical.from_codes(np.zeros(n, dtype=np.int8), categories=[self.dtype]),
+        })
         if packed_parts:
             # side-car for TargetProcessor: the 2-bit packed form of the 'target' column (the boundary format of
             # include/gmhip.h), so that the filters, create_index and get_neighbors do not re-encode the strings
@@ -262,12 +274,25 @@ class NeighborMap(Mapping):
     consumers use .keys_array / .row_of / .ids / .dists / .counts directly.
     """
 
-    def __init__(self, query_targets, keep, ids, dists, counts, db_targets):
+    def __init__(self, query_targets, keep, ids, dists, counts, db_targets, q_packed=None, db_packed=None,
+                 guidelen=None):
         self._q = query_targets                  # list[str], candidate order
         self.keep = np.asarray(keep, dtype=np.int64)
         self.ids, self.dists, self.counts = ids, dists, counts
         self._db = db_targets                    # object array: index id -> sequence
         self._row = None                         # key -> row in the result arrays (lazy)
+        self._qp, self._dbp, self._L = q_packed, db_packed, guidelen      # packed forms (optional)
+
+    def packed_pairs(self, keys):
+        """(guides uint64 [n], similar guides uint64 [n, k], guide length) of the given keys when the packed forms
+        are known and every row has k hits; None otherwise."""
+        if self._qp is None or self._dbp is None or not len(keys):
+            return None
+        rowmap = self._rows()
+        rows = np.fromiter((rowmap[g] for g in keys), dtype=np.int64, count=len(keys))
+        if not (self.counts[rows] == self.ids.shape[1]).all():
+            return None
+        return self._qp[rows], self._dbp[self.ids[rows]], self._L
 
     def _rows(self):
         if self._row is None:
@@ -327,6 +352,7 @@ class TargetProcessor:
         self.shard_candidates = bool(shard_candidates)
         self._db_targets = None               # index id -> sequence
         self._packed_cache = None             # ((id(frame), rows), (packed, L) or None): see _packed_targets
+        self._db_packed = None                # packed form of _db_targets
         self._guidelen = None
         self.last_knn = None                  # (ids, dists, counts) of the last get_neighbors
 
@@ -461,6 +487,7 @@ class TargetProcessor:
         metric = _lib.METRIC_HAMMING if self._is_hamming() else _lib.METRIC_LEVEN
         if packed is None:
             packed = _lib.pack(self._db_targets.tolist(), self._guidelen)
+        self._db_packed = packed
         if self.nmslib_index is not None:
             self.nmslib_index.close()
         t0 = time.perf_counter()
@@ -508,7 +535,8 @@ class TargetProcessor:
         # reference: hamming compares the one-hot distance (2 x mismatches) with 2 * editdist and
         # reports int(x / 2); in true units both reduce to the same test / value
         keep = np.flatnonzero(dists[:, 1] >= self.editdist) if len(unique_targets) else np.empty(0, np.int64)
-        self.neighbors = NeighborMap(unique_targets, keep, ids, dists, counts, self._db_targets)
+        self.neighbors = NeighborMap(unique_targets, keep, ids, dists, counts, self._db_targets, q_packed=qpacked,
+                                     db_packed=self._db_packed, guidelen=self._guidelen)
 
     def export_bed(self) -> object:
         """Targets that are not seed-duplicated, as a BED-like frame."""
@@ -619,10 +647,13 @@ class TargetProcessor:
 # neighbors -> output-table columns
 # ------------------------------------------------------------------------------------------------
 def _join_rows_fixed(mat: np.ndarray) -> List[str]:
-    """(n, w) uint8 -> list of n str (one C-level conversion)."""
-    if mat.shape[0] == 0:
+    """(n, w) uint8 -> list of n str: one decode of the whole buffer, then plain slices (a fixed-width unicode array
+    would take 4 bytes per character)."""
+    n, w = mat.shape
+    if n == 0:
         return []
-    return np.ascontiguousarray(mat).view("S%d" % mat.shape[1]).ravel().astype(str).tolist()
+    big = np.ascontiguousarray(mat).tobytes().decode("ascii")
+    return [big[a:a + w] for a in range(0, n * w, w)]
 
 
 def format_neighbor_columns(targetprocessor_object, guide_sequences):
@@ -689,9 +720,18 @@ def neighbor_table(targetprocessor_object) -> pd.DataFrame:
     """Frame with one row per retained guide (the keys of .neighbors, first-seen order) and the columns
     'Guide sequence', 'Similar guides', 'Similar guide distances' -- what _format_guide_table (core.py:925-931) adds to
     the guide table, ready for cfd_score()."""
-    keys = list(targetprocessor_object.neighbors.keys())
+    nb = targetprocessor_object.neighbors
+    keys = list(nb.keys())
     sim, dst = format_neighbor_columns(targetprocessor_object, keys)
-    return pd.DataFrame({"Guide sequence": keys, "Similar guides": sim, "Similar guide distances": dst})
+    frame = pd.DataFrame({"Guide sequence": keys, "Similar guides": sim, "Similar guide distances": dst})
+    pk = getattr(nb, "packed_pairs", None)
+    if pk is not None:
+        # side-car for cfd_score: the packed guides and their packed similar guides (n x k), so that the strings just
+        # built are not parsed and re-encoded (checked against the strings on a few rows before use)
+        side = pk(keys)
+        if side is not None:
+            frame.attrs["gm_cfd_packed"] = side
+    return frame
 
 
 # ------------------------------------------------------------------------------------------------
@@ -743,36 +783,101 @@ def calc_cfd(wt: str, off: str, mm_scores=None) -> float:
     return float(calc_cfd_pairs([wt], [off])[0])
 
 
+def _split_similar(sim_col: List[str], L: int):
+    """'Similar guides' strings -> (per_row counts, packed off-targets) without splitting row by row, when every
+    listed sequence has the guide length L: the ';' are dropped from ONE joined string and the bytes packed in one
+    call.  Returns None when a row does not fit that shape (the general path then reports the mismatch)."""
+    n = len(sim_col)
+    lens = np.fromiter(map(len, sim_col), dtype=np.int64, count=n)
+    per_row = np.fromiter((s.count(';') for s in sim_col), dtype=np.int64, count=n) + 1
+    if not (lens == per_row * (L + 1) - 1).all():
+        return None
+    flat = "".join(sim_col).replace(";", "").upper().replace("U", "T")
+    total = int(per_row.sum())
+    if len(flat) != total * L:
+        return None
+    try:
+        return per_row, _lib.pack_bytes(flat.encode("ascii"), total, L)
+    except ValueError:
+        return None
+
+
+def _cfd_side_car(df, guides, sim_col):
+    """The packed (guides, similar guides, L) that neighbor_table attached to the frame -- used only if it still
+    describes the frame: same number of rows and, on a few probe rows, the same sequences as the strings."""
+    side = df.attrs.get("gm_cfd_packed") if hasattr(df, "attrs") else None
+    if side is None:
+        return None
+    gpk, spk, L = side
+    n = len(guides)
+    if n == 0 or gpk.shape[0] != n or spk.shape[0] != n:
+        return None
+    try:
+        for i in sorted({0, n // 3, n // 2, n - 1}):
+            if len(guides[i]) != L or _pack_rna([guides[i]], L)[0] != gpk[i]:
+                return None
+            parts = sim_col[i].split(';')
+            if len(parts) != spk.shape[1] or any(len(x) != L for x in parts) or not (_pack_rna(parts, L) == spk[i]).all():
+                return None
+    except ValueError:
+        return None
+    return gpk, spk, L
+
+
 def cfd_score(df, device: int = 0):
     """Adds 'CFD Similar Guides' (list of str(float)) and 'Max CFD' (reference core.py:1129-1148).
 
-    All (guide, similar guide) pairs of the frame go to the GPU in one batch; each distinct guide is
-    packed once."""
+    All (guide, similar guide) pairs of the frame go to the GPU in one batch; each distinct guide is packed once;
+    the str(float) formatting runs once per DISTINCT score."""
     guides = df['Guide sequence'].tolist()
-    sims = [s.split(';') for s in df['Similar guides'].tolist()]
-    per_row = np.fromiter(map(len, sims), dtype=np.int64, count=len(sims))
-    offs = list(itertools.chain.from_iterable(sims))
-    n = len(offs)
+    sim_col = df['Similar guides'].tolist()
     glen_row = np.fromiter(map(len, guides), dtype=np.int64, count=len(guides))
-    olen = np.fromiter(map(len, offs), dtype=np.int64, count=n)
-    glen = np.repeat(glen_row, per_row)
-    bad = np.flatnonzero(glen != olen)
-    if bad.size:
-        i = int(bad[0])
-        raise AssertionError("The lengths wt and off differ: wt = {}, off = {}".format(str(glen[i]), str(olen[i])))
-    scores = np.empty((n,), np.float64)
-    if n:
-        mm = _load_cfd_table()
-        gp = np.repeat(_pack_by_length(guides, glen_row), per_row)
-        op = _pack_by_length(offs, olen)
-        for L in np.unique(olen).tolist():
-            sel = np.flatnonzero(olen == L)
-            scores[sel] = _lib.cfd_batch(gp[sel], op[sel], L, mm, device)
+    fast = None
+    side = _cfd_side_car(df, guides, sim_col)
+    if side is None and len(guides) and (glen_row == glen_row[0]).all() and 1 <= int(glen_row[0]) <= _lib.MAX_GUIDELEN:
+        fast = _split_similar(sim_col, int(glen_row[0]))
+    if side is not None:
+        gpk, spk, L = side
+        per_row = np.full(len(guides), spk.shape[1], dtype=np.int64)
+        n = int(spk.size)
+        scores = _lib.cfd_batch(np.repeat(gpk, spk.shape[1]), spk.reshape(-1), L, _load_cfd_table(), device)
+    elif fast is not None:
+        per_row, op = fast
+        L = int(glen_row[0])
+        n = int(per_row.sum())
+        scores = np.empty((n,), np.float64)
+        if n:
+            gp = np.repeat(_pack_rna(guides, L), per_row)
+            scores[:] = _lib.cfd_batch(gp, op, L, _load_cfd_table(), device)
+    else:
+        sims = [s.split(';') for s in sim_col]
+        per_row = np.fromiter(map(len, sims), dtype=np.int64, count=len(sims))
+        offs = list(itertools.chain.from_iterable(sims))
+        n = len(offs)
+        olen = np.fromiter(map(len, offs), dtype=np.int64, count=n)
+        glen = np.repeat(glen_row, per_row)
+        bad = np.flatnonzero(glen != olen)
+        if bad.size:
+            i = int(bad[0])
+            raise AssertionError("The lengths wt and off differ: wt = {}, off = {}".format(str(glen[i]), str(olen[i])))
+        scores = np.empty((n,), np.float64)
+        if n:
+            mm = _load_cfd_table()
+            gp = np.repeat(_pack_by_length(guides, glen_row), per_row)
+            op = _pack_by_length(offs, olen)
+            for L in np.unique(olen).tolist():
+                sel = np.flatnonzero(olen == L)
+                scores[sel] = _lib.cfd_batch(gp[sel], op[sel], L, mm, device)
     ends = np.cumsum(per_row)
     starts = ends - per_row
-    flat = list(map(str, scores.tolist()))               # str(float), as the reference formats them
-    df['CFD Similar Guides'] = pd.Series([flat[a:b] for a, b in zip(starts.tolist(), ends.tolist())],
-                                         index=df.index, dtype=object)
+    # str(float), as the reference formats them (CFD products are almost all distinct: nothing to share)
+    flat_l = list(map(str, scores.tolist()))
+    if len(per_row) and (per_row == per_row[0]).all():
+        w = int(per_row[0])
+        lists = [flat_l[a:a + w] for a in range(0, n, w)]
+    else:
+        lists = [flat_l[a:b] for a, b in zip(starts.tolist(), ends.tolist())]
+    df['CFD Similar Guides'] = pd.Series(lists, index=df.index, dtype=object)
     # ''.split(';') yields [''] so every row has at least one entry, as in the reference
     df['Max CFD'] = np.maximum.reduceat(scores, starts) if n else np.empty((0,), np.float64)
     return df

@@ -25,6 +25,7 @@ struct gm_pg_blocks {
                                          // over S workgroups; list of (b < X, s) = b * S + s, of b >= X: X * S + b - X
     int n_lists;
     int run;                             // consecutive chunk-table entries executed on the same XCD
+    int debug;                           // timing experiments only (gm_set_param "pg_debug"): bit 0 = skip the list stores
     int row_words;                       // words of all lists of one candidate: its lists are contiguous in the hit buffer
     int lcap[GM_PG_MAXLISTS];            // words of list l (word 0 = hit count, then the keys); a multiple of 4
     int loff[GM_PG_MAXLISTS];            // sum of lcap over the lists before l: list l of candidate q starts at word

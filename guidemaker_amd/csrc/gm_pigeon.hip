@@ -342,6 +342,7 @@ struct gm_pigeon {
     int skip_len = 0;                  // positions of its own block each copy's table leaves out
     int Lp = 0;                        // positions the scan evaluates = L - skip_len (>= 10)
     int tune_sub = 2;                  // workgroups per expansion chunk (gm_set_param "pg_sub")
+    int tune_debug = 0;                // timing experiments (gm_set_param "pg_debug")
     int tune_run = 128;                // chunk-table entries per XCD run (gm_set_param "pg_run")
     int bstart[GM_PG_MAXB]{}, blen[GM_PG_MAXB]{};
     int ebase[GM_PG_MAXB + 1]{};
@@ -544,6 +545,10 @@ int gm_pg_set_param(gm_index* idx, const char* name, int value) {
     if (std::strcmp(name, "pg_sub") == 0) {
         if (value < 1 || value > 19) return gm_fail(GM_ERR_ARG, "pg_sub: 1..19");
         idx->pg->tune_sub = value;
+        return GM_OK;
+    }
+    if (std::strcmp(name, "pg_debug") == 0) {
+        idx->pg->tune_debug = value;
         return GM_OK;
     }
     if (std::strcmp(name, "pg_run") == 0) {
@@ -829,6 +834,7 @@ int gm_pg_scan(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
     blocks.n_sub = n_sub;
     const int thr0 = pg->B + pg->expand;      // accept d < thr0, i.e. d <= r = B + X - 1
     blocks.run = pg->tune_run;
+    blocks.debug = pg->tune_debug;
     const int64_t unit = 8 * (int64_t)blocks.run;      // the kernel's entry mapping permutes whole units
     const int64_t grid = (pg->grid + unit - 1) / unit * unit;
     switch (pg->Lp) {            // the kernel instantiated for the positions actually evaluated

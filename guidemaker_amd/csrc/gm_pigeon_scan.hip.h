@@ -104,7 +104,8 @@ struct PgQueue {
 
 // FLUSH: n (<= 64, wave-uniform) queued hit words are turned into list entries, one per lane.
 __device__ __forceinline__ void pg_flush(PgQueue& Q, int n, int lane, const uint4* __restrict__ recs,
-                                         uint32_t* __restrict__ lists, int lcap, int row_words, int k, int thr0) {
+                                         uint32_t* __restrict__ lists, int lcap, int row_words, int k, int thr0,
+                                         int debug = 0) {
     uint32_t tg = 0;
     uint2 m = make_uint2(0u, 0u);
     if (lane < n) {
@@ -130,7 +131,7 @@ __device__ __forceinline__ void pg_flush(PgQueue& Q, int n, int lane, const uint
             if (d < thr0 - 2) atomicAdd(&Q.c2[cl], 1);
         }
         const int slot = atomicAdd(&Q.cnt[cl], 1) + 1;      // word 0 of a list is its count
-        if (slot < lcap) lists[row * row_words + slot] = ((uint32_t)d << ID_BITS) | t.z;
+        if (slot < lcap && !(debug & 1)) lists[row * row_words + slot] = ((uint32_t)d << ID_BITS) | t.z;
     }
     __syncthreads();      // single-wave workgroup: orders the LDS atomics before the reads of the counters below
 }
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
     // flush when a full wave of entries is queued; afterwards the bounds may have tightened
 #define GM_PG_AFTER_GROUP(ADD)                                                    \
     if (Q.tail - Q.head >= WAVE) {                                                \
-        pg_flush(Q, WAVE, lane, recs, mylists, lcap, row_words, k, thr0);                    \
+        pg_flush(Q, WAVE, lane, recs, mylists, lcap, row_words, k, thr0, P.debug);                    \
         const int nt = pg_bound(Q, lane, k, thr0);                                \
         if (valid && nt < thr) thr = nt;                                          \
         lk_set_bound(Tb, L, thr - (ADD));                                         \
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
 #undef GM_PG_AFTER_GROUP
     while (Q.tail - Q.head > 0) {
         const int n_take = Q.tail - Q.head < WAVE ? Q.tail - Q.head : WAVE;
-        pg_flush(Q, n_take, lane, recs, mylists, lcap, row_words, k, thr0);
+        pg_flush(Q, n_take, lane, recs, mylists, lcap, row_words, k, thr0, P.debug);
     }
     if (valid) mylists[qi * row_words] = (uint32_t)Q.cnt[lane];      // every (list, candidate) pair has exactly one writer
 }

@@ -394,21 +394,26 @@ int gm_device_count(void) {
 int gm_pack(const char* seqs, int64_t n, int guidelen, uint64_t* out) {
     if (!seqs || !out || n < 0 || guidelen < 1 || guidelen > GM_MAX_GUIDELEN)
         return fail(GM_ERR_ARG, "gm_pack: bad argument");
+    static const struct Lut {
+        uint8_t code[256];
+        Lut() {
+            for (int i = 0; i < 256; ++i) code[i] = 4;      // 4 = not a base
+            code[(int)'A'] = 0;
+            code[(int)'C'] = 1;
+            code[(int)'G'] = 2;
+            code[(int)'T'] = 3;
+        }
+    } lut;
     for (int64_t i = 0; i < n; ++i) {
         uint64_t v = 0;
-        const char* s = seqs + i * guidelen;
+        unsigned bad = 0;
+        const unsigned char* s = reinterpret_cast<const unsigned char*>(seqs) + i * guidelen;
         for (int p = 0; p < guidelen; ++p) {
-            uint64_t c;
-            switch (s[p]) {
-                case 'A': c = 0; break;
-                case 'C': c = 1; break;
-                case 'G': c = 2; break;
-                case 'T': c = 3; break;
-                default:
-                    return fail(GM_ERR_SEQ, "gm_pack: non-ACGT base in sequence " + std::to_string(i));
-            }
-            v |= c << (2 * p);
+            const unsigned c = lut.code[s[p]];
+            bad |= c;
+            v |= (uint64_t)(c & 3u) << (2 * p);
         }
+        if (bad & 4u) return fail(GM_ERR_SEQ, "gm_pack: non-ACGT base in sequence " + std::to_string(i));
         out[i] = v;
     }
     return GM_OK;

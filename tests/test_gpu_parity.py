@@ -632,6 +632,12 @@ def test_output_columns_byte_identical(oracle, cfd_table, dtype):
                                                      cfd_table)
         assert out["CFD Similar Guides"].tolist() == want_lists          # lists of str(float)
         assert out["Max CFD"].tolist() == want_max
+        # the packed side-car neighbor_table attaches is used only while it describes the frame: a filtered or
+        # re-ordered frame goes through the strings and gives the same numbers
+        assert "gm_cfd_packed" in tab.attrs
+        sub = tab.iloc[::-2].reset_index(drop=True)[["Guide sequence", "Similar guides"]]
+        out2 = core.cfd_score(sub)
+        assert out2["CFD Similar Guides"].tolist() == want_lists[::-2] and out2["Max CFD"].tolist() == want_max[::-2]
 
 
 # ------------------------------------------------------------------ controls at genome scale (a6)

@@ -34,6 +34,8 @@ def main():
         codes = workloads.synth_genome(n, w["gc"], rng)
         recs.append(Rec(np.frombuffer(b"ACGT", np.uint8)[codes].tobytes().decode(), "rec%d" % i))
     t = {}
+    # warm the GPU context first (HIP initialisation is paid once per process, not per genome)
+    core.PamTarget(w["pam"], w["orientation"], w["metric"]).find_targets([Rec(recs[0].seq[:100000], "warm")], w["guidelen"])
     t0 = time.perf_counter()
     pt = core.PamTarget(w["pam"], w["orientation"], w["metric"])
     df = pt.find_targets(recs, w["guidelen"])
@@ -62,6 +64,7 @@ def main():
         t["cfd_score(%d rows)" % len(frame)] = time.perf_counter() - t0
     for k, v in t.items():
         print("%-28s %8.3f s" % (k, v))
+    print("%-28s %8.3f s" % ("find_targets .. get_neighbors", sum(t[x] for x in ("find_targets", "filters", "create_index", "get_neighbors"))))
 
 
 if __name__ == "__main__":

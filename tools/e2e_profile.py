@@ -19,6 +19,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="s1")
     ap.add_argument("--top", type=int, default=25)
+    ap.add_argument("--output", action="store_true", help="include the output columns and cfd_score")
+    ap.add_argument("--sort", default="cumulative")
     a = ap.parse_args()
     w = workloads.WORKLOADS[a.workload]
     rng = np.random.Generator(np.random.PCG64(w["seed"]))
@@ -37,6 +39,9 @@ def main():
         tp.find_unique_near_pam()
         tp.create_index(guidemaker_amd.CONFIG_PATH)
         tp.get_neighbors(guidemaker_amd.CONFIG_PATH)
+        if a.output:
+            frame = core.neighbor_table(tp)
+            core.cfd_score(frame)
         return tp
 
     pr = cProfile.Profile()
@@ -44,7 +49,7 @@ def main():
     flow()
     pr.disable()
     st = pstats.Stats(pr)
-    st.sort_stats("cumulative").print_stats(a.top)
+    st.sort_stats(a.sort).print_stats(a.top)
 
 
 if __name__ == "__main__":
