@@ -92,9 +92,12 @@ GM_FOR_EACH_LEN(GM_DECL_PG)
 // gm_pg_scan: the K1P launch; gm_pg_merge: hit lists -> top k + the list of rows that are not exact;
 // gm_pg_incomplete: how many such rows (synchronises the stream); gm_pg_gather / gm_pg_scatter: move those rows
 // to / from a compact query.
-int gm_pg_plan(int64_t n_db, int64_t n_q, int L, int k, double p_match, int max_len, int* expand, int* len0);
+int gm_pg_plan(int64_t n_db, int64_t n_q, int L, int k, double p_match, gm_pg_layout* out);
+bool gm_pg_layout_make(int L, int B, int X, int lenx, int n2, gm_pg_layout* out);
+int gm_pg_layout_radius(const gm_pg_layout& lay);
+bool gm_pg_layout_forced(const gm_index* idx, gm_pg_layout* out);
 int gm_pg_pool_stats(gm_index* idx, hipStream_t st, double* p_match);
-int gm_pg_prepare(gm_index* idx, int B, int expand, int len0, hipStream_t st);
+int gm_pg_prepare(gm_index* idx, const gm_pg_layout* lay, hipStream_t st);
 int gm_pg_candidates(gm_index* idx, int64_t n_q, hipStream_t st);
 int gm_pg_scan(gm_index* idx, int64_t n_q, int k, hipStream_t st);
 int gm_pg_merge(gm_index* idx, int kcap, int64_t n_q, int k, int32_t* ids, int32_t* dists, int32_t* counts,

@@ -3,7 +3,7 @@
 #include <stdint.h>
 
 constexpr int GM_PG_MAXB = 8;        // blocks per layout
-constexpr int GM_PG_MAXLEN = 6;      // bases per block (4^6 buckets)
+constexpr int GM_PG_MAXLEN = 8;      // bases per block (4^8 buckets)
 constexpr int GM_PG_MAXLISTS = 64;   // hit lists per candidate
 constexpr int GM_PG_ALIGN = 128;     // every bucket of a block-sorted pool copy starts on a multiple of 128 positions
                                      // (= 2 groups of 64 targets = one LDS-DMA unit of the scan)
@@ -13,28 +13,37 @@ constexpr int GM_PG_ALIGN = 128;     // every bucket of a block-sorted pool copy
 struct gm_pg_blocks {
     const uint32_t* table[GM_PG_MAXB];   // one-hot table of copy b (K1L group format; padding positions all-zero)
     const uint4* recs[GM_PG_MAXB];       // per position {plane.x, plane.y, pool id, 0}; id = 0xffffffff on padding
-    const int32_t* goff[GM_PG_MAXB];     // bucket v starts at 64-target group goff[v] (even)
-    const int32_t* gcnt[GM_PG_MAXB];     // ... and holds targets in its first gcnt[v] groups
+    const int2* bdesc[GM_PG_MAXB];       // bucket v: .x = first 64-target group (even), .y = groups that hold targets
     const uint32_t* cperm[GM_PG_MAXB];   // candidates sorted by block b: sorted position -> candidate row
     int skip[GM_PG_MAXB];                // copy b's table leaves out sequence positions [skip[b], skip[b] + skip_len)
     int skip_len;
     int n_blocks;                        // B
-    int n_expand;                        // X: blocks 0 .. X-1 also scan the one-substitution neighbour buckets
-    int xlen;                            // bases of an expansion block (3 * xlen neighbour buckets per bucket)
-    int n_sub;                           // S: the 1 + 3 * xlen target buckets of an expansion block's chunk are split
-                                         // over S workgroups; list of (b < X, s) = b * S + s, of b >= X: X * S + b - X
+    int blen[GM_PG_MAXB];                // bases of block b (the kernel decodes neighbour buckets with it)
     int n_lists;
     int run;                             // consecutive chunk-table entries executed on the same XCD
     int debug;                           // timing experiments only (gm_set_param "pg_debug"): bit 0 = skip the list stores
-    int row_words;                       // words of all lists of one candidate: its lists are contiguous in the hit buffer
-    int lcap[GM_PG_MAXLISTS];            // words of list l (word 0 = hit count, then the keys); a multiple of 4
-    int loff[GM_PG_MAXLISTS];            // sum of lcap over the lists before l: list l of candidate q starts at word
-                                         // q * row_words + loff[l] of the hit buffer
+    int row_words;                       // words of one candidate's row of the hit buffer: [hit count of every list,
+                                         // padded to 4 words][keys of list 0][keys of list 1] ...
+    int lcap[GM_PG_MAXLISTS];            // key capacity of list l (a multiple of 4)
+    int loff[GM_PG_MAXLISTS];            // the keys of list l of candidate q start at word q * row_words + loff[l]
 };
 
+// A layout: B blocks of blen[b] bases (sum = guide length) with a search radius trad[b] per block: 0 = only the
+// candidates' own bucket is scanned, 1 = also its 3 len one-substitution neighbour buckets, 2 = also its
+// 9 C(len, 2) two-substitution neighbour buckets.  A pair that is NOT found under any block has more than trad[b]
+// mismatches in every block, so every pair within r = sum(trad[b] + 1) - 1 is found.
+struct gm_pg_layout {
+    int B;
+    int blen[GM_PG_MAXB];
+    int trad[GM_PG_MAXB];
+};
+__host__ __device__ constexpr int gm_pg_buckets_of(int len, int t) {      // target buckets per candidate bucket
+    return 1 + (t >= 1 ? 3 * len : 0) + (t >= 2 ? 9 * (len * (len - 1) / 2) : 0);
+}
+
 // one workgroup's work: cn (<= 64) candidates starting at sorted position c0 of block b's candidate order, all
-// from bucket v, against the target buckets e_lo .. e_hi - 1 of copy b (0 = bucket v itself, 1 + 3 * p + a = the
-// neighbour bucket whose base at block position p is replaced by the a-th other base); hits go to list lst.
+// from bucket v, against the target buckets e_lo .. e_hi - 1 of copy b (numbering: pg_target_bucket); hits go to
+// list lst.
 struct gm_pg_chunk {
     int b, v, c0, cn, e_lo, e_hi, lst, pad;
 };

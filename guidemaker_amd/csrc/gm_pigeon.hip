@@ -33,11 +33,13 @@ struct PgLayoutArg {              // per-block geometry + offsets, by value
     int B;
     int ebase[GM_PG_MAXB + 1];    // first entry of block b in the flattened (block, bucket) list
     const int32_t* coff[GM_PG_MAXB];
-    const int32_t* gcnt[GM_PG_MAXB];
-    int X;                        // expansion blocks (blocks 0 .. X-1), 0 = none
-    int xne;                      // neighbour buckets per bucket of an expansion block = 3 x block length
-    int S;                        // workgroups the 1 + xne target buckets of an expansion chunk are split over
-    int per;                      // target buckets per such workgroup
+    const int2* bdesc[GM_PG_MAXB];
+    int blen[GM_PG_MAXB];         // bases of block b
+    int nbk[GM_PG_MAXB];          // target buckets per candidate bucket of block b (own + neighbours within its radius)
+    int nsub[GM_PG_MAXB];         // workgroups those target buckets are split over
+    int per[GM_PG_MAXB];          // target buckets per such workgroup
+    int lbase[GM_PG_MAXB];        // hit list of (b, s) = lbase[b] + s
+    int smax;                     // max nsub
     int skip_len;
     int n_entries;
 };
@@ -206,15 +208,15 @@ __global__ __launch_bounds__(1024) void k_cand_scatter(const uint2* __restrict__
     }
 }
 
-// sorted position i (key v = keys[i], pool row rows[i]) -> position goff[v] * 64 + (i - raw_off[v]) of the padded copy
+// sorted position i (key v = keys[i], pool row rows[i]) -> position bdesc[v].x * 64 + (i - raw_off[v]) of the padded copy
 __global__ __launch_bounds__(256) void k_scatter_recs(const uint2* __restrict__ planes, const uint32_t* __restrict__ keys,
                                                       const uint32_t* __restrict__ rows, int64_t n,
-                                                      const int32_t* __restrict__ raw_off, const int32_t* __restrict__ goff,
+                                                      const int32_t* __restrict__ raw_off, const int2* __restrict__ bdesc,
                                                       uint4* __restrict__ recs) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t v = keys[i], row = rows[i];
-    const int64_t pos = (int64_t)goff[v] * gm::LK_GROUP + (i - raw_off[v]);
+    const int64_t pos = (int64_t)bdesc[v].x * gm::LK_GROUP + (i - raw_off[v]);
     const uint2 e = planes[row];
     recs[pos] = make_uint4(e.x, e.y, row, 0u);
 }
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(256) void k_chunk_count(PgLayoutArg A, int* __restr
     int b, v;
     pg_entry(A, e, b, v);
     const int cnt = A.coff[b][v + 1] - A.coff[b][v];
-    nch[e] = (cnt + 63) / 64 * (b < A.X ? A.S : 1);
+    nch[e] = (cnt + 63) / 64 * A.nsub[b];
 }
 
 // n_chunks = last exclusive offset + last count
@@ -265,18 +267,17 @@ __global__ void k_chunk_total(const int* __restrict__ nch, const int* __restrict
 __global__ __launch_bounds__(256) void k_fill_chunks(PgLayoutArg A, const int* __restrict__ cbase,
                                                      gm_pg_chunk* __restrict__ chunks, PgCounters* __restrict__ ctr) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int e = t / A.S, s = t % A.S;
+    const int e = t / A.smax, s = t % A.smax;
     if (e >= A.n_entries) return;
     int b, v;
     pg_entry(A, e, b, v);
+    if (s >= A.nsub[b]) return;
     const int c0 = A.coff[b][v], c1 = A.coff[b][v + 1];
     if (c1 <= c0) return;
-    const bool ex = b < A.X;
-    if (!ex && s > 0) return;
-    const int n_bk = ex ? 1 + A.xne : 1, per = ex ? A.per : 1;
+    const int n_bk = A.nbk[b], per = A.per[b];
     const int n_ch = (c1 - c0 + 63) / 64;
     const int e_lo = s * per, e_hi = e_lo + per < n_bk ? e_lo + per : n_bk;
-    const int lst = ex ? b * A.S + s : A.X * A.S + (b - A.X);
+    const int lst = A.lbase[b] + s;
     int w = cbase[e] + s * n_ch;
     for (int c = c0; c < c1; c += 64, ++w)
         chunks[w] = gm_pg_chunk{b, v, c, c1 - c < 64 ? c1 - c : 64, e_lo, e_hi, lst, 0};
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(256) void k_fill_chunks(PgLayoutArg A, const int* _
     unsigned long long groups = 0;
     for (int u = e_lo; u < e_hi; ++u) {
         int add;
-        groups += (unsigned long long)A.gcnt[b][gm::pg_target_bucket(v, u, A.skip_len, add)];
+        groups += (unsigned long long)A.bdesc[b][gm::pg_target_bucket(v, u, A.blen[b], A.skip_len, add)].y;
     }
     atomicAdd(&ctr->pairs, (unsigned long long)n_ch * 64ull * groups * gm::LK_GROUP);
 }
@@ -337,20 +338,22 @@ struct gm_pigeon {
     int B = 0;
     double p_match = 0.0;              // P(two pool sequences carry the same base at a position); 0 = not measured
     int max_bucket[GM_PG_MAXB]{};      // largest bucket of every pool copy
-    int expand = 0;                    // X: the neighbour buckets of blocks 0 .. X-1 are scanned too, B blocks then
-                                       // serve radius r = B + X - 1
+    int trad[GM_PG_MAXB]{};            // search radius of every block (gm_pg_layout): the layout serves
+                                       // r = sum(trad[b] + 1) - 1
+    int nbk[GM_PG_MAXB]{}, nsub[GM_PG_MAXB]{}, per[GM_PG_MAXB]{}, lbase[GM_PG_MAXB]{};      // see PgLayoutArg
+    int smax = 1;
     int skip_len = 0;                  // positions of its own block each copy's table leaves out
     int Lp = 0;                        // positions the scan evaluates = L - skip_len (>= 10)
     int tune_sub = 2;                  // workgroups per expansion chunk (gm_set_param "pg_sub")
     int tune_debug = 0;                // timing experiments (gm_set_param "pg_debug")
+    int tune_layout = 0;               // experiments: forced layout, decimal digit pairs (len, radius) per block
     int tune_run = 128;                // chunk-table entries per XCD run (gm_set_param "pg_run")
     int bstart[GM_PG_MAXB]{}, blen[GM_PG_MAXB]{};
     int ebase[GM_PG_MAXB + 1]{};
     // pool side
     uint32_t* table[GM_PG_MAXB]{};
     uint4* recs[GM_PG_MAXB]{};
-    int32_t* goff[GM_PG_MAXB]{};
-    int32_t* gcnt[GM_PG_MAXB]{};
+    int2* bdesc[GM_PG_MAXB]{};
     int32_t* raw_off = nullptr;        // build scratch: bucket offsets of the unpadded sorted order
     int64_t raw_off_cap = 0;
     // query side (grow-only)
@@ -370,7 +373,8 @@ struct gm_pigeon {
     uint32_t* lists = nullptr;    // hit lists (gm_pg_blocks::loff / lcap)
     int64_t lists_cap = 0;
     int64_t cap_nq = -1;          // candidate count / layout the list capacities were sized for
-    int cap_x_for = -1, cap_sub_for = -1;
+    int cap_sub_for = -1;
+    uint64_t cap_layout_for = 0;
     double mem_limit = 0.0;
     gm_pg_blocks blocks{};
     int32_t* inc = nullptr;
@@ -410,13 +414,11 @@ void free_pool_side(gm_pigeon* pg) {
     for (int b = 0; b < GM_PG_MAXB; ++b) {
         if (pg->table[b]) (void)hipFree(pg->table[b]);
         if (pg->recs[b]) (void)hipFree(pg->recs[b]);
-        if (pg->goff[b]) (void)hipFree(pg->goff[b]);
-        if (pg->gcnt[b]) (void)hipFree(pg->gcnt[b]);
+        if (pg->bdesc[b]) (void)hipFree(pg->bdesc[b]);
         if (pg->coff[b]) (void)hipFree(pg->coff[b]);
         pg->table[b] = nullptr;
         pg->recs[b] = nullptr;
-        pg->goff[b] = nullptr;
-        pg->gcnt[b] = nullptr;
+        pg->bdesc[b] = nullptr;
         pg->coff[b] = nullptr;
     }
     pg->B = 0;
@@ -456,41 +458,65 @@ static double tail_within(int n, int r, double pm) {
     return cum;
 }
 
+// Legacy layout forms (forced variants, tests): B blocks, the first X of them with radius 1 and lenx bases (see
+// pg_block_lengths), the others radius 0; n2 > 0: block 0 gets radius 2 instead.
+bool gm_pg_layout_make(int L, int B, int X, int lenx, int n2, gm_pg_layout* out) {
+    int blen[GM_PG_MAXB];
+    if (!pg_block_lengths(L, B, X, lenx, GM_PG_MAXLEN, blen)) return false;
+    out->B = B;
+    for (int b = 0; b < GM_PG_MAXB; ++b) {
+        out->blen[b] = b < B ? blen[b] : 0;
+        out->trad[b] = b < X ? 1 : 0;
+    }
+    if (n2 > 0) out->trad[0] = 2;
+    return true;
+}
+
+// experiments: layout from gm_set_param "pg_layout" (e.g. 826161 = blocks of 8, 6, 6 bases with radii 2, 1, 1)
+bool gm_pg_layout_forced(const gm_index* idx, gm_pg_layout* out) {
+    if (!idx->pg || idx->pg->tune_layout <= 0) return false;
+    int digits[16], n = 0;
+    for (int v = idx->pg->tune_layout; v > 0 && n < 16; v /= 10) digits[n++] = v % 10;
+    if (n % 2 != 0 || n / 2 > GM_PG_MAXB) return false;
+    out->B = n / 2;
+    for (int b = 0; b < out->B; ++b) {
+        out->blen[b] = digits[n - 1 - 2 * b];
+        out->trad[b] = digits[n - 2 - 2 * b];
+    }
+    return true;
+}
+
+int gm_pg_layout_radius(const gm_pg_layout& lay) {
+    int r = -1;
+    for (int b = 0; b < lay.B; ++b) r += lay.trad[b] + 1;
+    return r;
+}
+
 // Layout choice under an independent-base model with the pool's own composition (p_match = sum_b f_b^2).
-// Plain mode (X = 0): B = r + 1 blocks, every pair within r shares a block.  Expansion (X > 0): B blocks serve
-// r = B + X - 1 -- a pair within r that shares no block has m_b >= 1 mismatches in every block with
-// sum m_b <= r, so at most X - 1 blocks carry two or more and at least one of the X expansion blocks carries
-// exactly one: the pair sits in a one-substitution neighbour bucket of that block (3 x len per bucket), and
-// those buckets get one extra pass each.
-// cost = fraction of the pairs evaluated + P(Poisson(n P(d <= r)) < k) (rows re-scanned); 0 when the plain
-// scan is at least as good.  max_len = longest block the caller can use (buckets must hold enough candidates).
-// The block lengths are chosen too: block 0 (the expansion block) may be longer than the others.
-int gm_pg_plan(int64_t n_db, int64_t n_q, int L, int k, double p_match, int max_len, int* expand, int* len0_out) {
-    if (expand) *expand = 0;
-    if (len0_out) *len0_out = 0;
-    if (max_len > GM_PG_MAXLEN) max_len = GM_PG_MAXLEN;
+// A layout = blocks with a search radius t_b each (gm_pg_types.h): n2 blocks with the two-substitution
+// neighbourhood (len2 bases each), n1 with the one-substitution neighbourhood, n0 plain; it serves
+// r = 3 n2 + 2 n1 + n0 - 1.  A pair within r that is not found under any block would have more than t_b mismatches
+// in every block, i.e. at least r + 1 in total.
+// cost = group evaluations per pair + P(Poisson(n P(d <= r)) < k) (rows re-scanned):
+//   sum_b buckets_b x share_b x (1 + 128 / targets per bucket) x (1 + 32 / candidates per bucket)
+// (share = p_match^len; a bucket's targets are padded to whole 64-target groups and every bucket visit costs about
+// 1.5 group evaluations on top -- descriptor load, a DMA unit waited for cold; measured on S3 / S4, profiles/r02 --;
+// a bucket's candidates are padded to whole 64-lane chunks; under a skewed composition a
+// neighbour bucket holds rho = ((1 - p) / 3) / p times the targets of the own bucket per substitution).
+// Returns 1 and fills *out when a layout beats the plain scan clearly (cost < 0.45), else 0.
+int gm_pg_plan(int64_t n_db, int64_t n_q, int L, int k, double p_match, gm_pg_layout* out) {
     if (L < 12 || L > GM_MAX_GUIDELEN || n_db < 32768 || k < 1 || k > 20) return 0;
     if (!(p_match >= 0.25 && p_match < 0.9)) p_match = 0.25;
     if (n_q < 1) n_q = n_db;
+    const double rho = ((1.0 - p_match) / 3.0) / p_match;
     double best = 0.45;      // K1P has to be clearly cheaper than scanning everything
-    int best_B = 0;
-    for (int X = 0; X <= 3; ++X) {
-        for (int B = X + 1 > 2 ? X + 1 : 2; B <= GM_PG_MAXB; ++B) {
-            const int r = B + X - 1;
-            const int even = (L + B - 1) / B;
-            // longer expansion blocks (small buckets, cheap neighbour passes) against shorter others
-            for (int lenx = even; lenx <= (X ? max_len : even); ++lenx) {
-                int blen[GM_PG_MAXB];
-                if (!pg_block_lengths(L, B, X, lenx, max_len, blen)) continue;
-                // fraction of the pairs evaluated, with the padding of a bucket's ends to 64 targets / candidates
-                double work = 0.0;
-                for (int b = 0; b < B; ++b) {
-                    const double share = std::pow(p_match, (double)blen[b]);
-                    const double pad = (1.0 + 32.0 / (share * (double)n_db)) * (1.0 + 32.0 / (share * (double)n_q));
-                    double passes = 1.0;
-                    if (b < X) passes += 3.0 * blen[b] * ((1.0 - p_match) / 3.0) / p_match;
-                    work += share * pad * passes;
-                }
+    int found = 0;
+    for (int n2 = 0; n2 <= 1; ++n2)
+        for (int n1 = 0; n1 <= 3; ++n1)
+            for (int n0 = 0; n2 + n1 + n0 <= GM_PG_MAXB; ++n0) {
+                const int B = n2 + n1 + n0;
+                if (B < 2) continue;
+                const int r = 3 * n2 + 2 * n1 + n0 - 1;
                 const double mean = (double)n_db * tail_within(L, r, p_match);
                 double p_inc = 0.0, term = std::exp(-mean);      // P(Poisson(mean) < k)
                 for (int j = 0; j < k; ++j) {
@@ -498,17 +524,66 @@ int gm_pg_plan(int64_t n_db, int64_t n_q, int L, int k, double p_match, int max_
                     term *= mean / (j + 1);
                 }
                 if (mean > 700.0) p_inc = 0.0;
-                const double cost = work + (p_inc < 1.0 ? p_inc : 1.0);
-                if (cost < best) {
-                    best = cost;
-                    best_B = B;
-                    if (expand) *expand = X;
-                    if (len0_out) *len0_out = X ? lenx : 0;
-                }
+                if (p_inc >= best) continue;
+                for (int len2 = n2 ? 4 : 0; len2 <= (n2 ? GM_PG_MAXLEN : 0); ++len2)
+                    for (int len1 = (n1 && n0) ? 2 : 0; len1 <= ((n1 && n0) ? GM_PG_MAXLEN : 0); ++len1) {
+                        gm_pg_layout lay{};
+                        lay.B = B;
+                        int rest = L - n2 * len2, nb = 0;
+                        for (int b = 0; b < n2; ++b, ++nb) {
+                            lay.blen[nb] = len2;
+                            lay.trad[nb] = 2;
+                        }
+                        bool ok = true;
+                        if (n1 && n0) {      // radius-1 blocks of len1, the plain blocks share the rest evenly
+                            rest -= n1 * len1;
+                            for (int b = 0; b < n1; ++b, ++nb) {
+                                lay.blen[nb] = len1;
+                                lay.trad[nb] = 1;
+                            }
+                            for (int b = 0; b < n0; ++b, ++nb) {
+                                lay.blen[nb] = rest / n0 + (b < rest % n0 ? 1 : 0);
+                                lay.trad[nb] = 0;
+                            }
+                            ok = rest >= 2 * n0 && lay.blen[n2 + n1] <= len1;
+                        } else {             // one class of blocks besides the radius-2 block: even split
+                            const int m = n1 + n0;
+                            if (m == 0) {
+                                ok = rest == 0;
+                            } else {
+                                for (int b = 0; b < m; ++b, ++nb) {
+                                    lay.blen[nb] = rest / m + (b < rest % m ? 1 : 0);
+                                    lay.trad[nb] = n1 ? 1 : 0;
+                                }
+                                ok = rest >= 2 * m;
+                            }
+                        }
+                        if (!ok) continue;
+                        double work = 0.0;
+                        for (int b = 0; b < B && ok; ++b) {
+                            const int len = lay.blen[b];
+                            if (len < 2 || len > GM_PG_MAXLEN) ok = false;
+                            const double share = std::pow(p_match, (double)len);
+                            const double tpb = share * (double)n_db, cpb = share * (double)n_q;
+                            if (tpb < 8.0 || cpb < 8.0) ok = false;      // buckets far smaller than a group: never worth it
+                            double passes = 1.0;
+                            if (lay.trad[b] >= 1) passes += 3.0 * len * rho;
+                            if (lay.trad[b] >= 2) passes += 9.0 * (len * (len - 1) / 2) * rho * rho;
+                            work += share * passes * (1.0 + 128.0 / tpb) * (1.0 + 32.0 / cpb);
+                        }
+                        if (!ok) continue;
+                        int lists = 0;
+                        for (int b = 0; b < B; ++b) lists += (gm_pg_buckets_of(lay.blen[b], lay.trad[b]) + 7) / 8;
+                        if (lists > GM_PG_MAXLISTS) continue;
+                        const double cost = work + (p_inc < 1.0 ? p_inc : 1.0);
+                        if (cost < best) {
+                            best = cost;
+                            *out = lay;
+                            found = 1;
+                        }
+                    }
             }
-        }
-    }
-    return best_B;
+    return found;
 }
 
 // measures the pool's base composition once per index (one small kernel + a 32-byte read-back)
@@ -538,13 +613,22 @@ int gm_pg_pool_stats(gm_index* idx, hipStream_t st, double* p_match) {
 }
 
 int gm_pg_blocks_of(const gm_index* idx) { return idx->pg ? idx->pg->B : 0; }
-int gm_pg_radius(const gm_index* idx) { return idx->pg ? idx->pg->B + idx->pg->expand - 1 : 0; }
+int gm_pg_radius(const gm_index* idx) {
+    if (!idx->pg) return 0;
+    int r = -1;
+    for (int b = 0; b < idx->pg->B; ++b) r += idx->pg->trad[b] + 1;
+    return r;
+}
 
 int gm_pg_set_param(gm_index* idx, const char* name, int value) {
     if (!idx->pg) idx->pg = new gm_pigeon();
     if (std::strcmp(name, "pg_sub") == 0) {
         if (value < 1 || value > 19) return gm_fail(GM_ERR_ARG, "pg_sub: 1..19");
         idx->pg->tune_sub = value;
+        return GM_OK;
+    }
+    if (std::strcmp(name, "pg_layout") == 0) {
+        idx->pg->tune_layout = value;
         return GM_OK;
     }
     if (std::strcmp(name, "pg_debug") == 0) {
@@ -573,18 +657,27 @@ void gm_pg_free(gm_index* idx) {
     idx->pg = nullptr;
 }
 
-// Block-sorted, bucket-padded pool copies for the layout (B blocks, `expand` of them of len0 bases).
-int gm_pg_prepare(gm_index* idx, int B, int expand, int len0, hipStream_t st) {
-    const int L = idx->L;
-    int blen[GM_PG_MAXB];
-    if (!pg_block_lengths(L, B, expand, len0, GM_PG_MAXLEN, blen)) return gm_fail(GM_ERR_ARG, "gm_pg_prepare: bad layout");
+// Block-sorted, bucket-padded pool copies for the layout (they depend on the block lengths only; the radii just
+// select which buckets a query visits).
+int gm_pg_prepare(gm_index* idx, const gm_pg_layout* lay, hipStream_t st) {
+    const int L = idx->L, B = lay->B;
+    int sum = 0;
+    if (B < 2 || B > GM_PG_MAXB) return gm_fail(GM_ERR_ARG, "gm_pg_prepare: bad layout");
+    for (int b = 0; b < B; ++b) {
+        if (lay->blen[b] < 2 || lay->blen[b] > GM_PG_MAXLEN || lay->trad[b] < 0 || lay->trad[b] > 2)
+            return gm_fail(GM_ERR_ARG, "gm_pg_prepare: bad layout");
+        sum += lay->blen[b];
+    }
+    if (sum != L) return gm_fail(GM_ERR_ARG, "gm_pg_prepare: bad layout");
     if (!idx->pg) idx->pg = new gm_pigeon();
     gm_pigeon* pg = idx->pg;
-    pg->expand = expand;
     bool same = pg->B == B;
-    for (int b = 0; b < B && same; ++b) same = pg->blen[b] == blen[b];
-    if (same) return GM_OK;            // the pool copies depend on the block lengths only
+    for (int b = 0; b < B && same; ++b) same = pg->blen[b] == lay->blen[b];
+    for (int b = 0; b < B; ++b) pg->trad[b] = lay->trad[b];
+    if (same) return GM_OK;
     free_pool_side(pg);
+    for (int b = 0; b < B; ++b) pg->trad[b] = lay->trad[b];
+    const int* blen = lay->blen;
     const int64_t n = idx->n_db;
     int pos = 0, base = blen[0];
     pg->ebase[0] = 0;
@@ -608,8 +701,7 @@ int gm_pg_prepare(gm_index* idx, int B, int expand, int len0, hipStream_t st) {
     for (int b = 0; b < B && rc == GM_OK; ++b) {
         const int nb = 1 << (2 * pg->blen[b]);
         if ((rc = ensure(&pg->raw_off, &pg->raw_off_cap, nb + 1, "bucket offsets"))) break;
-        if (hipMalloc(reinterpret_cast<void**>(&pg->goff[b]), sizeof(int32_t) * (size_t)(nb + 1)) != hipSuccess ||
-            hipMalloc(reinterpret_cast<void**>(&pg->gcnt[b]), sizeof(int32_t) * (size_t)(nb + 1)) != hipSuccess ||
+        if (hipMalloc(reinterpret_cast<void**>(&pg->bdesc[b]), sizeof(int2) * (size_t)(nb + 1)) != hipSuccess ||
             hipMalloc(reinterpret_cast<void**>(&pg->coff[b]), sizeof(int32_t) * (size_t)(nb + 1)) != hipSuccess) {
             rc = gm_fail(GM_ERR_ALLOC, "hipMalloc(K1P bucket tables) failed");
             break;
@@ -619,7 +711,8 @@ int gm_pg_prepare(gm_index* idx, int B, int expand, int len0, hipStream_t st) {
         if ((rc = sort_pairs(pg, n, 2 * pg->blen[b], st))) break;
         hipLaunchKernelGGL(k_bucket_offsets, grid_for(nb + 1), dim3(256), 0, st, pg->k1, n, nb, pg->raw_off);
         // bucket geometry on the host: every bucket starts on a multiple of GM_PG_ALIGN positions
-        std::vector<int32_t> off((size_t)nb + 1), goff((size_t)nb + 1), gcnt((size_t)nb + 1);
+        std::vector<int32_t> off((size_t)nb + 1);
+        std::vector<int2> bdesc((size_t)nb + 1);
         if (hipMemcpyAsync(off.data(), pg->raw_off, sizeof(int32_t) * off.size(), hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess) {
             rc = gm_fail(GM_ERR_DEVICE, "K1P bucket offsets read-back failed");
@@ -630,12 +723,10 @@ int gm_pg_prepare(gm_index* idx, int B, int expand, int len0, hipStream_t st) {
         for (int v = 0; v < nb; ++v) {
             const int cnt = off[v + 1] - off[v];
             mx = cnt > mx ? cnt : mx;
-            goff[v] = (int32_t)g;
-            gcnt[v] = (cnt + gm::LK_GROUP - 1) / gm::LK_GROUP;
+            bdesc[v] = make_int2((int)g, (cnt + gm::LK_GROUP - 1) / gm::LK_GROUP);
             g += (int64_t)((cnt + GM_PG_ALIGN - 1) / GM_PG_ALIGN) * GPA;
         }
-        goff[nb] = (int32_t)g;
-        gcnt[nb] = 0;
+        bdesc[nb] = make_int2((int)g, 0);
         pg->max_bucket[b] = mx;
         const int64_t n_groups = g > 0 ? g : GPA;
         if (n_groups * gm::LK_GROUP >= ((int64_t)1 << 31)) {
@@ -648,20 +739,18 @@ int gm_pg_prepare(gm_index* idx, int B, int expand, int len0, hipStream_t st) {
             rc = gm_fail(GM_ERR_ALLOC, "hipMalloc(K1P pool copy) failed");
             break;
         }
-        hipError_t e = hipMemcpyAsync(pg->goff[b], goff.data(), sizeof(int32_t) * goff.size(), hipMemcpyHostToDevice, st);
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(pg->gcnt[b], gcnt.data(), sizeof(int32_t) * gcnt.size(), hipMemcpyHostToDevice, st);
+        hipError_t e = hipMemcpyAsync(pg->bdesc[b], bdesc.data(), sizeof(int2) * bdesc.size(), hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = hipMemsetAsync(pg->recs[b], 0xff, sizeof(uint4) * (size_t)(n_groups * gm::LK_GROUP), st);
         if (e != hipSuccess) {
             rc = gm_fail(GM_ERR_DEVICE, std::string("K1P pool copy: ") + hipGetErrorString(e));
             break;
         }
-        hipLaunchKernelGGL(k_scatter_recs, grid_for(n), dim3(256), 0, st, idx->d_db, pg->k1, pg->r1, n, pg->raw_off, pg->goff[b],
+        hipLaunchKernelGGL(k_scatter_recs, grid_for(n), dim3(256), 0, st, idx->d_db, pg->k1, pg->r1, n, pg->raw_off, pg->bdesc[b],
                            pg->recs[b]);
         hipLaunchKernelGGL(k_onehot_recs, grid_for(words), dim3(256), 0, st, pg->recs[b], pg->table[b], n_groups, pg->Lp,
                            pg->bstart[b], pg->skip_len);
         if (hipGetLastError() != hipSuccess) rc = gm_fail(GM_ERR_DEVICE, "K1P pool-copy kernels failed to launch");
-        // (goff / gcnt host vectors are pageable: the copies above were staged by the runtime before returning)
+        // (the bdesc host vector is pageable: the copies above were staged by the runtime before returning)
         if (hipStreamSynchronize(st) != hipSuccess && rc == GM_OK) rc = gm_fail(GM_ERR_DEVICE, "K1P pool-copy build failed");
     }
     if (rc != GM_OK) {
@@ -672,18 +761,32 @@ int gm_pg_prepare(gm_index* idx, int B, int expand, int len0, hipStream_t st) {
     return GM_OK;
 }
 
-// workgroups per expansion chunk and target buckets per workgroup for the current layout
-static void pg_sub_split(const gm_pigeon* pg, int* n_sub, int* per) {
-    if (!pg->expand) {
-        *n_sub = 1;
-        *per = 1;
-        return;
+// per block: target buckets of a candidate bucket, the workgroups they are split over (about 16 / pg_sub = 8 buckets
+// per workgroup, at most 6 workgroups per chunk -- every workgroup means one more hit list per candidate), and the
+// hit-list numbering
+static void pg_geometry(gm_pigeon* pg) {
+    const int per_target = (16 + pg->tune_sub - 1) / pg->tune_sub;
+    int cap_sub = 6;
+    for (;;) {
+        int lists = 0;
+        pg->smax = 1;
+        for (int b = 0; b < pg->B; ++b) {
+            const int n_bk = gm_pg_buckets_of(pg->blen[b], pg->trad[b]);
+            int n_sub = (n_bk + per_target - 1) / per_target;
+            if (n_sub > cap_sub) n_sub = cap_sub;
+            const int per = (n_bk + n_sub - 1) / n_sub;
+            n_sub = (n_bk + per - 1) / per;      // every workgroup of a chunk has at least one target bucket
+            pg->nbk[b] = n_bk;
+            pg->per[b] = per;
+            pg->nsub[b] = n_sub;
+            pg->lbase[b] = lists;
+            lists += n_sub;
+            if (n_sub > pg->smax) pg->smax = n_sub;
+        }
+        pg->blocks.n_lists = lists;
+        if (lists <= GM_PG_MAXLISTS || cap_sub == 1) break;
+        --cap_sub;
     }
-    const int n_bk = 1 + 3 * pg->blen[0];
-    int S = pg->tune_sub;
-    while (S > 1 && pg->expand * S + (pg->B - pg->expand) > GM_PG_MAXLISTS) --S;
-    *per = (n_bk + S - 1) / S;
-    *n_sub = (n_bk + *per - 1) / *per;      // every workgroup of a chunk has at least one target bucket
 }
 
 // group the candidates in idx->d_q by every block's value and build the chunk table
@@ -699,8 +802,7 @@ int gm_pg_candidates(gm_index* idx, int64_t n_q, hipStream_t st) {
     A.B = pg->B;
     PgKeyArg K{};
     K.B = pg->B;
-    int n_sub = 1, per = 1;
-    pg_sub_split(pg, &n_sub, &per);
+    pg_geometry(pg);
     int64_t grid = 0;
     for (int b = 0; b <= pg->B; ++b) A.ebase[b] = K.ebase[b] = pg->ebase[b];
     for (int b = 0; b < pg->B; ++b) {
@@ -710,8 +812,13 @@ int gm_pg_candidates(gm_index* idx, int64_t n_q, hipStream_t st) {
         K.coff[b] = pg->coff[b];
         K.cperm[b] = pg->cperm[b];
         A.coff[b] = pg->coff[b];
-        A.gcnt[b] = pg->gcnt[b];
-        grid += ((n_q + 63) / 64 + (1 << (2 * pg->blen[b]))) * (b < pg->expand ? n_sub : 1);
+        A.bdesc[b] = pg->bdesc[b];
+        A.blen[b] = pg->blen[b];
+        A.nbk[b] = pg->nbk[b];
+        A.nsub[b] = pg->nsub[b];
+        A.per[b] = pg->per[b];
+        A.lbase[b] = pg->lbase[b];
+        grid += ((n_q + 63) / 64 + (1 << (2 * pg->blen[b]))) * pg->nsub[b];
     }
     // counting sort of the candidates by every block's value: histogram, per-block scan, scatter
     const int use_lds = n_entries <= 8192 ? 1 : 0;
@@ -722,10 +829,7 @@ int gm_pg_candidates(gm_index* idx, int64_t n_q, hipStream_t st) {
     hipLaunchKernelGGL(k_cand_scatter, grid_for(n_q, 1024), dim3(1024), lds, st, idx->d_q, n_q, K, pg->cursor, use_lds);
     HIP_TRY(hipGetLastError());
     // chunk table
-    A.X = pg->expand;
-    A.xne = pg->expand ? 3 * pg->blen[0] : 0;
-    A.S = n_sub;
-    A.per = per;
+    A.smax = pg->smax;
     A.skip_len = pg->skip_len;
     A.n_entries = n_entries;
     if ((rc = ensure(&pg->nch, &pg->nch_cap, A.n_entries, "chunk counts"))) return rc;
@@ -748,36 +852,34 @@ int gm_pg_candidates(gm_index* idx, int64_t n_q, hipStream_t st) {
                                         rocprim::plus<int>(), st));
         hipLaunchKernelGGL(k_chunk_total, dim3(1), dim3(64), 0, st, pg->nch, pg->cbase, A.n_entries, &pg->ctr->n_chunks);
     }
-    hipLaunchKernelGGL(k_fill_chunks, grid_for((int64_t)A.n_entries * A.S), dim3(256), 0, st, A, pg->cbase, pg->chunks, pg->ctr);
+    hipLaunchKernelGGL(k_fill_chunks, grid_for((int64_t)A.n_entries * A.smax), dim3(256), 0, st, A, pg->cbase, pg->chunks, pg->ctr);
     HIP_TRY(hipGetLastError());
     pg->grid = grid;
     return GM_OK;
 }
 
-// Words per candidate of every hit list (word 0 = count): mean + 4 sigma (+ 2) of the hits expected from the
+// Key capacity of every hit list: mean + 4 sigma (+ 2) of the hits expected from the
 // list's target buckets under the independent-base model with the pool's own composition, taking every bucket as
-// large as the LARGEST bucket of its copy; a multiple of 4 (the merge reads 16 bytes at a time), at least 8.  A
+// large as the LARGEST bucket of its copy; a multiple of 4 (the merge reads 16 bytes at a time), at least 4.  A
 // list that still overflows (repeat families) only makes its row incomplete: the row is re-scanned by the plain
 // kernel.  All lists together stay within a quarter of the free device memory (at least 2 GiB).
 static void pg_list_capacity(const gm_index* idx, gm_pigeon* pg, int64_t n_q) {
-    const int L = idx->L, r = pg->B + pg->expand - 1, X = pg->expand;
+    const int L = idx->L, r = gm_pg_radius(idx);
     const double pm = pg->p_match >= 0.25 ? pg->p_match : 0.25;
-    int n_sub = 1, per = 1;
-    pg_sub_split(pg, &n_sub, &per);
+    pg_geometry(pg);
     gm_pg_blocks& P = pg->blocks;
-    P.n_lists = X * n_sub + (pg->B - X);
     double mean[GM_PG_MAXLISTS];
     for (int b = 0; b < pg->B; ++b) {
-        const double own = (double)pg->max_bucket[b] * tail_within(L - pg->blen[b], r, pm) + 1.0;
-        const double nbr = (double)pg->max_bucket[b] * tail_within(L - pg->blen[b], r - 1, pm);
-        if (b >= X) {
-            mean[X * n_sub + (b - X)] = own;
-            continue;
-        }
-        const int n_bk = 1 + 3 * pg->blen[0];
-        for (int s = 0; s < n_sub; ++s) {
-            const int e_lo = s * per, e_hi = e_lo + per < n_bk ? e_lo + per : n_bk;
-            mean[b * n_sub + s] = (e_lo == 0 ? own : nbr) + (double)(e_hi - e_lo - 1) * nbr;
+        const int len = pg->blen[b];
+        // expected hits from an own / one-substitution / two-substitution bucket (the pair already has 0 / 1 / 2
+        // mismatches on the block)
+        double h[3];
+        for (int j = 0; j < 3; ++j) h[j] = (double)pg->max_bucket[b] * tail_within(L - len, r - j, pm);
+        for (int s = 0; s < pg->nsub[b]; ++s) {
+            const int e_lo = s * pg->per[b], e_hi = e_lo + pg->per[b] < pg->nbk[b] ? e_lo + pg->per[b] : pg->nbk[b];
+            double m = 0.0;
+            for (int e = e_lo; e < e_hi; ++e) m += e == 0 ? h[0] + 1.0 : (e <= 3 * len ? h[1] : h[2]);
+            mean[pg->lbase[b] + s] = m;
         }
     }
     if (pg->mem_limit == 0.0) {      // (cached: hipMemGetInfo is not free)
@@ -787,13 +889,14 @@ static void pg_list_capacity(const gm_index* idx, gm_pigeon* pg, int64_t n_q) {
             pg->mem_limit = (double)free_b / 4.0;
     }
     double scale = 1.0;
+    const int header = (P.n_lists + 3) / 4 * 4;      // the counts of all lists, then the keys
     for (;;) {
-        int64_t words = 0;
+        int64_t words = header;
         for (int l = 0; l < P.n_lists; ++l) {
-            double c = std::ceil(scale * (mean[l] + 4.0 * std::sqrt(mean[l]) + 2.0)) + 1.0;
+            double c = std::ceil(scale * (mean[l] + 4.0 * std::sqrt(mean[l]) + 2.0));
             if (c > 4096.0) c = 4096.0;
             int cap = ((int)c + 3) / 4 * 4;
-            if (cap < 8) cap = 8;
+            if (cap < 4) cap = 4;
             P.lcap[l] = cap;
             P.loff[l] = (int)words;
             words += cap;
@@ -809,30 +912,27 @@ int64_t gm_pg_list_words(const gm_pigeon* pg) { return pg->blocks.row_words; }
 int gm_pg_scan(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
     gm_pigeon* pg = idx->pg;
     int rc;
-    if (pg->cap_nq != n_q || pg->cap_x_for != pg->expand || pg->cap_sub_for != pg->tune_sub) {
+    uint64_t lkey = 0;      // the radii of the layout in use (the block lengths are fixed while the copies live)
+    for (int b = 0; b < pg->B; ++b) lkey = lkey * 4 + (uint64_t)pg->trad[b] + 1;
+    if (pg->cap_nq != n_q || pg->cap_layout_for != lkey || pg->cap_sub_for != pg->tune_sub) {
         pg_list_capacity(idx, pg, n_q);
         pg->cap_nq = n_q;
-        pg->cap_x_for = pg->expand;
+        pg->cap_layout_for = lkey;
         pg->cap_sub_for = pg->tune_sub;
     }
     if ((rc = ensure(&pg->lists, &pg->lists_cap, gm_pg_list_words(pg) * n_q, "K1P hit lists"))) return rc;
     gm_pg_blocks& blocks = pg->blocks;
-    int n_sub = 1, per = 1;
-    pg_sub_split(pg, &n_sub, &per);
     for (int b = 0; b < pg->B; ++b) {
+        blocks.blen[b] = pg->blen[b];
         blocks.table[b] = pg->table[b];
         blocks.recs[b] = pg->recs[b];
-        blocks.goff[b] = pg->goff[b];
-        blocks.gcnt[b] = pg->gcnt[b];
+        blocks.bdesc[b] = pg->bdesc[b];
         blocks.cperm[b] = pg->cperm[b];
         blocks.skip[b] = pg->bstart[b];
     }
     blocks.skip_len = pg->skip_len;
     blocks.n_blocks = pg->B;
-    blocks.n_expand = pg->expand;
-    blocks.xlen = pg->expand ? pg->blen[0] : 0;
-    blocks.n_sub = n_sub;
-    const int thr0 = pg->B + pg->expand;      // accept d < thr0, i.e. d <= r = B + X - 1
+    const int thr0 = gm_pg_radius(idx) + 1;      // accept d < thr0, i.e. d <= r
     blocks.run = pg->tune_run;
     blocks.debug = pg->tune_debug;
     const int64_t unit = 8 * (int64_t)blocks.run;      // the kernel's entry mapping permutes whole units

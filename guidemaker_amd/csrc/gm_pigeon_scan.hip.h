@@ -3,8 +3,9 @@
 //
 // The guide is cut into B blocks of positions.  Two sequences with at most r mismatches agree exactly on at least
 // one of r + 1 disjoint blocks, so for block b it is enough to compare a candidate with the pool targets that carry
-// the same bases on block b (its bucket); with the one-substitution neighbour buckets of X of the blocks scanned
-// as well, B blocks serve r = B + X - 1 (gm_pigeon.hip, gm_pg_plan).  The pool is stored B times, stable-sorted by
+// the same bases on block b (its bucket); with the one- (two-) substitution neighbour buckets of a block scanned as
+// well, the block covers every pair with up to one (two) mismatches on it, and B blocks with such radii t_b serve
+// r = sum(t_b + 1) - 1 (gm_pg_types.h gm_pg_layout; gm_pigeon.hip gm_pg_plan).  The pool is stored B times, stable-sorted by
 // the block's value (ids ascend inside a bucket), every bucket padded to whole LDS-DMA units, with one one-hot
 // table per copy; candidates are grouped by the same value into chunks of <= 64 that never straddle a bucket.
 //
@@ -21,8 +22,8 @@
 //     hit bits (almost always one), gathers the 16-byte record of the target {planes, pool id} from the sorted
 //     copy, recomputes the distance with one xor / or / popcount, takes a slot in the candidate's hit list from a
 //     counter in LDS and stores (distance << 27 | pool id) to the list in HBM.  A list has one writer (this
-//     workgroup) and all lists of a candidate are contiguous (word 0 of each = count), so the 4-byte stores of a
-//     list combine in the L2 of the workgroup's XCD and the merge reads one contiguous run per candidate.
+//     workgroup); a candidate's row of the hit buffer holds the counts of all its lists first, then their keys, so the
+//     merge reads one header and only the key runs that are not empty.
 // Bound tightening needs no sorted list: per candidate the flush counts the hits closer than r and closer than
 // r - 1; once k of them are known nothing at distance r (r - 1) can enter the top k.  k = 1 follows the best distance.
 // k_merge_hits folds the lists of a candidate (duplicates -- pairs that share several blocks -- taken once) into
@@ -43,16 +44,33 @@ __host__ __device__ constexpr size_t pg_lds_bytes(int L) {
     return sizeof(uint32_t) * (size_t)(2 * pg_pair_words(L) + PG_QCAP * 3 + WAVE * 2 + WAVE * 4);
 }
 
-// target bucket e of the chunk's run: 0 = the candidates' own bucket v; 1 + 3 p + a = v with the base at block
-// position p replaced by the a-th of the three other bases.  add = 1 when that position is one the copy's table
-// leaves out (the scan cannot see the mismatch; the comparator bound accounts for it).
-__device__ __forceinline__ int pg_target_bucket(int v, int e, int skip_len, int& add) {
+// target bucket e of a candidate bucket v of a block of `len` bases: 0 = v itself; 1 + 3 p + a = v with the base at
+// block position p replaced by the a-th of the three other bases; beyond 3 len: the two-substitution neighbours,
+// 1 + 3 len + 9 pair + 3 a1 + a2 with pair = rank of (p1 < p2).  add = number of substituted positions the copy's
+// table leaves out (the scan cannot see those mismatches; the comparator bound accounts for them).
+__host__ __device__ __forceinline__ int pg_subst(int v, int pidx, int alt) {
+    const int code = (v >> (2 * pidx)) & 3;
+    return (v & ~(3 << (2 * pidx))) | (((code + 1 + alt) & 3) << (2 * pidx));
+}
+__host__ __device__ __forceinline__ int pg_target_bucket(int v, int e, int len, int skip_len, int& add) {
     add = 0;
     if (e == 0) return v;
-    const int ne = e - 1, pidx = ne / 3, alt = ne % 3;
-    const int code = (v >> (2 * pidx)) & 3;
-    add = pidx < skip_len ? 1 : 0;
-    return (v & ~(3 << (2 * pidx))) | (((code + 1 + alt) & 3) << (2 * pidx));
+    if (e <= 3 * len) {
+        const int ne = e - 1, pidx = ne / 3;
+        add = pidx < skip_len ? 1 : 0;
+        return pg_subst(v, pidx, ne % 3);
+    }
+    const int e2 = e - 1 - 3 * len;
+    int pi = e2 / 9;
+    const int a1 = (e2 % 9) / 3, a2 = e2 % 3;
+    int p1 = 0;
+    while (pi >= len - 1 - p1) {      // unrank the pair (p1 < p2)
+        pi -= len - 1 - p1;
+        ++p1;
+    }
+    const int p2 = p1 + 1 + pi;
+    add = (p1 < skip_len ? 1 : 0) + (p2 < skip_len ? 1 : 0);
+    return pg_subst(pg_subst(v, p1, a1), p2, a2);
 }
 
 // walks the 2-group DMA units ("pairs") of the non-empty target buckets of a chunk, in order
@@ -66,9 +84,10 @@ __device__ __forceinline__ bool pg_next(const gm_pg_blocks& P, const gm_pg_chunk
     } else {
         do {
             if (++it.e >= ch.e_hi) return false;
-            const int vt = pg_target_bucket(ch.v, it.e, P.skip_len, it.add);
-            it.gc = P.gcnt[ch.b][vt];
-            it.g0 = P.goff[ch.b][vt];
+            const int vt = pg_target_bucket(ch.v, it.e, P.blen[ch.b], P.skip_len, it.add);
+            const int2 d = P.bdesc[ch.b][vt];      // one scalar 8-byte load
+            it.g0 = d.x;
+            it.gc = d.y;
         } while (it.gc <= 0);
         it.pi = 0;
     }
@@ -130,7 +149,7 @@ __device__ __forceinline__ void pg_flush(PgQueue& Q, int n, int lane, const uint
             if (d < thr0 - 1) atomicAdd(&Q.c1[cl], 1);
             if (d < thr0 - 2) atomicAdd(&Q.c2[cl], 1);
         }
-        const int slot = atomicAdd(&Q.cnt[cl], 1) + 1;      // word 0 of a list is its count
+        const int slot = atomicAdd(&Q.cnt[cl], 1);
         if (slot < lcap && !(debug & 1)) lists[row * row_words + slot] = ((uint32_t)d << ID_BITS) | t.z;
     }
     __syncthreads();      // single-wave workgroup: orders the LDS atomics before the reads of the counters below
@@ -213,7 +232,7 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
         ptr[p] = tiles + p * 8 + (int)code * 2;
     }
     const int lcap = P.lcap[ch.lst], row_words = P.row_words;
-    uint32_t* __restrict__ mylists = lists + P.loff[ch.lst];     // list of candidate row: mylists + row * row_words
+    uint32_t* __restrict__ mylists = lists + P.loff[ch.lst];     // keys of candidate row: mylists + row * row_words
     int thr = valid ? thr0 : 0;                                 // accept d < thr
     uint32_t Tb[5];
 
@@ -264,7 +283,7 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
         const int n_take = Q.tail - Q.head < WAVE ? Q.tail - Q.head : WAVE;
         pg_flush(Q, n_take, lane, recs, mylists, lcap, row_words, k, thr0, P.debug);
     }
-    if (valid) mylists[qi * row_words] = (uint32_t)Q.cnt[lane];      // every (list, candidate) pair has exactly one writer
+    if (valid) lists[qi * row_words + ch.lst] = (uint32_t)Q.cnt[lane];      // every (list, candidate) pair has exactly one writer
 }
 
 // K1P merge: PG_MERGE_SPLIT adjacent lanes per candidate, each folding every PG_MERGE_SPLIT-th hit list into its
@@ -283,24 +302,21 @@ __global__ void k_merge_hits(gm_pg_blocks P, const uint32_t* __restrict__ lists,
     RegList<KCAP> list;
     list.init(k, nullptr, 0);
     int overflow = 0;
+    const uint32_t* __restrict__ row = lists + qi * P.row_words;      // [counts][keys of list 0][keys of list 1] ...
     for (int l = sub; l < P.n_lists; l += PG_MERGE_SPLIT) {
         const int lcap = P.lcap[l];                    // multiple of 4
-        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(lists + qi * P.row_words + P.loff[l]);
-        uint4 w = src[0];
-        int c = (int)w.x;
-        if (c > lcap - 1) {
+        int c = (int)row[l];
+        if (c > lcap) {
             overflow = 1;
-            c = lcap - 1;
+            c = lcap;
         }
-        // keys sit in words 1 .. c
-        for (int base = 0; base <= c; base += 4) {
-            if (base) w = src[base >> 2];
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(row + P.loff[l]);
+        for (int base = 0; base < c; base += 4) {      // an empty list costs no key read
+            const uint4 w = src[base >> 2];
             const uint32_t kk[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int i = base + j;
-                if (i >= 1 && i <= c && kk[j] + 1u < list.v[KCAP - 1]) list.insert_unique(kk[j]);
-            }
+            for (int j = 0; j < 4; ++j)
+                if (base + j < c && kk[j] + 1u < list.v[KCAP - 1]) list.insert_unique(kk[j]);
         }
     }
 #pragma unroll

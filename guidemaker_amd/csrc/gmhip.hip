@@ -167,7 +167,12 @@ int run_hamming_lookup(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
     if (n_seg > n_tiles / 2) n_seg = n_tiles / 2;
     // the merge is one thread per candidate walking n_seg lists: with few candidates it is the serial part,
     // so long lists get fewer segments (5 000 candidates, k = 10: 512 segments merged in 1.2 ms, 64 in 0.1 ms)
-    const int64_t seg_cap = a.kcap == 1 ? 512 : (a.kcap == 5 ? 128 : 64);      // (lists x keys the merge walks)
+    int64_t seg_cap = a.kcap == 1 ? 512 : (a.kcap == 5 ? 128 : 64);      // (lists x keys the merge walks)
+    // a handful of candidates (K1P's re-scan on large pools: tens of rows): the scan itself is the serial part, so
+    // cut the pool finer -- enough (chunk, segment) workgroups for one per wave slot; the 16-lanes-per-candidate merge
+    // walks them in a few microseconds
+    const int64_t fill = (int64_t)idx->n_simd * 8 / (chunks > 0 ? chunks : 1);
+    if (fill > seg_cap) seg_cap = fill < 512 ? fill : 512;
     if (n_seg > seg_cap) n_seg = seg_cap;
     if (idx->variant >= 50 && idx->variant < 100) n_seg = idx->variant - 50;     // A/B knob: force the segment count
     int rc;
@@ -272,33 +277,31 @@ int run_hamming_pigeon(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
     if (keff > 20 || idx->n_db < keff || n_q < 1) return GM_OK;
     // variants 100 + B force the plain layout of B blocks; 200 + B one expansion block (even lengths), 300 + B
     // the same with the expansion block one base longer, 400 + B / 500 + B two / three expansion blocks one
-    // base longer than the even split, 600 + B / 700 + B two / three expansion blocks of even length (tests,
-    // A/B); the result is exact for any layout
+    // base longer than the even split, 600 + B / 700 + B two / three expansion blocks of even length; 800 + B:
+    // block 0 with the two-substitution neighbourhood, the others plain; 900 + B: block 0 two-substitution, block 1
+    // one-substitution (tests, A/B); the result is exact for any layout
     const int vcode = idx->variant / 100;
-    const bool forced = vcode >= 1 && vcode <= 7 && idx->variant % 100 >= 2 && idx->variant % 100 <= GM_PG_MAXB;
+    const bool forced = vcode >= 1 && vcode <= 9 && idx->variant % 100 >= 2 && idx->variant % 100 <= GM_PG_MAXB;
     int rc;
     double p_match = 0.25;
     if (idx->n_db >= 32768 || forced) {
         if ((rc = gm_pg_pool_stats(idx, st, &p_match))) return rc;
     }
-    // enough candidates per bucket to fill the 64-lane chunks: at least 160 x 4^(longest block)
-    // (measured break-even on a 600k pool: ~10k candidates for 3-base blocks)
-    int len_ok = 0;
-    while (len_ok < GM_PG_MAXLEN && n_q >= ((int64_t)160 << (2 * (len_ok + 1)))) ++len_ok;
-    int expand = 0, len0 = 0;
-    int B = 0;
+    gm_pg_layout lay{};
     if (forced) {
-        B = idx->variant % 100;
-        expand = vcode == 1 ? 0 : (vcode <= 3 ? 1 : (vcode <= 5 ? vcode - 2 : vcode - 4));
-        len0 = (idx->L + B - 1) / B + (vcode >= 3 && vcode <= 5 ? 1 : 0);
+        const int B = idx->variant % 100;
+        int expand = vcode == 1 ? 0 : (vcode <= 3 ? 1 : (vcode <= 5 ? vcode - 2 : (vcode <= 7 ? vcode - 4 : vcode - 7)));
+        const int len0 = (idx->L + B - 1) / B + (vcode >= 3 && vcode <= 5 ? 1 : 0);
         if (expand >= B || len0 > GM_PG_MAXLEN) return GM_OK;      // not a usable layout: plain scan
         if (expand > 0 && idx->L - expand * len0 < 2 * (B - expand)) return GM_OK;
         if (idx->L / B < 2 && expand == 0) return GM_OK;
-    } else {
-        B = gm_pg_plan(idx->n_db, n_q, idx->L, keff, p_match, len_ok, &expand, &len0);
+        if (!gm_pg_layout_make(idx->L, B, expand, len0, vcode >= 8 ? 1 : 0, &lay)) return GM_OK;
+    } else if (gm_pg_layout_forced(idx, &lay)) {
+        // (gm_set_param "pg_layout": experiments)
+    } else if (!gm_pg_plan(idx->n_db, n_q, idx->L, keff, p_match, &lay)) {
+        return GM_OK;
     }
-    if (B == 0) return GM_OK;
-    if ((rc = gm_pg_prepare(idx, B, expand, len0, st))) {
+    if ((rc = gm_pg_prepare(idx, &lay, st))) {
         if (forced && rc == GM_ERR_ARG) return GM_OK;      // forced layout not usable for this length
         return rc;
     }
@@ -338,7 +341,7 @@ int run_hamming_pigeon(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
 
 // variant 0 = default (K1L look-up kernel), 1 = popcount kernel K1, 5 and 2x/3x = K1v knobs
 bool use_lookup(const gm_index* idx) {
-    return idx->metric == GM_METRIC_HAMMING && idx->d_onehot != nullptr && (idx->variant == 0 || idx->variant == 7 || idx->variant == 8 || idx->variant == 9 || (idx->variant >= 40 && idx->variant < 100) || (idx->variant >= 102 && idx->variant < 800 && idx->variant % 100 >= 2 && idx->variant % 100 <= GM_PG_MAXB));
+    return idx->metric == GM_METRIC_HAMMING && idx->d_onehot != nullptr && (idx->variant == 0 || idx->variant == 7 || idx->variant == 8 || idx->variant == 9 || (idx->variant >= 40 && idx->variant < 100) || (idx->variant >= 102 && idx->variant < 1000 && idx->variant % 100 >= 2 && idx->variant % 100 <= GM_PG_MAXB));
 }
 
 bool use_bitslice(const gm_index* idx) {
@@ -868,11 +871,21 @@ int64_t gm_last_kernel_evaluated(gm_index* idx) { return idx ? idx->last_evaluat
 int64_t gm_last_incomplete(gm_index* idx) { return idx ? idx->last_incomplete : 0; }
 int gm_pigeon_blocks(gm_index* idx) { return idx ? gm_pg_blocks_of(idx) : 0; }
 int gm_pigeon_plan(int64_t n_db, int guidelen, int k, double p_match) {
-    int expand = 0;
-    int len0 = 0;
-    const int B = gm_pg_plan(n_db, n_db, guidelen, k, p_match, GM_PG_MAXLEN, &expand, &len0);
-    if (!B) return 0;
-    return B + 100 * expand + (expand && len0 != (guidelen + B - 1) / B ? 1000 * len0 : 0);
+    gm_pg_layout lay{};
+    if (!gm_pg_plan(n_db, n_db, guidelen, k, p_match, &lay)) return 0;
+    // B + 100 n1 + 1000 len1 (only when the radius-1 blocks are not of the even-split length) + 10000 n2 + 100000 len2
+    int n1 = 0, n2 = 0, len1 = 0, len2 = 0;
+    for (int b = 0; b < lay.B; ++b) {
+        if (lay.trad[b] == 2) {
+            ++n2;
+            len2 = lay.blen[b];
+        } else if (lay.trad[b] == 1) {
+            ++n1;
+            len1 = lay.blen[b] > len1 ? lay.blen[b] : len1;
+        }
+    }
+    const int even = (guidelen + lay.B - 1) / lay.B;
+    return lay.B + 100 * n1 + (n1 && len1 != even ? 1000 * len1 : 0) + 10000 * n2 + 100000 * len2;
 }
 
 }  // extern "C"

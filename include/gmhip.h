@@ -163,11 +163,13 @@ int64_t gm_last_kernel_evaluated(gm_index* idx);
 int64_t gm_last_incomplete(gm_index* idx);
 /* Number of blocks B of the K1P layout currently built for this handle (0: none built yet). */
 int gm_pigeon_blocks(gm_index* idx);
-/* The layout planner on its own (host arithmetic only, no device needed): number of blocks B K1P would use for
- * a pool of n_db targets of this length, k neighbours and base-match probability p_match (sum of squared base
- * frequencies; 0.25 = uniform), assuming as many candidates as targets; + 100 * X when X blocks get the
- * neighbour-bucket expansion (B blocks then serve radius B + X - 1); + 1000 * len when those blocks are longer
- * than the even split (len bases each); 0 when the plain scan is the better choice. */
+/* The layout planner on its own (host arithmetic only, no device needed): the layout K1P would use for a pool of n_db
+ * targets of this length, k neighbours and base-match probability p_match (sum of squared base frequencies;
+ * 0.25 = uniform), assuming as many candidates as targets, encoded as
+ *   B + 100 n1 + 1000 len1 + 10000 n2 + 100000 len2
+ * B = blocks; n1 = blocks whose one-substitution neighbour buckets are scanned too; len1 = their length, given only
+ * when it differs from the even split ceil(guidelen / B); n2 = blocks with the two-substitution neighbourhood, len2 =
+ * their length.  The layout serves radius 3 n2 + 2 n1 + (B - n1 - n2) - 1.  0 when the plain scan is the better choice. */
 int gm_pigeon_plan(int64_t n_db, int guidelen, int k, double p_match);
 
 /* Per-launch timing history: gm_timing_reserve(idx, n) arms n HIP-event pairs (and resets the
@@ -183,13 +185,17 @@ int gm_timing_read(gm_index* idx, double* ms_out, int max_n);
  *                K1v (L = 20 only); 40..49 = K1L with the resident waves capped; 50..99 = K1L with
  *                (variant - 50) pool segments; 100 + B = K1P with B blocks, no expansion; 200 + B / 300 + B one
  *                expansion block (even length / one base longer); 400 + B / 500 + B two / three longer expansion
- *                blocks; 600 + B / 700 + B two / three expansion blocks of even length.
+ *                blocks; 600 + B / 700 + B two / three expansion blocks of even length; 800 + B block 0 with the
+ *                two-substitution neighbourhood; 900 + B the same plus block 1 with the one-substitution one.
  *   Levenshtein: 2 = per-pair Myers kernel K2L; 1 = plane-based kernel (also used for L < 10 and k > 20). */
 int gm_set_variant(gm_index* idx, int variant);
 /* Named tuning knobs (experiments; results are identical for every value).
  *   "pg_sub" (1..19, default 2): workgroups the target buckets of one expansion chunk of the pigeonhole-partitioned
  *   scan are split over (more = shorter work items and more hit lists per candidate);
- *   "pg_run" (default 128): consecutive chunk-table entries of that scan executed on the same XCD. */
+ *   "pg_run" (default 128): consecutive chunk-table entries of that scan executed on the same XCD;
+ *   "pg_layout": force a layout of that scan, decimal digit pairs (bases, radius) per block, e.g. 826161 = blocks of
+ *   8, 6, 6 bases with the two-, one-, one-substitution neighbourhoods (0 = let the planner choose);
+ *   "pg_debug": timing experiments only (bit 0: the scan skips its list stores -- results are then WRONG). */
 int gm_set_param(gm_index* idx, const char* name, int value);
 
 #ifdef __cplusplus

@@ -43,7 +43,7 @@ def run(seconds, seed, max_cases=None):
         variant = 0
         if metric == "hamming":
             B = rng.randint(2, 8)
-            variant = rng.choice([0, 8, 100 + B, 200 + B, 300 + B, 400 + B, 600 + B, 700 + B])
+            variant = rng.choice([0, 8, 100 + B, 200 + B, 300 + B, 400 + B, 600 + B, 700 + B, 800 + B, 900 + B])
         idx = _lib.Index(_lib.pack(db, L), L, _lib.METRIC_HAMMING if metric == "hamming" else _lib.METRIC_LEVEN)
         idx.set_variant(variant)
         qp = _lib.pack(q, L)

@@ -373,7 +373,8 @@ def test_kernel_variants_agree(oracle):
     (12, 204), (16, 208), (20, 204), (20, 206), (23, 205), (27, 208),      # one expansion block, even lengths
     (12, 304), (16, 306), (20, 306), (23, 305), (27, 308),                 # ... one base longer
     (16, 406), (20, 405), (23, 405), (20, 504), (27, 507),                 # two / three longer expansion blocks
-    (20, 605), (20, 704), (24, 706)])                                      # two / three, even lengths
+    (20, 605), (20, 704), (24, 706),                                       # two / three, even lengths
+    (16, 803), (20, 803), (20, 904), (23, 803), (27, 904), (24, 903)])     # a block with the two-substitution neighbourhood
 def test_pigeonhole_layouts_match_oracle(oracle, L, variant):
     """K1P, the pigeonhole-partitioned scan, with a forced layout (gm_set_variant codes of
     run_hamming_pigeon: 100 + B plain, 200..700 + B with one to three expansion blocks).  It must be exact

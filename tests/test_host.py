@@ -163,13 +163,23 @@ def test_neighbor_map_schema_and_duplicates():
 
 
 def test_pigeonhole_planner_choices():
-    """gm_pigeon_plan is host arithmetic: runs without a GPU.  Layouts for the BASELINE shapes (B + 100 X: B
-    blocks, X of them with the neighbour-bucket expansion; + 1000 len: those blocks longer than the even split),
-    and the cases where the plain scan must stay in charge."""
+    """gm_pigeon_plan is host arithmetic: runs without a GPU.  Layouts for the BASELINE shapes, encoded as
+    B + 100 n1 + 1000 len1 + 10000 n2 + 100000 len2 (include/gmhip.h), and the cases where the plain scan must stay
+    in charge."""
     from guidemaker_amd import _lib
-    assert _lib.pigeon_plan(599_093, 20, 10) == 304         # S1: blocks 5,5,5,5, neighbour buckets of three of them
-    assert _lib.pigeon_plan(3_124_711, 20, 20) == 304       # S4
-    assert _lib.pigeon_plan(891_135, 20, 5, 0.2637) == 304  # S3 (gc 0.383)
+
+    def decode(code):
+        return dict(B=code % 100, n1=code % 1000 // 100, len1=code % 10000 // 1000, n2=code % 100000 // 10000,
+                    len2=code // 100000)
+
+    def radius(code):
+        d = decode(code)
+        return 3 * d["n2"] + 2 * d["n1"] + (d["B"] - d["n1"] - d["n2"]) - 1
+
+    assert _lib.pigeon_plan(599_093, 20, 10) == 304          # S1: blocks 5,5,5,5, neighbour buckets of three of them
+    s4 = decode(_lib.pigeon_plan(3_124_711, 20, 20))         # S4: one block with the two-substitution neighbourhood
+    assert (s4["B"], s4["n1"], s4["n2"], s4["len2"]) == (3, 2, 1, 8) and radius(_lib.pigeon_plan(3_124_711, 20, 20)) == 6
+    assert radius(_lib.pigeon_plan(891_135, 20, 5, 0.2637)) == 6     # S3 (gc 0.383)
     assert _lib.pigeon_plan(3_814, 20, 10) == 0            # Carsonella-sized pool: plain scan
     assert _lib.pigeon_plan(600_000, 20, 21) == 0          # lists beyond the register capacity
     assert _lib.pigeon_plan(600_000, 11, 10) == 0          # too short
@@ -177,11 +187,10 @@ def test_pigeonhole_planner_choices():
         for L in range(12, 28):
             for k in (1, 2, 10, 20):
                 code = _lib.pigeon_plan(n, L, k)
-                B, X, lenx = code % 100, code % 1000 // 100, code // 1000
-                assert code == 0 or (2 <= B <= 8 and X < B and X <= 3 and lenx <= 6), (n, L, k, code)
-    # a larger pool never needs a wider radius (radius = B - 1 plain, B with the expansion)
-    def radius(code):
-        return code % 100 + code % 1000 // 100 - 1
+                d = decode(code)
+                assert code == 0 or (2 <= d["B"] <= 8 and d["n1"] + d["n2"] <= d["B"] and d["n1"] <= 3 and d["n2"] <= 1
+                                     and d["len1"] <= 8 and d["len2"] <= 8), (n, L, k, code)
+    # a larger pool never needs a wider radius
     assert radius(_lib.pigeon_plan(20_000_000, 20, 10)) <= radius(_lib.pigeon_plan(600_000, 20, 10))
 
 
