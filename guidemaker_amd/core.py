@@ -331,7 +331,7 @@ class TargetProcessor:
     """A set of guide RNA targets and its MI355X-resident neighbour index."""
 
     def __init__(self, targets: pd.DataFrame, lsr: int, editdist: int = 2, knum: int = 2,
-                 device: int = 0, shard_candidates: bool = None) -> None:
+                 device: int = None, shard_candidates: bool = None) -> None:
         self.targets = targets
         self.lsr: int = lsr
         self.editdist: int = editdist
@@ -343,7 +343,8 @@ class TargetProcessor:
         self.gc_percent: float = None
         self.genomesize: float = None
         self.pam_orientation: bool = targets['pam_orientation'].iat[0]
-        self.device = device
+        self._device_arg, self._shard_arg = device, shard_candidates
+        self.device = 0 if device is None else device
         # multi-GPU: one process per GPU, every process holds the SAME targets frame; opt in with
         # shard_candidates=True (or GM_SHARD_CANDIDATES=1) -- an initialised process group alone does not switch it
         # on, because ranks that work on different genomes must not enter a collective together
@@ -470,6 +471,13 @@ class TargetProcessor:
             config = yaml.safe_load(cf)
         # read for interface compatibility; an exact scan has no M / efC / post
         _ = config['NMSLIB']['M'], config['NMSLIB']['efc'], config['NMSLIB']['post']
+        # optional GPU block (absent from the reference's config files): device ordinal / sharding, unless the
+        # constructor already said
+        gpu_cfg = config.get('GPU') or {}
+        if self._device_arg is None and 'DEVICE' in gpu_cfg:
+            self.device = int(gpu_cfg['DEVICE'])
+        if self._shard_arg is None and 'SHARD_CANDIDATES' in gpu_cfg and "GM_SHARD_CANDIDATES" not in os.environ:
+            self.shard_candidates = bool(gpu_cfg['SHARD_CANDIDATES'])
         pk = self._packed_targets()
         if pk is not None:
             # de-duplicate on the packed words: first-occurrence order (the reference's list(set(...)) order is

@@ -714,3 +714,38 @@ def test_multi_device_entry_matches_single_device(oracle):
         _lib.MultiIndex(_lib.pack(db, L), L, _lib.METRIC_HAMMING, [0, 0])      # duplicate ordinal
     with pytest.raises(_lib.GmHipError):
         _lib.MultiIndex(_lib.pack(db, L), L, _lib.METRIC_HAMMING, [99])        # no such device
+
+
+# ------------------------------------------------------------------ every guide length, both metrics
+@pytest.mark.parametrize("L", list(range(10, 28)))
+def test_every_guide_length_matches_oracle(oracle, L):
+    """Myers/Hyyro bit-sliced DP == textbook DP and bit-sliced Hamming == popcount of XOR over the one-hot words, for
+    every guide length the CLI accepts (10..27): seeded bounds put most waves on the banded / narrow-band paths, the
+    unseeded rows (k larger than the neighbours in reach) on the full-matrix path."""
+    db = list(dict.fromkeys(random_pool(2500 + 13 * L, L, seed=500 + L, planted=0.05, indel=True)))
+    q = db[::5] + random_pool(150, L, seed=600 + L, indel=True)
+    for metric in ("leven", "hamming"):
+        for k in (3, 12):
+            ids, dists, counts = _gpu_knn(db, q, L, metric, k)
+            oi, od, oc = _oracle_true_units(oracle, db, q, L, metric, k)
+            assert (counts == oc).all() and (dists == od).all() and (ids == oi).all(), (L, metric, k)
+
+
+def test_pack_unpack_roundtrip_and_one_hot_equivalence(oracle):
+    """gm_pack / gm_unpack round trip for every length, and Hamming on the 2-bit packing == nmslib's bit_hamming on
+    the reference's one-hot strings / 2 (core.py:379-386, :510-514)."""
+    rng = random.Random(5)
+    for L in (1, 2, 9, 10, 20, 27):
+        seqs = ["".join(rng.choice("ACGT") for _ in range(L)) for _ in range(257)]
+        packed = _lib.pack(seqs, L)
+        assert _lib.unpack(packed, L) == seqs
+        assert int(packed.max()) < (1 << (2 * L))
+    L = 20
+    seqs = ["".join(rng.choice("ACGT") for _ in range(L)) for _ in range(40)]
+    onehot = oracle.one_hot_encode(seqs)
+    idx = _lib.Index(_lib.pack(seqs, L), L, _lib.METRIC_HAMMING)
+    ids, dists, counts = idx.knn(_lib.pack(seqs, L), len(seqs))
+    idx.close()
+    for i in range(len(seqs)):
+        for j, d in zip(ids[i].tolist(), dists[i].tolist()):
+            assert 2 * d == oracle.py_bit_hamming(onehot[i], onehot[j])
