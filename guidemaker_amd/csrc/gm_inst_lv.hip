@@ -25,7 +25,11 @@ int launch_lvb_cfg(gm_index* idx, int64_t n_q, int k, int n_seg, int tiles_per_s
                    const int32_t* seed_c, int seed_k, uint32_t* keys, hipStream_t st) {
     const int64_t chunks = (n_q + gm::WAVE - 1) / gm::WAVE;
     const size_t lds = 2 * (size_t)gm::lk_tile_bytes(L);
-    hipLaunchKernelGGL((gm::k_leven_knn_bs<L, KCAP>), dim3((unsigned)chunks, (unsigned)n_seg), dim3(gm::WAVE), lds, st,
+    // band-only workgroups first (the bulk once the bounds are seeded), then the workgroups that need the full matrix
+    hipLaunchKernelGGL((gm::k_leven_knn_bs<L, KCAP, false>), dim3((unsigned)chunks, (unsigned)n_seg), dim3(gm::WAVE), lds, st,
+                       idx->d_onehot, (int)idx->n_db, (int)idx->n_lk_tiles, tiles_per_seg, idx->d_q, n_q, k, seed_d,
+                       seed_c, seed_k, keys);
+    hipLaunchKernelGGL((gm::k_leven_knn_bs<L, KCAP, true>), dim3((unsigned)chunks, (unsigned)n_seg), dim3(gm::WAVE), lds, st,
                        idx->d_onehot, (int)idx->n_db, (int)idx->n_lk_tiles, tiles_per_seg, idx->d_q, n_q, k, seed_d,
                        seed_c, seed_k, keys);
     HIP_TRY(hipGetLastError());

@@ -19,7 +19,10 @@
 // Same tiles (LDS-DMA, double buffered), Hamming-seeded bounds, chunks x segments grid and merge as K2L.
 #pragma once
 #ifndef GM_LVB_WAVES
-#define GM_LVB_WAVES 3     /* waves per SIMD asked of the allocator for k_leven_knn_bs (the full-matrix path needs ~150 VGPRs) */
+#define GM_LVB_WAVES 3     /* waves per SIMD asked of the allocator for the full-matrix kernel (~150 VGPRs) */
+#endif
+#ifndef GM_LVB_BAND_WAVES
+#define GM_LVB_BAND_WAVES 4     /* ... and for the band-only kernel (~110 VGPRs with both halves of a group in flight) */
 #endif
 #include "gm_leven.hip.h"
 
@@ -186,11 +189,136 @@ __device__ __forceinline__ void lvb_eval_half_banded(const uint32_t (&adr)[L], u
     asm volatile("" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]));
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Both halves of a group at once (band-only kernel).  The table keeps the two halves of a (column, base) entry side
+// by side, so ONE ds_read_b64 per row and column fetches the Eq words of 64 targets: half the LDS instructions of
+// the per-half evaluation, and two independent delta chains for the VALU to interleave.  The diagonal words are not
+// kept for a tree at the end (2 L registers for two halves) but fed into a streaming carry-save counter as they
+// appear: at most two pending words per weight, a full adder whenever a third arrives.  The counter's fill levels
+// are template parameters (the column index is one), so every word has a fixed register.
+// ---------------------------------------------------------------------------------------------------
+// Level lv of the counter receives its inputs one by one; input number T (1-based, a compile-time constant): the
+// first is parked in a[lv], an even one in b[lv], an odd one >= 3 closes a full adder (sum back to a[lv], carry =
+// input number (T - 1) / 2 of level lv + 1).  After T inputs a level holds T == 0 ? 0 : (T odd ? 1 : 2) words.
+struct LvbDiagCount {
+    uint32_t a[5], b[5];
+    template <int LV, int T>
+    __device__ __forceinline__ void add(uint32_t x) {
+        static_assert(LV < 5, "5-bit counter");
+        if constexpr (T == 1) {
+            a[LV] = x;
+        } else if constexpr (T % 2 == 0) {
+            b[LV] = x;
+        } else {
+            const uint32_t s = GM_BITOP3(a[LV], b[LV], x, TT_XOR3);
+            const uint32_t c = GM_BITOP3(a[LV], b[LV], x, TT_MAJ);
+            a[LV] = s;
+            if constexpr (LV < 4) add<LV + 1, (T - 1) / 2>(c);
+        }
+    }
+    // bits of the total once level LV has received T inputs (and the levels above theirs)
+    template <int LV, int T>
+    __device__ __forceinline__ void finish(uint32_t (&c)[5]) {
+        constexpr int TN = T >= 1 ? (T - 1) / 2 : 0;      // inputs level LV + 1 has received so far
+        if constexpr (T == 0) {
+            c[LV] = 0u;
+            if constexpr (LV < 4) finish<LV + 1, 0>(c);
+        } else if constexpr (T % 2 == 1) {
+            c[LV] = a[LV];
+            if constexpr (LV < 4) finish<LV + 1, TN>(c);
+        } else {      // two words pending: half adder, its carry is one more input of the next level
+            c[LV] = a[LV] ^ b[LV];
+            if constexpr (LV < 4) {
+                add<LV + 1, TN + 1>(a[LV] & b[LV]);
+                finish<LV + 1, TN + 1>(c);
+            }
+        }
+    }
+};
+
+template <int BOFF>
+__device__ __forceinline__ uint64_t lvb_read2(uint32_t adr) {
+    uint64_t v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(adr), "n"(BOFF));
+    return v;
+}
+__device__ __forceinline__ void lvb_wait2(uint64_t& a, uint64_t& b) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b));
+}
+
+template <int L, int BAND, int J>
+__device__ __forceinline__ void lvb_column_banded2(const uint32_t (&adr)[L], uint32_t (&Pv0)[L], uint32_t (&Mv0)[L],
+                                                   uint32_t (&Pv1)[L], uint32_t (&Mv1)[L], LvbDiagCount& d0,
+                                                   LvbDiagCount& d1) {
+    constexpr int LO = J - BAND > 0 ? J - BAND : 0;
+    constexpr int HI = J + BAND < L - 1 ? J + BAND : L - 1;
+    constexpr int N = HI - LO + 1, NP = (N + 1) / 2 * 2;
+    uint64_t eq[NP];
+#pragma unroll
+    for (int r = 0; r < NP; ++r) eq[r] = r < N ? lvb_read2<32 * J>(adr[LO + r]) : 0ull;
+#pragma unroll
+    for (int g = 0; g < NP / 2; ++g) lvb_wait2(eq[2 * g], eq[2 * g + 1]);
+    uint32_t Ph0 = 0xffffffffu, Mh0 = 0u, Ph1 = 0xffffffffu, Mh1 = 0u;
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+        const int i = LO + r;
+        const uint32_t e0 = (uint32_t)eq[r], e1 = (uint32_t)(eq[r] >> 32);
+        const uint32_t D00 = GM_BITOP3(e0, Mv0[i], Mh0, TT_OR3);
+        const uint32_t D01 = GM_BITOP3(e1, Mv1[i], Mh1, TT_OR3);
+        const uint32_t Pho0 = GM_BITOP3(Mv0[i], D00, Pv0[i], TT_A_OR_NOR_BC);
+        const uint32_t Pho1 = GM_BITOP3(Mv1[i], D01, Pv1[i], TT_A_OR_NOR_BC);
+        const uint32_t Mho0 = Pv0[i] & D00;
+        const uint32_t Mho1 = Pv1[i] & D01;
+        Pv0[i] = GM_BITOP3(Mh0, D00, Ph0, TT_A_OR_NOR_BC);
+        Pv1[i] = GM_BITOP3(Mh1, D01, Ph1, TT_A_OR_NOR_BC);
+        Mv0[i] = Ph0 & D00;
+        Mv1[i] = Ph1 & D01;
+        Ph0 = Pho0;
+        Mh0 = Mho0;
+        Ph1 = Pho1;
+        Mh1 = Mho1;
+        if (i == J) {
+            d0.template add<0, J + 1>(D00);
+            d1.template add<0, J + 1>(D01);
+        }
+    }
+    asm volatile("" : "+v"(Ph0), "+v"(Mh0), "+v"(Ph1), "+v"(Mh1));
+}
+
+template <int L, int BAND, int... J>
+__device__ __forceinline__ void lvb_columns_banded2(const uint32_t (&adr)[L], uint32_t (&Pv0)[L], uint32_t (&Mv0)[L],
+                                                    uint32_t (&Pv1)[L], uint32_t (&Mv1)[L], LvbDiagCount& d0,
+                                                    LvbDiagCount& d1, std::integer_sequence<int, J...>) {
+    (lvb_column_banded2<L, BAND, J>(adr, Pv0, Mv0, Pv1, Mv1, d0, d1), ...);
+}
+
+// banded DP of a whole group (both halves); adr[] is NOT advanced
+template <int L, int BAND>
+__device__ __forceinline__ void lvb_eval_group_banded(const uint32_t (&adr)[L], uint32_t (&c0)[5], uint32_t (&c1)[5]) {
+    uint32_t Pv0[L], Mv0[L], Pv1[L], Mv1[L];
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        Pv0[i] = Pv1[i] = 0xffffffffu;
+        Mv0[i] = Mv1[i] = 0u;
+    }
+    LvbDiagCount d0, d1;
+    lvb_columns_banded2<L, BAND>(adr, Pv0, Mv0, Pv1, Mv1, d0, d1, std::make_integer_sequence<int, L>{});
+    d0.template finish<0, L>(c0);
+    d1.template finish<0, L>(c1);
+    asm volatile("" : "+v"(c0[0]), "+v"(c0[1]), "+v"(c0[2]), "+v"(c0[3]), "+v"(c0[4]));
+    asm volatile("" : "+v"(c1[0]), "+v"(c1[1]), "+v"(c1[2]), "+v"(c1[3]), "+v"(c1[4]));
+}
+
 // K2B scan.  grid = (ceil(n_q / 64), n_seg); tiles = the K1L one-hot table tiles (LK_TG groups of 64).
 // Dynamic LDS: 2 tiles.  seed_*: Hamming k-NN of the same candidates (lev <= hamming).
 // keys: [n_seg][n_q][KCAP] raw RegList contents, folded by k_merge_lists.
-template <int L, int KCAP>
-__global__ __launch_bounds__(WAVE, GM_LVB_WAVES) void k_leven_knn_bs(const uint32_t* __restrict__ table, int n_db, int n_tiles,
+// Two instantiations share the grid: FULL = false serves the workgroups whose 64 candidates all start with a bound
+// inside the band (bounds only tighten, so such a wave never needs the full matrix); it contains the banded code only,
+// fits ~110 VGPRs and runs at 4 waves/SIMD.  FULL = true serves the other workgroups (unseeded rows, far k-th
+// neighbours) with every path (~155 VGPRs, 3 waves/SIMD).  Each workgroup decides from its seeds alone which of the
+// two launches it belongs to and leaves the other at once.
+template <int L, int KCAP, bool FULL>
+__global__ __launch_bounds__(WAVE, (FULL ? GM_LVB_WAVES : GM_LVB_BAND_WAVES)) void k_leven_knn_bs(const uint32_t* __restrict__ table, int n_db, int n_tiles,
                                                        int tiles_per_seg, const uint2* __restrict__ q,
                                                        int64_t n_q, int k, const int32_t* __restrict__ seed_dists,
                                                        const int32_t* __restrict__ seed_counts, int seed_k,
@@ -211,6 +339,10 @@ __global__ __launch_bounds__(WAVE, GM_LVB_WAVES) void k_leven_knn_bs(const uint3
         thr_seed = seed_dists[qi * seed_k + (seed_k - 1)] + 1;      // lev <= hamming
     if (thr_seed > L + 1) thr_seed = L + 1;
     int thr = valid ? thr_seed : 0;
+    {
+        const bool in_band = __builtin_amdgcn_ballot_w64(thr > 2 * lvb_band(L) + 2) == 0ull;
+        if (in_band == FULL) return;      // the other launch serves this workgroup
+    }
     uint32_t Tb[5];
     lk_set_bound(Tb, L, thr);
 
@@ -236,23 +368,33 @@ __global__ __launch_bounds__(WAVE, GM_LVB_WAVES) void k_leven_knn_bs(const uint3
         for (int gl = 0; gl < LK_TG; ++gl) {
             uint32_t c0[5], c1[5];
             constexpr int BAND = lvb_band(L), NARROW = BAND - 1;
-            const bool banded = __builtin_amdgcn_ballot_w64(thr > 2 * BAND + 2) == 0ull;
+            const bool banded = !FULL || __builtin_amdgcn_ballot_w64(thr > 2 * BAND + 2) == 0ull;
             const bool narrow = NARROW >= 2 && __builtin_amdgcn_ballot_w64(thr > 2 * NARROW + 2) == 0ull;
             if (narrow) {
-                lvb_eval_half_banded<L, 0, (NARROW >= 2 ? NARROW : 2)>(adr, c0);
-                lvb_eval_half_banded<L, 4, (NARROW >= 2 ? NARROW : 2)>(adr, c1);
+                if constexpr (!FULL) {
+                    lvb_eval_group_banded<L, (NARROW >= 2 ? NARROW : 2)>(adr, c0, c1);
+                } else {
+                    lvb_eval_half_banded<L, 0, (NARROW >= 2 ? NARROW : 2)>(adr, c0);
+                    lvb_eval_half_banded<L, 4, (NARROW >= 2 ? NARROW : 2)>(adr, c1);
+                }
 #pragma unroll
                 for (int i = 0; i < L; ++i) asm volatile("v_add_u32 %0, %1, %0" : "+v"(adr[i]) : "n"(GW * 4));
             } else if (banded) {
-                lvb_eval_half_banded<L, 0, BAND>(adr, c0);
-                lvb_eval_half_banded<L, 4, BAND>(adr, c1);
+                if constexpr (!FULL) {
+                    lvb_eval_group_banded<L, BAND>(adr, c0, c1);
+                } else {
+                    lvb_eval_half_banded<L, 0, BAND>(adr, c0);
+                    lvb_eval_half_banded<L, 4, BAND>(adr, c1);
+                }
 #pragma unroll
                 for (int i = 0; i < L; ++i) asm volatile("v_add_u32 %0, %1, %0" : "+v"(adr[i]) : "n"(GW * 4));
-            } else {
+            } else if constexpr (FULL) {
                 lvb_eval_half<L, 0>(adr, c0);                              // adr: -> next group
 #pragma unroll
                 for (int i = 0; i < L; ++i) asm volatile("v_subrev_u32 %0, %1, %0" : "+v"(adr[i]) : "n"(GW * 4));
                 lvb_eval_half<L, 4>(adr, c1);
+            } else {
+                __builtin_unreachable();      // (a band-only workgroup started inside the band and bounds only tighten)
             }
             uint32_t h0 = GM_BITOP3(c0[0], Tb[0], Tb[0], TT_A_OR_NOTB), h1 = GM_BITOP3(c1[0], Tb[0], Tb[0], TT_A_OR_NOTB);
 #pragma unroll
