@@ -233,7 +233,7 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
     }
     const int lcap = P.lcap[ch.lst], row_words = P.row_words;
     uint32_t* __restrict__ mylists = lists + P.loff[ch.lst];     // keys of candidate row: mylists + row * row_words
-    int thr = valid ? thr0 : 0;                                 // accept d < thr
+    int thr = valid && !(P.debug & 2) ? thr0 : 0;              // accept d < thr  (debug bit 1: no hits at all, timing only)
     uint32_t Tb[5];
 
     PgIter it{ch.e_lo - 1, 0, 0, 0, 0};

@@ -28,9 +28,9 @@
  *     fewer than k db points are padded with -1 and counts[] holds the valid length
  *   - *_dev variants take DEVICE pointers (HBM-resident inputs/outputs) and a hipStream_t passed as
  *     void*; they enqueue on that stream and return without waiting for the results.  (Large Hamming pools go
- *     through the pigeonhole-partitioned scan, which waits for the stream twice inside the call: to learn how
- *     many rows need the follow-up scan and to verify it; the first call on a handle also builds the
- *     block-sorted pool copies.)
+ *     through the pigeonhole-partitioned scan, which waits for the stream once inside the call -- a 32-byte
+ *     read-back of how many rows need the follow-up scan -- and once more, to verify that follow-up, only when there
+ *     are such rows; the first call on a handle also builds the block-sorted pool copies.)
  *   - one host thread per handle; handles are independent; one handle = one GPU (multi-GPU is one
  *     process per GPU)
  *   - there is NO CPU fallback: without a gfx950 device every compute entry point fails with
@@ -195,7 +195,8 @@ int gm_set_variant(gm_index* idx, int variant);
  *   "pg_run" (default 128): consecutive chunk-table entries of that scan executed on the same XCD;
  *   "pg_layout": force a layout of that scan, decimal digit pairs (bases, radius) per block, e.g. 826161 = blocks of
  *   8, 6, 6 bases with the two-, one-, one-substitution neighbourhoods (0 = let the planner choose);
- *   "pg_debug": timing experiments only (bit 0: the scan skips its list stores -- results are then WRONG). */
+ *   "pg_debug": timing experiments only (bit 0: the scan skips its list stores; bit 1: the scan accepts no hit at
+ *   all -- results are then WRONG). */
 int gm_set_param(gm_index* idx, const char* name, int value);
 
 #ifdef __cplusplus
