@@ -101,6 +101,7 @@ extern "C" {
 
 int gm_site_flags(const uint64_t* packed, int64_t n, int guidelen, const char* const* sites, int n_sites,
                   uint8_t* flags, int device) {
+    GM_ENTER();
     if (n < 0 || (n > 0 && (!packed || !flags)) || guidelen < 1 || guidelen > GM_MAX_GUIDELEN || n_sites < 0 ||
         (n_sites > 0 && !sites))
         return gm_fail(GM_ERR_ARG, "gm_site_flags: bad argument");
@@ -144,6 +145,7 @@ int gm_site_flags(const uint64_t* packed, int64_t n, int guidelen, const char* c
 
 int gm_seed_duplicated(const uint64_t* packed, int64_t n, int guidelen, int start, int count, uint8_t* flags,
                        int device) {
+    GM_ENTER();
     if (n < 0 || (n > 0 && (!packed || !flags)) || guidelen < 1 || guidelen > GM_MAX_GUIDELEN || start < 0 ||
         count < 0 || start + count > guidelen)
         return gm_fail(GM_ERR_ARG, "gm_seed_duplicated: bad argument");

@@ -58,6 +58,11 @@ int gm_fail(int code, const std::string& msg);   // records the thread-local err
             return gm_fail(GM_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// hipGetLastError() is per host thread and STICKY across libraries: an error left behind by somebody else's HIP call
+// (RCCL probing peer devices, torch) would otherwise be reported by our next launch check.  Every public entry point
+// starts by clearing it.
+#define GM_ENTER() (void)hipGetLastError()
+
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 // K1L launchers, one per guide length (gm_inst_lk.hip)

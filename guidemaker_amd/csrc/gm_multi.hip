@@ -12,7 +12,8 @@
 // the calling thread inside ncclGroupStart / ncclGroupEnd.
 //
 // (The Python package drives multi-GPU as one process per GPU over torch.distributed instead --
-// guidemaker_amd/distributed.py; this entry serves hosts without torch.)
+// guidemaker_amd/distributed.py; this entry serves hosts without torch.  Do not drive RCCL through both in one
+// process: PyTorch ships its own copy of librccl.so.)
 #include "gm_host.h"
 
 #include <dlfcn.h>
@@ -40,9 +41,17 @@ Rccl& rccl() {
     static bool tried = false;
     if (tried) return r;
     tried = true;
-    for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-        r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    // a process must not hold two copies of RCCL (PyTorch ships its own librccl.so next to libtorch_hip.so): take the
+    // copy that is already loaded if there is one, load the system's only otherwise; never export its symbols
+    for (const char* name : {"librccl.so", "librccl.so.1"}) {
+        r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
         if (r.lib) break;
+    }
+    if (!r.lib) {
+        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.lib) break;
+        }
     }
     if (!r.lib) return r;
     r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(dlsym(r.lib, "ncclCommInitAll"));
@@ -123,6 +132,7 @@ extern "C" {
 
 int gm_multi_create(const uint64_t* packed, int64_t n_db, int guidelen, int metric, const int* devices, int n_devices,
                     gm_multi** out) {
+    GM_ENTER();
     if (!out) return gm_fail(GM_ERR_ARG, "gm_multi_create: null out");
     *out = nullptr;
     if (!devices || n_devices < 1 || n_devices > 64) return gm_fail(GM_ERR_ARG, "gm_multi_create: need 1..64 devices");
@@ -181,6 +191,7 @@ int gm_multi_has_comm(const gm_multi* m) { return m && m->have_comm ? 1 : 0; }
 gm_index* gm_multi_index(gm_multi* m, int i) { return (m && i >= 0 && i < m->n) ? m->idx[i] : nullptr; }
 
 int gm_multi_knn_query(gm_multi* m, const uint64_t* q, int64_t n_q, int k, int32_t* ids, int32_t* dists, int32_t* counts) {
+    GM_ENTER();
     if (!m) return gm_fail(GM_ERR_ARG, "gm_multi_knn_query: null handle");
     if (n_q < 0 || k < 1 || k > GM_MAX_K) return gm_fail(GM_ERR_ARG, "gm_multi_knn_query: need n_q >= 0, 1 <= k <= 64");
     if (n_q == 0) return GM_OK;

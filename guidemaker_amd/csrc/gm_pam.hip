@@ -214,6 +214,7 @@ void gm_pam_free(gm_scan* s) {
 
 int gm_pam_count(const char* seq, int64_t n, const char* pam, int pam_len, int five_prime, int guidelen,
                  int device, gm_scan** out, int64_t* n_fwd, int64_t* n_rev) {
+    GM_ENTER();
     if (!out || !n_fwd || !n_rev) return gm_fail(GM_ERR_ARG, "gm_pam_count: null output");
     *out = nullptr;
     *n_fwd = *n_rev = 0;
@@ -269,6 +270,7 @@ int gm_pam_count(const char* seq, int64_t n, const char* pam, int pam_len, int f
 }
 
 int gm_pam_emit(gm_scan* s, uint64_t* packed, int64_t* tstart, int64_t* mstart) {
+    GM_ENTER();
     if (!s) return gm_fail(GM_ERR_ARG, "gm_pam_emit: null scan handle");
     const long long total = s->n_fwd + s->n_rev;
     if (total == 0) return GM_OK;

@@ -433,6 +433,7 @@ int gm_unpack(const uint64_t* packed, int64_t n, int guidelen, char* out) {
 
 int gm_index_create_dev(const void* d_packed, int64_t n_db, int guidelen, int metric, int device,
                         void* stream, gm_index** out) {
+    GM_ENTER();
     if (!out) return fail(GM_ERR_ARG, "gm_index_create: null out");
     *out = nullptr;
     if (n_db < 0 || n_db > GM_MAX_DB) return fail(GM_ERR_ARG, "gm_index_create: n_db out of range");
@@ -516,6 +517,7 @@ int gm_index_create_dev(const void* d_packed, int64_t n_db, int guidelen, int me
 
 int gm_index_create(const uint64_t* packed, int64_t n_db, int guidelen, int metric, int device,
                     gm_index** out) {
+    GM_ENTER();
     if (!out) return fail(GM_ERR_ARG, "gm_index_create: null out");
     *out = nullptr;
     if (n_db < 0 || n_db > GM_MAX_DB) return fail(GM_ERR_ARG, "gm_index_create: n_db out of range");
@@ -586,6 +588,7 @@ static int knn_query_dev_impl(gm_index* idx, const void* d_q, int64_t n_q, int k
 
 int gm_knn_query_dev(gm_index* idx, const void* d_q, int64_t n_q, int k, void* d_ids, void* d_dists,
                      void* d_counts, void* stream) {
+    GM_ENTER();
     if (check_index(idx)) return GM_ERR_ARG;
     HIP_TRY(hipSetDevice(idx->device));
     HIP_TRY(hipEventRecord(idx->evq0, reinterpret_cast<hipStream_t>(stream)));
@@ -648,6 +651,7 @@ static int knn_query_dev_impl(gm_index* idx, const void* d_q, int64_t n_q, int k
 
 int gm_knn_query(gm_index* idx, const uint64_t* q, int64_t n_q, int k, int32_t* ids, int32_t* dists,
                  int32_t* counts) {
+    GM_ENTER();
     if (check_index(idx)) return GM_ERR_ARG;
     if (n_q < 0 || k < 1 || k > GM_MAX_K) return fail(GM_ERR_ARG, "gm_knn_query: need n_q >= 0, 1 <= k <= 64");
     if (n_q == 0) return GM_OK;
@@ -671,6 +675,7 @@ int gm_knn_query(gm_index* idx, const uint64_t* q, int64_t n_q, int k, int32_t* 
 static int nearest_dist_dev_impl(gm_index* idx, const void* d_q, int64_t n_q, void* d_d1, void* stream);
 
 int gm_nearest_dist_dev(gm_index* idx, const void* d_q, int64_t n_q, void* d_d1, void* stream) {
+    GM_ENTER();
     if (check_index(idx)) return GM_ERR_ARG;
     HIP_TRY(hipSetDevice(idx->device));
     HIP_TRY(hipEventRecord(idx->evq0, reinterpret_cast<hipStream_t>(stream)));
@@ -730,6 +735,7 @@ static int nearest_dist_dev_impl(gm_index* idx, const void* d_q, int64_t n_q, vo
 }
 
 int gm_nearest_dist(gm_index* idx, const uint64_t* q, int64_t n_q, int32_t* d1) {
+    GM_ENTER();
     if (check_index(idx)) return GM_ERR_ARG;
     if (n_q < 0) return fail(GM_ERR_ARG, "gm_nearest_dist: n_q < 0");
     if (n_q == 0) return GM_OK;
@@ -748,6 +754,7 @@ int gm_nearest_dist(gm_index* idx, const uint64_t* q, int64_t n_q, int32_t* d1) 
 
 int gm_cfd_batch_dev(const void* d_guides, const void* d_offs, int64_t n_pairs, int guidelen,
                      const void* d_mm, void* d_out, void* stream) {
+    GM_ENTER();
     if (n_pairs < 0 || guidelen < 1 || guidelen > GM_MAX_GUIDELEN)
         return fail(GM_ERR_ARG, "gm_cfd_batch: bad argument");
     if (n_pairs == 0) return GM_OK;
@@ -762,6 +769,7 @@ int gm_cfd_batch_dev(const void* d_guides, const void* d_offs, int64_t n_pairs, 
 
 int gm_cfd_batch(const uint64_t* guides, const uint64_t* offs, int64_t n_pairs, int guidelen,
                  const double* mm, double* out, int device) {
+    GM_ENTER();
     if (n_pairs < 0 || guidelen < 1 || guidelen > GM_MAX_GUIDELEN)
         return fail(GM_ERR_ARG, "gm_cfd_batch: bad argument");
     if (n_pairs == 0) return GM_OK;
@@ -790,6 +798,7 @@ int gm_cfd_batch(const uint64_t* guides, const uint64_t* offs, int64_t n_pairs, 
 }
 
 int gm_pack_keys_dev(const void* d_ids, const void* d_dists, int64_t n_q, int k, void* d_keys, void* stream) {
+    GM_ENTER();
     if (n_q < 0 || k < 1) return fail(GM_ERR_ARG, "gm_pack_keys: bad argument");
     if (n_q == 0) return GM_OK;
     if (!d_ids || !d_dists || !d_keys) return fail(GM_ERR_ARG, "gm_pack_keys: null buffer");
@@ -803,6 +812,7 @@ int gm_pack_keys_dev(const void* d_ids, const void* d_dists, int64_t n_q, int k,
 
 int gm_unpack_keys_dev(const void* d_keys, int64_t n_q, int k, void* d_ids, void* d_dists, void* d_counts,
                        void* stream) {
+    GM_ENTER();
     if (n_q < 0 || k < 1) return fail(GM_ERR_ARG, "gm_unpack_keys: bad argument");
     if (n_q == 0) return GM_OK;
     if (!d_keys || !d_ids || !d_dists || !d_counts) return fail(GM_ERR_ARG, "gm_unpack_keys: null buffer");

@@ -696,24 +696,46 @@ def test_fuzz_against_oracle_time_boxed(oracle):
 
 
 # ------------------------------------------------------------------ in-library multi-device entry
-def test_multi_device_entry_matches_single_device(oracle):
+_MULTI_CHILD = r"""
+import sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import numpy as np
+from helpers import random_pool
+from guidemaker_amd import _lib
+from oracle import oracle as orc
+assert "torch" not in sys.modules
+L, k = 20, 10
+db = list(dict.fromkeys(random_pool(6000, L, seed=71)))
+q = db[::2] + random_pool(333, L, seed=72)
+m = _lib.MultiIndex(_lib.pack(db, L), L, _lib.METRIC_HAMMING, [0])
+assert m.devices() == 1 and m.has_comm()          # librccl.so loaded, communicator created
+ids, dists, counts = m.knn(_lib.pack(q, L), k)
+oi, od, oc = orc.knn(db, q, L, "hamming", k)
+od = np.where(od >= 0, od // 2, -1)
+assert (ids == oi).all() and (dists == od).all() and (counts == oc).all()
+assert m.knn(np.empty((0,), np.uint64), k)[0].shape == (0, k)
+m.close()
+for bad in ([0, 0], [99]):                        # duplicate ordinal / no such device
+    try:
+        _lib.MultiIndex(_lib.pack(db, L), L, _lib.METRIC_HAMMING, bad)
+        raise SystemExit("expected GmHipError for devices %r" % bad)
+    except _lib.GmHipError:
+        pass
+print("multi ok")
+"""
+
+
+def test_multi_device_entry_matches_single_device():
     """gm_multi_* (one process, n GPUs, ncclCommInitAll + one ncclAllGather of the keys): on this box the device list
-    has one entry, which still runs the whole sequence -- shard, scan, key packing, RCCL all-gather, unpack."""
-    L, k = 20, 10
-    db = list(dict.fromkeys(random_pool(6000, L, seed=71)))
-    q = db[::2] + random_pool(333, L, seed=72)
-    m = _lib.MultiIndex(_lib.pack(db, L), L, _lib.METRIC_HAMMING, [0])
-    assert m.devices() == 1 and m.has_comm()          # librccl.so loaded, communicator created
-    ids, dists, counts = m.knn(_lib.pack(q, L), k)
-    oi, od, oc = _oracle_true_units(oracle, db, q, L, "hamming", k)
-    assert (ids == oi).all() and (dists == od).all() and (counts == oc).all()
-    e_ids, _, _ = m.knn(np.empty((0,), np.uint64), k)
-    assert e_ids.shape == (0, k)
-    m.close()
-    with pytest.raises(_lib.GmHipError):
-        _lib.MultiIndex(_lib.pack(db, L), L, _lib.METRIC_HAMMING, [0, 0])      # duplicate ordinal
-    with pytest.raises(_lib.GmHipError):
-        _lib.MultiIndex(_lib.pack(db, L), L, _lib.METRIC_HAMMING, [99])        # no such device
+    has one entry, which still runs the whole sequence -- shard, scan, key packing, RCCL all-gather, unpack.  Runs in
+    a child process without torch: this entry is for hosts that do not use torch.distributed, and one process should
+    not drive RCCL through both (PyTorch ships its own copy of the library)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _MULTI_CHILD, root], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "multi ok" in out.stdout, out.stdout + out.stderr
 
 
 # ------------------------------------------------------------------ every guide length, both metrics (SURVEY.md 4(iii))
@@ -749,3 +771,41 @@ def test_pack_unpack_roundtrip_and_one_hot_equivalence(oracle):
     for i in range(len(seqs)):
         for j, d in zip(ids[i].tolist(), dists[i].tolist()):
             assert 2 * d == oracle.py_bit_hamming(onehot[i], onehot[j])
+
+
+# ------------------------------------------------------------------ RCCL path of the one-process-per-GPU driver
+def test_sharded_knn_index_over_rccl_single_rank(oracle):
+    """guidemaker_amd.distributed on the real backend (nccl = RCCL) with a one-rank group: the device-resident
+    sharded_knn_index (Index.knn_dev -> key packing -> all_gather_into_tensor -> unpack) and the asynchronous
+    double-buffered gather bench.py uses.  (More than one rank needs more than one GPU; the rank arithmetic is
+    covered by the gloo tests.)"""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from guidemaker_amd import distributed
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        L, k = 20, 10
+        db = list(dict.fromkeys(random_pool(5000, L, seed=81)))
+        q = db[::3] + random_pool(257, L, seed=82)
+        idx = _lib.Index(_lib.pack(db, L), L, _lib.METRIC_HAMMING)
+        qp = _lib.pack(q, L)
+        ids, dists, counts = distributed.sharded_knn_index(idx, qp, k, 0)
+        oi, od, oc = _oracle_true_units(oracle, db, q, L, "hamming", k)
+        assert (ids == oi).all() and (dists == od).all() and (counts == oc).all()
+        dev = torch.device("cuda", 0)
+        t_ids, t_d = torch.from_numpy(oi).to(dev), torch.from_numpy(od.astype(np.int32)).to(dev)
+        bufs = [torch.empty((len(q), k), dtype=torch.int32, device=dev) for _ in range(2)]
+        pend = [distributed.all_gather_neighbors_async(t_ids, t_d, len(q), out=b) for b in bufs]
+        for p in pend:
+            gi, gd, gc = p.result()
+            assert (gi.cpu().numpy() == oi).all() and (gd.cpu().numpy() == od).all() and (gc.cpu().numpy() == oc).all()
+        idx.close()
+    finally:
+        dist.destroy_process_group()
