@@ -138,6 +138,11 @@ def roofline_block(workload, pool, kname, kern_s, n_timed, query_ms, launch_pair
         roof["frac"] = useful / peak
         roof["counters"] = None
         roof["note_counters"] = "no PMC pass registered for this workload/kernel: achieved = the modelled useful ops"
+    if "achieved" in roof and useful > roof["achieved"]:
+        # (K2B: part of the waves run the narrower band, i.e. fewer cells than the model's band: the kernel cannot do
+        # more useful work than it issues)
+        useful = roof["achieved"]
+        model += "; capped at the issued rate"
     roof["useful"] = {"achieved": useful, "frac": useful / peak, "ops_per_pair": useful_opp, "model": model}
     compulsory = 8.0 * (n_q + n_db) + 8.0 * k * n_q
     traffic = reg.get("hbm_side_bytes_per_launch")
