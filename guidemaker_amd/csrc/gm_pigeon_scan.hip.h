@@ -319,13 +319,15 @@ __global__ void k_merge_hits(gm_pg_blocks P, const uint32_t* __restrict__ lists,
                 if (base + j < c && kk[j] + 1u < list.v[KCAP - 1]) list.insert_unique(kk[j]);
         }
     }
+    // shuffle tree over the PG_MERGE_SPLIT lanes of a candidate: lane s takes the list of lane s + off over
 #pragma unroll
-    for (int s = 1; s < PG_MERGE_SPLIT; ++s) {
-        overflow |= __shfl_down(overflow, s, PG_MERGE_SPLIT);
+    for (int off = PG_MERGE_SPLIT / 2; off >= 1; off >>= 1) {
+        overflow |= __shfl_down(overflow, off, PG_MERGE_SPLIT);
 #pragma unroll
         for (int i = 0; i < KCAP; ++i) {
-            const uint32_t v = __shfl_down(list.v[i], s, PG_MERGE_SPLIT);
-            if (sub == 0 && v != 0u && v != RegList<KCAP>::EMPTY) list.insert_unique(v - 1u);
+            const uint32_t v = __shfl_down(list.v[i], off, PG_MERGE_SPLIT);
+            // (a partner's entries ascend: nothing that cannot beat the current k-th needs the 3 KCAP-op insert)
+            if (sub < off && v != 0u && v < list.v[KCAP - 1]) list.insert_unique(v - 1u);
         }
     }
     if (sub != 0 || !valid) return;
