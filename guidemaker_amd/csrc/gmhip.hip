@@ -236,11 +236,24 @@ bool use_leven_lookup(const gm_index* idx, int k) {
            (idx->variant == 0 || idx->variant == 2);      // 0 = K2B bit-sliced DP, 2 = K2L (A/B baseline)
 }
 
+int run_hamming_pigeon(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t* ids, int32_t* dists,
+                       int32_t* counts, hipStream_t st, bool* used, bool timed);
+
 int run_leven_lookup(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* dists, int32_t* counts,
                      int32_t* d1, hipStream_t st) {
     const bool nearest = d1 != nullptr;
     const int kcap = nearest ? 1 : (k <= 10 ? 10 : 20);    // (a capacity-5 instantiation measured slower than 10)
-    int rc = nearest ? run_hamming_lookup(idx, true, n_q, 1, nullptr, d1, nullptr, false, st)
+    // seeds: the exact Hamming k-NN of the same candidates (lev <= hamming) -- through the pigeonhole-partitioned scan
+    // where the planner finds a layout (pools >= 32 768), else the plain two-phase scan
+    bool seeded = false;
+    int rc = GM_OK;
+    if (idx->variant == 0) {
+        rc = nearest ? run_hamming_pigeon(idx, true, n_q, 1, nullptr, d1, nullptr, st, &seeded, false)
+                     : run_hamming_pigeon(idx, false, n_q, k, ids, dists, counts, st, &seeded, false);
+        if (rc) return rc;
+    }
+    if (!seeded)
+        rc = nearest ? run_hamming_lookup(idx, true, n_q, 1, nullptr, d1, nullptr, false, st)
                      : run_hamming_lookup(idx, false, n_q, k, ids, dists, counts, false, st);
     if (rc) return rc;
     // enough (chunk, segment) workgroups to fill the chip several times over, segments of whole tiles
@@ -271,7 +284,7 @@ int run_leven_lookup(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* d
 // candidates whose merged list did not fill.  Returns through *used whether K1P ran (the layout planner
 // may decide that the plain scan is the better choice for this pool / k).
 int run_hamming_pigeon(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t* ids, int32_t* dists,
-                       int32_t* counts, hipStream_t st, bool* used) {
+                       int32_t* counts, hipStream_t st, bool* used, bool timed = true) {
     *used = false;
     const int keff = nearest ? 1 : k;
     if (keff > 20 || idx->n_db < keff || n_q < 1) return GM_OK;
@@ -307,18 +320,20 @@ int run_hamming_pigeon(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
     }
     if ((rc = gm_pg_candidates(idx, n_q, st))) return rc;
     const int kcap = nearest ? 1 : (k <= 5 ? 5 : (k <= 10 ? 10 : 20));
-    if ((rc = timing_begin(idx, st))) return rc;
-    idx->last_kernel = "k_hamming_scan_pg";
+    if (timed && (rc = timing_begin(idx, st))) return rc;
+    if (timed) idx->last_kernel = "k_hamming_scan_pg";
     if ((rc = gm_pg_scan(idx, n_q, keff, st))) {
         if (rc == GM_ERR_ALLOC) return GM_OK;      // no room for the slot lists: the plain scan takes over
         return rc;
     }
-    if ((rc = timing_end(idx, st, n_q * idx->n_db))) return rc;
+    if (timed && (rc = timing_end(idx, st, n_q * idx->n_db))) return rc;
     if ((rc = gm_pg_merge(idx, kcap, n_q, keff, ids, dists, counts, nearest, st))) return rc;
     int64_t n_inc = 0, pairs = 0;
     if ((rc = gm_pg_incomplete(idx, &n_inc, &pairs, st))) return rc;
-    idx->last_evaluated = pairs;
-    idx->last_incomplete = n_inc;
+    if (timed) {
+        idx->last_evaluated = pairs;
+        idx->last_incomplete = n_inc;
+    }
     if (n_inc > 0) {
         const uint2* q2 = nullptr;
         int32_t *ids2 = nullptr, *dists2 = nullptr, *counts2 = nullptr;
