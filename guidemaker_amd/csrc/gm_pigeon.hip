@@ -526,7 +526,8 @@ int gm_pg_plan(int64_t n_db, int64_t n_q, int L, int k, double p_match, gm_pg_la
                 if (mean > 700.0) p_inc = 0.0;
                 if (p_inc >= best) continue;
                 for (int len2 = n2 ? 4 : 0; len2 <= (n2 ? GM_PG_MAXLEN : 0); ++len2)
-                    for (int len1 = (n1 && n0) ? 2 : 0; len1 <= ((n1 && n0) ? GM_PG_MAXLEN : 0); ++len1) {
+                    for (int len1 = (n1 && n0) ? 2 : 0; len1 <= ((n1 && n0) ? GM_PG_MAXLEN : 0); ++len1)
+                    for (int e1 = 0; e1 < ((n1 && n0) ? n1 : 1); ++e1) {      // e1 of the radius-1 blocks one base longer
                         gm_pg_layout lay{};
                         lay.B = B;
                         int rest = L - n2 * len2, nb = 0;
@@ -535,10 +536,10 @@ int gm_pg_plan(int64_t n_db, int64_t n_q, int L, int k, double p_match, gm_pg_la
                             lay.trad[nb] = 2;
                         }
                         bool ok = true;
-                        if (n1 && n0) {      // radius-1 blocks of len1, the plain blocks share the rest evenly
-                            rest -= n1 * len1;
+                        if (n1 && n0) {      // radius-1 blocks of len1 (+ 1 for the first e1), the plain blocks share the rest evenly
+                            rest -= n1 * len1 + e1;
                             for (int b = 0; b < n1; ++b, ++nb) {
-                                lay.blen[nb] = len1;
+                                lay.blen[nb] = len1 + (b < e1 ? 1 : 0);
                                 lay.trad[nb] = 1;
                             }
                             for (int b = 0; b < n0; ++b, ++nb) {

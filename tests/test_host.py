@@ -176,7 +176,8 @@ def test_pigeonhole_planner_choices():
         d = decode(code)
         return 3 * d["n2"] + 2 * d["n1"] + (d["B"] - d["n1"] - d["n2"]) - 1
 
-    assert _lib.pigeon_plan(599_093, 20, 10) == 304          # S1: blocks 5,5,5,5, neighbour buckets of three of them
+    s1 = decode(_lib.pigeon_plan(599_093, 20, 10))           # S1: blocks 6,5,5,4, neighbour buckets of the first three
+    assert (s1["B"], s1["n1"], s1["n2"], s1["len1"]) == (4, 3, 0, 6) and radius(_lib.pigeon_plan(599_093, 20, 10)) == 6
     s4 = decode(_lib.pigeon_plan(3_124_711, 20, 20))         # S4: one block with the two-substitution neighbourhood
     assert (s4["B"], s4["n1"], s4["n2"]) == (3, 2, 1) and s4["len2"] in (7, 8) and radius(_lib.pigeon_plan(3_124_711, 20, 20)) == 6
     assert radius(_lib.pigeon_plan(891_135, 20, 5, 0.2637)) == 6     # S3 (gc 0.383)
