@@ -113,6 +113,7 @@ int gm_pg_gather(gm_index* idx, int64_t n_inc, int k, bool nearest, const uint2*
 int gm_pg_scatter(gm_index* idx, int64_t n_inc, int k, bool nearest, int32_t* ids, int32_t* dists, int32_t* counts,
                   hipStream_t st);
 int gm_pg_blocks_of(const gm_index* idx);
+int gm_pg_positions_of(const gm_index* idx);      // positions the scan evaluates per pair (guide length - table gap)
 int gm_pg_radius(const gm_index* idx);      // r of the layout in use: every pair within r is enumerated
 int gm_pg_count_incomplete(gm_index* idx, int64_t n, int need, const int32_t* counts, const int32_t* d1,
                            int64_t* n_bad, hipStream_t st);      // rows that are not full; synchronises

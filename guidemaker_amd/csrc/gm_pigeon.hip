@@ -614,6 +614,7 @@ int gm_pg_pool_stats(gm_index* idx, hipStream_t st, double* p_match) {
 }
 
 int gm_pg_blocks_of(const gm_index* idx) { return idx->pg ? idx->pg->B : 0; }
+int gm_pg_positions_of(const gm_index* idx) { return idx->pg && idx->pg->B ? idx->pg->Lp : 0; }
 int gm_pg_radius(const gm_index* idx) {
     if (!idx->pg) return 0;
     int r = -1;

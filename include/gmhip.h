@@ -163,6 +163,9 @@ int64_t gm_last_kernel_evaluated(gm_index* idx);
 int64_t gm_last_incomplete(gm_index* idx);
 /* Number of blocks B of the K1P layout currently built for this handle (0: none built yet). */
 int gm_pigeon_blocks(gm_index* idx);
+/* Positions per pair the K1P scan evaluates with that layout (guide length minus the positions every copy's table
+ * leaves out); 0: none built yet. */
+int gm_pigeon_positions(gm_index* idx);
 /* The layout planner on its own (host arithmetic only, no device needed): the layout K1P would use for a pool of n_db
  * targets of this length, k neighbours and base-match probability p_match (sum of squared base frequencies;
  * 0.25 = uniform), assuming as many candidates as targets, encoded as
