@@ -85,7 +85,7 @@ def bitsliced_leven_ops_per_pair(L):
 
 
 def roofline_block(workload, pool, kname, kern_s, n_timed, query_ms, launch_pairs, evaluated_pairs, rescanned,
-                   pigeon_blocks, n_q, n_db, pigeon_positions=0):
+                   pigeon_blocks, n_q, n_db, block_info=None):
     """Roofline of the dominant scan kernel.  The scans are integer-VALU bound (O(N) bytes for O(N^2) pair work, all
     of it on bit-sliced words in registers / LDS), so the roof is the int32 VALU issue rate: 256 CUs x 4 SIMD-32 x
     2.4 GHz = 78.6 T lane-ops/s.
@@ -105,9 +105,16 @@ def roofline_block(workload, pool, kname, kern_s, n_timed, query_ms, launch_pair
     ctr = reg.get("counters", {})
     peak = VALU_LANE_OPS_PER_S / 1e12
     if metric == "hamming":
-        L_eval = pigeon_positions if pigeon_positions else L      # K1P evaluates the positions outside each copy's table gap
-        useful_opp = lookup_ops_per_pair(L_eval)
-        model = "2 v_bitop3 per adder of the carry-save tree over %d match words + 5 comparator ops per 32 pairs + 1 v_cmp per 64" % L_eval
+        if block_info and sum(p for _, p in block_info) > 0:
+            # K1P: every copy's table leaves its own block out; pair-weighted over the blocks of the layout
+            tot = float(sum(p for _, p in block_info))
+            useful_opp = sum(lookup_ops_per_pair(pos) * p for pos, p in block_info) / tot
+            L_eval = sum(pos * p for pos, p in block_info) / tot
+        else:
+            L_eval = L
+            useful_opp = lookup_ops_per_pair(L)
+        model = ("2 v_bitop3 per adder of the carry-save tree over the match words (%.2f positions per pair on average) "
+                 "+ 5 comparator ops per 32 pairs + 1 v_cmp per 64" % L_eval)
     elif "knn_bs" in kname:
         useful_opp = bitsliced_leven_ops_per_pair(L)
         model = "5 ops per DP cell of the band per 32 pairs + diagonal count tree + comparator (banded path)"
@@ -121,7 +128,8 @@ def roofline_block(workload, pool, kname, kern_s, n_timed, query_ms, launch_pair
             "candidates_rescanned": int(rescanned)}
     if pigeon_blocks:
         roof["pigeon_blocks"] = pigeon_blocks
-        roof["positions_evaluated"] = L_eval
+        roof["positions_evaluated"] = L_eval if metric == "hamming" else None
+        roof["blocks"] = [{"positions": pos, "pairs_evaluated": p} for pos, p in (block_info or [])]
     if "SQ_INSTS_VALU" in ctr:
         issued = ctr["SQ_INSTS_VALU"] * 64.0 / kern_s / 1e12
         roof["achieved"] = issued
@@ -403,7 +411,7 @@ def main():
         evaluated_pairs = float(evaluated_pairs)
         roof = roofline_block(args.workload, pool, kname, kern_s, len(kernel_ms), query_ms, launch_pairs,
                               evaluated_pairs, rescanned, idx.pigeon_blocks() if "scan_pg" in kname else 0, n_q, n_db,
-                              idx.pigeon_positions() if "scan_pg" in kname else 0)
+                              idx.pigeon_block_info() if "scan_pg" in kname else None)
         out = {
             "metric": "guide-pair distance comparisons/sec (whole node)",
             "value": value, "unit": "guide-pair comparisons/s", "n_gpus": world, "steps": args.steps,

@@ -74,8 +74,8 @@ def lib():
     L.gm_last_incomplete.restype = i64
     L.gm_pigeon_blocks.argtypes = [vp]
     L.gm_pigeon_blocks.restype = i32
-    L.gm_pigeon_positions.argtypes = [vp]
-    L.gm_pigeon_positions.restype = i32
+    L.gm_pigeon_block_info.argtypes = [vp, i32, c.POINTER(i32), c.POINTER(i64)]
+    L.gm_pigeon_block_info.restype = i32
     L.gm_pigeon_plan.argtypes = [i64, i32, i32, c.c_double]
     L.gm_pigeon_plan.restype = i32
     L.gm_set_variant.argtypes = [vp, i32]
@@ -128,7 +128,7 @@ EXPORTS = [
     "gm_cfd_batch_dev", "gm_last_kernel_ms", "gm_last_query_ms", "gm_last_kernel_name", "gm_last_kernel_pairs",
     "gm_set_variant", "gm_timing_reserve", "gm_timing_read", "gm_pam_count", "gm_pam_emit", "gm_pam_free",
     "gm_pack_keys_dev", "gm_unpack_keys_dev", "gm_site_flags", "gm_seed_duplicated",
-    "gm_last_kernel_evaluated", "gm_last_incomplete", "gm_pigeon_blocks", "gm_pigeon_plan", "gm_pigeon_positions", "gm_set_param",
+    "gm_last_kernel_evaluated", "gm_last_incomplete", "gm_pigeon_blocks", "gm_pigeon_plan", "gm_pigeon_block_info", "gm_set_param",
     "gm_multi_create", "gm_multi_knn_query", "gm_multi_devices", "gm_multi_has_comm", "gm_multi_index", "gm_multi_free",
 ]
 
@@ -280,9 +280,15 @@ class Index:
         L = lib()
         return int(L.gm_last_kernel_evaluated(self._h)), int(L.gm_last_incomplete(self._h))
 
-    def pigeon_positions(self):
-        """Positions per pair the pigeonhole-partitioned scan evaluates with the layout built for this index."""
-        return int(lib().gm_pigeon_positions(self._h))
+    def pigeon_block_info(self):
+        """[(positions evaluated per pair, pairs evaluated in the last launch)] per block of the K1P layout in use."""
+        out = []
+        for b in range(8):
+            pos, pairs = ctypes.c_int(), ctypes.c_int64()
+            if not lib().gm_pigeon_block_info(self._h, b, ctypes.byref(pos), ctypes.byref(pairs)):
+                break
+            out.append((int(pos.value), int(pairs.value)))
+        return out
 
     def pigeon_blocks(self):
         """Blocks of the pigeonhole layout built for this index (0: the plain scan is in use)."""

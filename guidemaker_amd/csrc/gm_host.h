@@ -84,11 +84,12 @@ struct gm_lk_args {
 GM_FOR_EACH_LEN(GM_DECL_LK)
 #undef GM_DECL_LK
 
-// K1P launchers, one per guide length (gm_inst_lk.hip): grid = upper bound of the chunk count, a multiple of 128
+// K1P launchers, one per number of evaluated positions (gm_inst_lk.hip): the launch covers the chunk-table entries
+// [*c_begin, *c_end); grid = upper bound of their number, a multiple of 8 x pg_run
 #define GM_DECL_PG(LEN)                                                                                      \
     int gm_launch_pg_L##LEN(gm_index* idx, const gm_pg_blocks* blocks, const gm_pg_chunk* chunks,             \
-                            const int* n_chunks, int64_t grid, int64_t n_q, int k, int thr0, uint32_t* lists,  \
-                            hipStream_t st);
+                            const int* c_begin, const int* c_end, int64_t grid, int64_t n_q, int k, int thr0,  \
+                            uint32_t* lists, hipStream_t st);
 GM_FOR_EACH_LEN(GM_DECL_PG)
 #undef GM_DECL_PG
 
@@ -113,7 +114,7 @@ int gm_pg_gather(gm_index* idx, int64_t n_inc, int k, bool nearest, const uint2*
 int gm_pg_scatter(gm_index* idx, int64_t n_inc, int k, bool nearest, int32_t* ids, int32_t* dists, int32_t* counts,
                   hipStream_t st);
 int gm_pg_blocks_of(const gm_index* idx);
-int gm_pg_positions_of(const gm_index* idx);      // positions the scan evaluates per pair (guide length - table gap)
+int gm_pg_block_info(const gm_index* idx, int b, int* positions, int64_t* pairs);
 int gm_pg_radius(const gm_index* idx);      // r of the layout in use: every pair within r is enumerated
 int gm_pg_count_incomplete(gm_index* idx, int64_t n, int need, const int32_t* counts, const int32_t* d1,
                            int64_t* n_bad, hipStream_t st);      // rows that are not full; synchronises

@@ -49,12 +49,12 @@ int launch_lk(gm_index* idx, const gm_lk_args& a, hipStream_t st) {
 }
 
 template <int L>
-int launch_pg_cfg(gm_index* idx, const gm_pg_blocks* blocks, const gm_pg_chunk* chunks, const int* n_chunks,
-                  int64_t grid, int64_t n_q, int k, int thr0, uint32_t* lists, hipStream_t st) {
+int launch_pg_cfg(gm_index* idx, const gm_pg_blocks* blocks, const gm_pg_chunk* chunks, const int* c_begin,
+                  const int* c_end, int64_t grid, int64_t n_q, int k, int thr0, uint32_t* lists, hipStream_t st) {
     (void)idx;
     const size_t lds = gm::pg_lds_bytes(L);
     hipLaunchKernelGGL((gm::k_hamming_scan_pg<L>), dim3((unsigned)grid), dim3(gm::WAVE), lds, st, *blocks, chunks,
-                       n_chunks, idx->d_q, n_q, k, thr0, lists);
+                       c_begin, c_end, idx->d_q, n_q, k, thr0, lists);
     HIP_TRY(hipGetLastError());
     return GM_OK;
 }
@@ -69,7 +69,7 @@ int GM_CAT(gm_launch_lk_L, GM_LEN)(gm_index* idx, const gm_lk_args* a, hipStream
 }
 
 int GM_CAT(gm_launch_pg_L, GM_LEN)(gm_index* idx, const gm_pg_blocks* blocks, const gm_pg_chunk* chunks,
-                                   const int* n_chunks, int64_t grid, int64_t n_q, int k, int thr0, uint32_t* lists,
-                                   hipStream_t st) {
-    return launch_pg_cfg<GM_LEN>(idx, blocks, chunks, n_chunks, grid, n_q, k, thr0, lists, st);
+                                   const int* c_begin, const int* c_end, int64_t grid, int64_t n_q, int k, int thr0,
+                                   uint32_t* lists, hipStream_t st) {
+    return launch_pg_cfg<GM_LEN>(idx, blocks, chunks, c_begin, c_end, grid, n_q, k, thr0, lists, st);
 }

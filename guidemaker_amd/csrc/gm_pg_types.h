@@ -15,8 +15,8 @@ struct gm_pg_blocks {
     const uint4* recs[GM_PG_MAXB];       // per position {plane.x, plane.y, pool id, 0}; id = 0xffffffff on padding
     const int2* bdesc[GM_PG_MAXB];       // bucket v: .x = first 64-target group (even), .y = groups that hold targets
     const uint32_t* cperm[GM_PG_MAXB];   // candidates sorted by block b: sorted position -> candidate row
-    int skip[GM_PG_MAXB];                // copy b's table leaves out sequence positions [skip[b], skip[b] + skip_len)
-    int skip_len;
+    int skip[GM_PG_MAXB];                // copy b's table leaves out sequence positions [skip[b], skip[b] + skiplen[b]):
+    int skiplen[GM_PG_MAXB];             // its own block (all of it unless fewer than 10 positions would remain)
     int n_blocks;                        // B
     int blen[GM_PG_MAXB];                // bases of block b (the kernel decodes neighbour buckets with it)
     int n_lists;

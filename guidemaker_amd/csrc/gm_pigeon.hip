@@ -40,14 +40,16 @@ struct PgLayoutArg {              // per-block geometry + offsets, by value
     int per[GM_PG_MAXB];          // target buckets per such workgroup
     int lbase[GM_PG_MAXB];        // hit list of (b, s) = lbase[b] + s
     int smax;                     // max nsub
-    int skip_len;
+    int skiplen[GM_PG_MAXB];      // positions of its own block copy b's table leaves out
     int n_entries;
 };
 
 struct PgCounters {               // device-resident
+    int cstart[GM_PG_MAXB + 1];   // chunk-table range of block b: [cstart[b], cstart[b + 1]); cstart[B] = all chunks
     int n_chunks;
     int n_inc;
     unsigned long long pairs;     // pairs the last K1P launch evaluates (chunks x 64 x scanned groups x 64)
+    unsigned long long bpairs[GM_PG_MAXB];      // ... per block
     int n_bad;                    // re-scanned rows that did not fill under the guessed bound
     int pad;
 };
@@ -258,9 +260,14 @@ __global__ __launch_bounds__(256) void k_chunk_count(PgLayoutArg A, int* __restr
     nch[e] = (cnt + 63) / 64 * A.nsub[b];
 }
 
-// n_chunks = last exclusive offset + last count
-__global__ void k_chunk_total(const int* __restrict__ nch, const int* __restrict__ cbase, int n, int* __restrict__ total) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) *total = n > 0 ? cbase[n - 1] + nch[n - 1] : 0;
+// n_chunks = last exclusive offset + last count; cstart[b] = first chunk of block b (the table is block-major)
+__global__ void k_chunk_total(PgLayoutArg A, const int* __restrict__ nch, const int* __restrict__ cbase,
+                              PgCounters* __restrict__ ctr) {
+    const int n = A.n_entries;
+    const int total = n > 0 ? cbase[n - 1] + nch[n - 1] : 0;
+    if (threadIdx.x == 0 && blockIdx.x == 0) ctr->n_chunks = total;
+    if (blockIdx.x == 0 && (int)threadIdx.x <= A.B)
+        ctr->cstart[threadIdx.x] = (int)threadIdx.x < A.B ? cbase[A.ebase[threadIdx.x]] : total;
 }
 
 // one thread per ((block, bucket) entry, run of target buckets)
@@ -285,9 +292,9 @@ __global__ __launch_bounds__(256) void k_fill_chunks(PgLayoutArg A, const int* _
     unsigned long long groups = 0;
     for (int u = e_lo; u < e_hi; ++u) {
         int add;
-        groups += (unsigned long long)A.bdesc[b][gm::pg_target_bucket(v, u, A.blen[b], A.skip_len, add)].y;
+        groups += (unsigned long long)A.bdesc[b][gm::pg_target_bucket(v, u, A.blen[b], A.skiplen[b], add)].y;
     }
-    atomicAdd(&ctr->pairs, (unsigned long long)n_ch * 64ull * groups * gm::LK_GROUP);
+    atomicAdd(&ctr->bpairs[b], (unsigned long long)n_ch * 64ull * groups * gm::LK_GROUP);      // (summed on the host)
 }
 
 __global__ __launch_bounds__(256) void k_count_incomplete(const int32_t* __restrict__ counts, const int32_t* __restrict__ d1,
@@ -342,11 +349,14 @@ struct gm_pigeon {
                                        // r = sum(trad[b] + 1) - 1
     int nbk[GM_PG_MAXB]{}, nsub[GM_PG_MAXB]{}, per[GM_PG_MAXB]{}, lbase[GM_PG_MAXB]{};      // see PgLayoutArg
     int smax = 1;
-    int skip_len = 0;                  // positions of its own block each copy's table leaves out
-    int Lp = 0;                        // positions the scan evaluates = L - skip_len (>= 10)
+    int skiplen[GM_PG_MAXB]{};         // positions of its own block copy b's table leaves out
+    int Lp[GM_PG_MAXB]{};              // positions the scan evaluates under block b = L - skiplen[b] (>= 10)
+    int64_t bgrid[GM_PG_MAXB]{};       // upper bound of block b's chunk count
+    int64_t last_bpairs[GM_PG_MAXB]{}; // pairs block b's part of the last launch evaluated
     int tune_sub = 2;                  // workgroups per expansion chunk (gm_set_param "pg_sub")
     int tune_debug = 0;                // timing experiments (gm_set_param "pg_debug")
     int tune_layout = 0;               // experiments: forced layout, decimal digit pairs (len, radius) per block
+    int tune_gap = 0;                  // table gaps: 0 = choose, 1 = common gap (one launch), 2 = per-block gaps
     int tune_run = 128;                // chunk-table entries per XCD run (gm_set_param "pg_run")
     int bstart[GM_PG_MAXB]{}, blen[GM_PG_MAXB]{};
     int ebase[GM_PG_MAXB + 1]{};
@@ -614,7 +624,6 @@ int gm_pg_pool_stats(gm_index* idx, hipStream_t st, double* p_match) {
 }
 
 int gm_pg_blocks_of(const gm_index* idx) { return idx->pg ? idx->pg->B : 0; }
-int gm_pg_positions_of(const gm_index* idx) { return idx->pg && idx->pg->B ? idx->pg->Lp : 0; }
 int gm_pg_radius(const gm_index* idx) {
     if (!idx->pg) return 0;
     int r = -1;
@@ -631,6 +640,11 @@ int gm_pg_set_param(gm_index* idx, const char* name, int value) {
     }
     if (std::strcmp(name, "pg_layout") == 0) {
         idx->pg->tune_layout = value;
+        return GM_OK;
+    }
+    if (std::strcmp(name, "pg_gap") == 0) {      // (takes effect when the pool copies are next built)
+        idx->pg->tune_gap = value;
+        idx->pg->B = 0;
         return GM_OK;
     }
     if (std::strcmp(name, "pg_debug") == 0) {
@@ -694,11 +708,66 @@ int gm_pg_prepare(gm_index* idx, const gm_pg_layout* lay, hipStream_t st) {
     if ((rc = ensure_sort_buffers(pg, n))) return rc;
     if (!pg->ctr && hipMalloc(reinterpret_cast<void**>(&pg->ctr), sizeof(PgCounters)) != hipSuccess)
         return gm_fail(GM_ERR_ALLOC, "hipMalloc(K1P counters) failed");
-    // every pair of a bucket agrees on the copy's own block: leave the first `base` (= shortest block length)
-    // positions of the block out of the table and run the scan for L - base positions
-    pg->skip_len = base;
-    if (L - pg->skip_len < 10) pg->skip_len = L - 10;
-    pg->Lp = L - pg->skip_len;
+    // every pair of a bucket agrees on the copy's own block (a neighbour bucket differs there on known positions):
+    // each copy's table leaves its own block out and the scan of that copy's chunks runs the kernel instantiated for
+    // the remaining positions (at least 10: the look-up kernels start there)
+    // Option A: every table leaves out as many positions as the SHORTEST block has: one launch for all blocks.
+    // Option B: block b leaves out min(its length, G) positions, G = the length of the block with the most bucket
+    // visits: fewer positions (and a cheaper adder tree: 16 match words cost 35 ops per half, 15 cost 27) for most
+    // pairs, at the price of one launch per run of blocks with equal positions.  B is taken when the modelled VALU
+    // work drops by more than a tenth.
+    {
+        auto tree_ops = [](int n) {      // v_bitop3 per half group: carry-save count of n one-bit words + 5-bit compare
+            int ops = 0;
+            while (n > 0) {
+                int words = n, carries = 0;
+                while (words > 1) {
+                    if (words == 2) {
+                        ops += 2;
+                        carries += 1;
+                        words = 1;
+                    } else {
+                        const int t = words / 3;
+                        ops += 2 * t;
+                        carries += t;
+                        words = t + words % 3;
+                    }
+                }
+                n = carries;
+            }
+            return ops + 5;
+        };
+        double visits[GM_PG_MAXB], tot = 0.0;
+        int G = blen[0];
+        double best_v = -1.0;
+        for (int b = 0; b < B; ++b) {
+            visits[b] = (double)gm_pg_buckets_of(blen[b], lay->trad[b]) * std::pow(0.25, (double)blen[b]);
+            tot += visits[b];
+            if (visits[b] > best_v) {
+                best_v = visits[b];
+                G = blen[b];
+            }
+        }
+        double cost_a = 0.0, cost_b = 0.0;
+        for (int b = 0; b < B; ++b) {
+            int sa = base, sb = blen[b] < G ? blen[b] : G;
+            if (L - sa < 10) sa = L - 10;
+            if (L - sb < 10) sb = L - 10;
+            cost_a += visits[b] / tot * tree_ops(L - sa);
+            cost_b += visits[b] / tot * tree_ops(L - sb);
+        }
+        // Measured (profiles/r02/NOTES.md): on S1 / S3 / S4 option B loses -- (6,5,5,4): 0.65 -> 0.73 ms although the
+        // model says -20 % VALU work; two launches drain and refill the chip and the small one runs badly -- so the
+        // common gap is the default and B stays a knob (gm_set_param "pg_gap" = 2).
+        (void)cost_a;
+        (void)cost_b;
+        const bool per_block = idx->pg->tune_gap == 2;
+        for (int b = 0; b < B; ++b) {
+            pg->skiplen[b] = per_block ? (blen[b] < G ? blen[b] : G) : base;
+            if (L - pg->skiplen[b] < 10) pg->skiplen[b] = L - 10;
+            pg->Lp[b] = L - pg->skiplen[b];
+        }
+    }
     constexpr int GPA = GM_PG_ALIGN / gm::LK_GROUP;      // groups per alignment unit
     for (int b = 0; b < B && rc == GM_OK; ++b) {
         const int nb = 1 << (2 * pg->blen[b]);
@@ -735,7 +804,7 @@ int gm_pg_prepare(gm_index* idx, const gm_pg_layout* lay, hipStream_t st) {
             rc = gm_fail(GM_ERR_ARG, "K1P: padded pool copy too large");
             break;
         }
-        const int64_t words = n_groups * gm::lk_group_words(pg->Lp);
+        const int64_t words = n_groups * gm::lk_group_words(pg->Lp[b]);
         if (hipMalloc(reinterpret_cast<void**>(&pg->recs[b]), sizeof(uint4) * (size_t)(n_groups * gm::LK_GROUP)) != hipSuccess ||
             hipMalloc(reinterpret_cast<void**>(&pg->table[b]), sizeof(uint32_t) * (size_t)words) != hipSuccess) {
             rc = gm_fail(GM_ERR_ALLOC, "hipMalloc(K1P pool copy) failed");
@@ -749,8 +818,8 @@ int gm_pg_prepare(gm_index* idx, const gm_pg_layout* lay, hipStream_t st) {
         }
         hipLaunchKernelGGL(k_scatter_recs, grid_for(n), dim3(256), 0, st, idx->d_db, pg->k1, pg->r1, n, pg->raw_off, pg->bdesc[b],
                            pg->recs[b]);
-        hipLaunchKernelGGL(k_onehot_recs, grid_for(words), dim3(256), 0, st, pg->recs[b], pg->table[b], n_groups, pg->Lp,
-                           pg->bstart[b], pg->skip_len);
+        hipLaunchKernelGGL(k_onehot_recs, grid_for(words), dim3(256), 0, st, pg->recs[b], pg->table[b], n_groups, pg->Lp[b],
+                           pg->bstart[b], pg->skiplen[b]);
         if (hipGetLastError() != hipSuccess) rc = gm_fail(GM_ERR_DEVICE, "K1P pool-copy kernels failed to launch");
         // (the bdesc host vector is pageable: the copies above were staged by the runtime before returning)
         if (hipStreamSynchronize(st) != hipSuccess && rc == GM_OK) rc = gm_fail(GM_ERR_DEVICE, "K1P pool-copy build failed");
@@ -820,7 +889,9 @@ int gm_pg_candidates(gm_index* idx, int64_t n_q, hipStream_t st) {
         A.nsub[b] = pg->nsub[b];
         A.per[b] = pg->per[b];
         A.lbase[b] = pg->lbase[b];
-        grid += ((n_q + 63) / 64 + (1 << (2 * pg->blen[b]))) * pg->nsub[b];
+        A.skiplen[b] = pg->skiplen[b];
+        pg->bgrid[b] = ((n_q + 63) / 64 + (1 << (2 * pg->blen[b]))) * pg->nsub[b];
+        grid += pg->bgrid[b];
     }
     // counting sort of the candidates by every block's value: histogram, per-block scan, scatter
     const int use_lds = n_entries <= 8192 ? 1 : 0;
@@ -832,7 +903,6 @@ int gm_pg_candidates(gm_index* idx, int64_t n_q, hipStream_t st) {
     HIP_TRY(hipGetLastError());
     // chunk table
     A.smax = pg->smax;
-    A.skip_len = pg->skip_len;
     A.n_entries = n_entries;
     if ((rc = ensure(&pg->nch, &pg->nch_cap, A.n_entries, "chunk counts"))) return rc;
     if ((rc = ensure(&pg->cbase, &pg->cbase_cap, A.n_entries, "chunk offsets"))) return rc;
@@ -852,7 +922,7 @@ int gm_pg_candidates(gm_index* idx, int64_t n_q, hipStream_t st) {
         }
         HIP_TRY(rocprim::exclusive_scan(pg->sort_tmp, bytes, pg->nch, pg->cbase, 0, (size_t)A.n_entries,
                                         rocprim::plus<int>(), st));
-        hipLaunchKernelGGL(k_chunk_total, dim3(1), dim3(64), 0, st, pg->nch, pg->cbase, A.n_entries, &pg->ctr->n_chunks);
+        hipLaunchKernelGGL(k_chunk_total, dim3(1), dim3(64), 0, st, A, pg->nch, pg->cbase, pg->ctr);
     }
     hipLaunchKernelGGL(k_fill_chunks, grid_for((int64_t)A.n_entries * A.smax), dim3(256), 0, st, A, pg->cbase, pg->chunks, pg->ctr);
     HIP_TRY(hipGetLastError());
@@ -931,21 +1001,33 @@ int gm_pg_scan(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
         blocks.bdesc[b] = pg->bdesc[b];
         blocks.cperm[b] = pg->cperm[b];
         blocks.skip[b] = pg->bstart[b];
+        blocks.skiplen[b] = pg->skiplen[b];
     }
-    blocks.skip_len = pg->skip_len;
     blocks.n_blocks = pg->B;
     const int thr0 = gm_pg_radius(idx) + 1;      // accept d < thr0, i.e. d <= r
     blocks.run = pg->tune_run;
     blocks.debug = pg->tune_debug;
     const int64_t unit = 8 * (int64_t)blocks.run;      // the kernel's entry mapping permutes whole units
-    const int64_t grid = (pg->grid + unit - 1) / unit * unit;
-    switch (pg->Lp) {            // the kernel instantiated for the positions actually evaluated
+    // one launch per run of consecutive blocks whose copies keep the same number of positions
+    for (int b0 = 0; b0 < pg->B;) {
+        int b1 = b0 + 1;
+        int64_t g = pg->bgrid[b0];
+        while (b1 < pg->B && pg->Lp[b1] == pg->Lp[b0]) g += pg->bgrid[b1++];
+        const int64_t grid = (g + unit - 1) / unit * unit;
+        const int* c_begin = &pg->ctr->cstart[b0];
+        const int* c_end = &pg->ctr->cstart[b1];
+        int rc2 = GM_OK;
+        switch (pg->Lp[b0]) {            // the kernel instantiated for the positions actually evaluated
 #define GM_CASE(LEN) \
-    case LEN: return gm_launch_pg_L##LEN(idx, &blocks, pg->chunks, &pg->ctr->n_chunks, grid, n_q, k, thr0, pg->lists, st);
-        GM_FOR_EACH_LEN(GM_CASE)
+    case LEN: rc2 = gm_launch_pg_L##LEN(idx, &blocks, pg->chunks, c_begin, c_end, grid, n_q, k, thr0, pg->lists, st); break;
+            GM_FOR_EACH_LEN(GM_CASE)
 #undef GM_CASE
-        default: return gm_fail(GM_ERR_ARG, "pigeonhole kernel: guidelen out of range");
+            default: rc2 = gm_fail(GM_ERR_ARG, "pigeonhole kernel: guidelen out of range");
+        }
+        if (rc2) return rc2;
+        b0 = b1;
     }
+    return GM_OK;
 }
 
 // hit lists -> top k; rows that are not exact are listed in pg->inc (count in pg->ctr->n_inc)
@@ -974,8 +1056,20 @@ int gm_pg_incomplete(gm_index* idx, int64_t* n_inc, int64_t* pairs_evaluated, hi
     HIP_TRY(hipMemcpyAsync(&h, pg->ctr, sizeof(PgCounters), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     *n_inc = h.n_inc;
-    *pairs_evaluated = (int64_t)h.pairs;
+    *pairs_evaluated = 0;
+    for (int b = 0; b < GM_PG_MAXB; ++b) {
+        pg->last_bpairs[b] = (int64_t)h.bpairs[b];
+        *pairs_evaluated += (int64_t)h.bpairs[b];
+    }
     return GM_OK;
+}
+
+// per block of the layout in use: positions its scan evaluates per pair, pairs its part of the last launch evaluated
+int gm_pg_block_info(const gm_index* idx, int b, int* positions, int64_t* pairs) {
+    if (!idx->pg || b < 0 || b >= idx->pg->B) return 0;
+    *positions = idx->pg->Lp[b];
+    *pairs = idx->pg->last_bpairs[b];
+    return 1;
 }
 
 int gm_pg_count_incomplete(gm_index* idx, int64_t n, int need, const int32_t* counts, const int32_t* d1,

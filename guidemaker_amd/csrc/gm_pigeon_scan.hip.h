@@ -84,7 +84,7 @@ __device__ __forceinline__ bool pg_next(const gm_pg_blocks& P, const gm_pg_chunk
     } else {
         do {
             if (++it.e >= ch.e_hi) return false;
-            const int vt = pg_target_bucket(ch.v, it.e, P.blen[ch.b], P.skip_len, it.add);
+            const int vt = pg_target_bucket(ch.v, it.e, P.blen[ch.b], P.skiplen[ch.b], it.add);
             const int2 d = P.bdesc[ch.b][vt];      // one scalar 8-byte load
             it.g0 = d.x;
             it.gc = d.y;
@@ -186,18 +186,20 @@ __device__ __forceinline__ void pg_group(const uint32_t* const (&ptr)[L], const 
 // lists: the hit buffer (see gm_pg_blocks::loff / lcap)
 template <int L>
 __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
-    gm_pg_blocks P, const gm_pg_chunk* __restrict__ chunks, const int* __restrict__ n_chunks,
-    const uint2* __restrict__ q, int64_t n_q, int k, int thr0, uint32_t* __restrict__ lists) {
+    gm_pg_blocks P, const gm_pg_chunk* __restrict__ chunks, const int* __restrict__ c_begin,
+    const int* __restrict__ c_end, const uint2* __restrict__ q, int64_t n_q, int k, int thr0,
+    uint32_t* __restrict__ lists) {
     extern __shared__ __align__(16) uint32_t smem[];
     constexpr int GW = lk_group_words(L);
     constexpr int PW = pg_pair_words(L);
     // XCD-aware order: workgroups are dealt to the 8 XCDs round-robin; give every XCD runs of P.run consecutive
     // chunk-table entries (the chunks of one candidate bucket share their target buckets: same L2)
-    const int n = *n_chunks;
+    // (one launch per run of blocks with the same number of evaluated positions: entries [*c_begin, *c_end))
+    const int first = *c_begin, n = *c_end - first;
     const int wg = (int)blockIdx.x, xcd = wg & 7, slot = wg >> 3;
     const int entry = (slot / P.run) * (8 * P.run) + xcd * P.run + (slot % P.run);
     if (entry >= n) return;
-    const gm_pg_chunk ch = chunks[entry];
+    const gm_pg_chunk ch = chunks[first + entry];
     const uint32_t* __restrict__ table = P.table[ch.b];
     const uint4* __restrict__ recs = P.recs[ch.b];
     uint32_t* tiles = smem;                                     // [2][PW]
@@ -220,10 +222,10 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
     Q.c1[lane] = k == 1 ? thr0 : 0;
     Q.c2[lane] = 0;
 
-    // L = positions evaluated: the copy's table leaves out P.skip_len positions of its own block (all pairs of
+    // L = positions evaluated: the copy's table leaves out P.skiplen[b] positions of its own block (all pairs of
     // the bucket agree there, or differ on exactly one of them: `add`), so table position p is sequence position p
     // (+ skip_len behind the gap)
-    const int skip_start = P.skip[ch.b], skip_len = P.skip_len;
+    const int skip_start = P.skip[ch.b], skip_len = P.skiplen[ch.b];
     const uint32_t* ptr[L];
 #pragma unroll
     for (int p = 0; p < L; ++p) {

@@ -895,7 +895,10 @@ int64_t gm_last_kernel_pairs(gm_index* idx) { return idx ? idx->last_pairs : 0; 
 int64_t gm_last_kernel_evaluated(gm_index* idx) { return idx ? idx->last_evaluated : 0; }
 int64_t gm_last_incomplete(gm_index* idx) { return idx ? idx->last_incomplete : 0; }
 int gm_pigeon_blocks(gm_index* idx) { return idx ? gm_pg_blocks_of(idx) : 0; }
-int gm_pigeon_positions(gm_index* idx) { return idx ? gm_pg_positions_of(idx) : 0; }
+int gm_pigeon_block_info(gm_index* idx, int b, int* positions, int64_t* pairs) {
+    if (!idx || !positions || !pairs) return 0;
+    return gm_pg_block_info(idx, b, positions, pairs);
+}
 int gm_pigeon_plan(int64_t n_db, int guidelen, int k, double p_match) {
     gm_pg_layout lay{};
     if (!gm_pg_plan(n_db, n_db, guidelen, k, p_match, &lay)) return 0;

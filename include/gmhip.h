@@ -163,9 +163,10 @@ int64_t gm_last_kernel_evaluated(gm_index* idx);
 int64_t gm_last_incomplete(gm_index* idx);
 /* Number of blocks B of the K1P layout currently built for this handle (0: none built yet). */
 int gm_pigeon_blocks(gm_index* idx);
-/* Positions per pair the K1P scan evaluates with that layout (guide length minus the positions every copy's table
- * leaves out); 0: none built yet. */
-int gm_pigeon_positions(gm_index* idx);
+/* Block b of that layout: the positions per pair its scan evaluates (guide length minus the block itself, which its
+ * copy's table leaves out) and the pairs its part of the last K1P launch evaluated.  Returns 1, or 0 when there is no
+ * such block. */
+int gm_pigeon_block_info(gm_index* idx, int b, int* positions, int64_t* pairs);
 /* The layout planner on its own (host arithmetic only, no device needed): the layout K1P would use for a pool of n_db
  * targets of this length, k neighbours and base-match probability p_match (sum of squared base frequencies;
  * 0.25 = uniform), assuming as many candidates as targets, encoded as
@@ -198,6 +199,9 @@ int gm_set_variant(gm_index* idx, int variant);
  *   "pg_run" (default 128): consecutive chunk-table entries of that scan executed on the same XCD;
  *   "pg_layout": force a layout of that scan, decimal digit pairs (bases, radius) per block, e.g. 826161 = blocks of
  *   8, 6, 6 bases with the two-, one-, one-substitution neighbourhoods (0 = let the planner choose);
+ *   "pg_gap": 2 = every copy's table leaves out its own block up to the length of the most-visited block (one launch
+ *   per run of blocks with equal positions; measured slower), otherwise as many positions as the shortest block has
+ *   (one launch, the default);
  *   "pg_debug": timing experiments only (bit 0: the scan skips its list stores; bit 1: the scan accepts no hit at
  *   all -- results are then WRONG). */
 int gm_set_param(gm_index* idx, const char* name, int value);

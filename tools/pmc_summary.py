@@ -99,24 +99,36 @@ def main():
             shutil.copyfile(cand[0], a.stats_out)
             print("wrote", a.stats_out)
     if a.register and a.kernel:
-        hits = [k for k in table if a.kernel in k]
+        hits = sorted(k for k in table if a.kernel in k)
         if hits:
-            k = max(hits, key=lambda x: table[x]["mean_ns_in_pmc_passes"])
+            # the dominant "kernel" may be several instantiations launched once each per step (the pigeonhole scan runs
+            # one launch per number of evaluated positions): their counters and durations add up
+            launches = [min((v["launches"] for v in table[k]["counters"].values()), default=0) for k in hits]
+            ref = max(launches) if launches else 0
+            hits = [k for k, n in zip(hits, launches) if ref and n >= ref // 2]      # (drop stray variants with few launches)
+            counters = collections.defaultdict(float)
+            for k in hits:
+                for c, v in table[k]["counters"].items():
+                    counters[c] += v["mean_per_launch"]
+            total = None
+            if "FETCH_SIZE" in counters or "WRITE_SIZE" in counters:
+                total = int(2 * counters.get("FETCH_SIZE", 0.0) * 1024 + counters.get("WRITE_SIZE", 0.0) * 1024)
             data = {}
             if os.path.exists(a.counters_json):
                 with open(a.counters_json) as fh:
                     data = json.load(fh)
-            data["_comment"] = ("per workload: PMC counters of bench.py's dominant kernel, mean per launch, from rocprofv3 "
-                                "passes (tools/profile.sh + tools/pmc_summary.py --register).  FETCH_SIZE / WRITE_SIZE in "
-                                "KiB; hbm_side_bytes_per_launch = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction, "
+            data["_comment"] = ("per workload: PMC counters of bench.py's dominant kernel, mean per launch (summed over its "
+                                "instantiations when it runs as several launches per step), from rocprofv3 passes "
+                                "(tools/profile.sh + tools/pmc_summary.py --register).  FETCH_SIZE / WRITE_SIZE in KiB; "
+                                "hbm_side_bytes_per_launch = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction, "
                                 "MI355X_MICROARCH.md HBM section; includes Infinity-Cache hits).")
-            data[a.register] = {"kernel": k, "source": a.out, "resources": table[k]["resources"],
-                                "mean_ns_in_pmc_passes": table[k]["mean_ns_in_pmc_passes"],
-                                "hbm_side_bytes_per_launch": table[k].get("hbm_side_bytes_per_launch"),
-                                "counters": {c: v["mean_per_launch"] for c, v in table[k]["counters"].items()}}
+            data[a.register] = {"kernel": " + ".join(hits), "source": a.out,
+                                "resources": {k: table[k]["resources"] for k in hits},
+                                "mean_ns_in_pmc_passes": sum(table[k]["mean_ns_in_pmc_passes"] for k in hits),
+                                "hbm_side_bytes_per_launch": total, "counters": dict(counters)}
             with open(a.counters_json, "w") as fh:
                 json.dump(data, fh, indent=1, sort_keys=True)
-            print("registered", a.register, k, "in", a.counters_json)
+            print("registered", a.register, " + ".join(hits), "in", a.counters_json)
 
 
 if __name__ == "__main__":
