@@ -260,7 +260,12 @@ int run_leven_lookup(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* d
     const int algo = idx->variant == 2 ? 0 : 1;
     const int64_t n_tiles = algo == 1 ? idx->n_lk_tiles : idx->n_lv_tiles;
     const int64_t chunks = (n_q + gm::WAVE - 1) / gm::WAVE;
-    int64_t want = ((int64_t)idx->n_simd * 8 + chunks - 1) / chunks;
+    // about eight rounds of (chunk, segment) workgroups at the kernel's four waves per SIMD: long work items in two
+    // ragged rounds cost 10 % on S2 (swept 1 .. 256 segments: 12.6 ms at 4, 11.0 at 16-32, 12.4 at 256 where the merge
+    // of the segment lists takes over)
+    int64_t want = ((int64_t)idx->n_simd * 32 + chunks - 1) / chunks;
+    if (want > 64) want = 64;
+    if (idx->lv_seg > 0) want = idx->lv_seg;
     if (want < 1) want = 1;
     if (want > n_tiles) want = n_tiles;
     const int tiles_per_seg = (int)((n_tiles + want - 1) / want);
@@ -595,6 +600,10 @@ int gm_set_variant(gm_index* idx, int variant) {
 int gm_set_param(gm_index* idx, const char* name, int value) {
     if (check_index(idx)) return GM_ERR_ARG;
     if (!name) return fail(GM_ERR_ARG, "gm_set_param: null name");
+    if (std::strcmp(name, "lv_seg") == 0) {
+        idx->lv_seg = value;
+        return GM_OK;
+    }
     return gm_pg_set_param(idx, name, value);
 }
 

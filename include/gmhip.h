@@ -202,6 +202,7 @@ int gm_set_variant(gm_index* idx, int variant);
  *   "pg_gap": 2 = every copy's table leaves out its own block up to the length of the most-visited block (one launch
  *   per run of blocks with equal positions; measured slower), otherwise as many positions as the shortest block has
  *   (one launch, the default);
+ *   "lv_seg": pool segments of the Levenshtein scan (0 = choose);
  *   "pg_debug": timing experiments only (bit 0: the scan skips its list stores; bit 1: the scan accepts no hit at
  *   all -- results are then WRONG). */
 int gm_set_param(gm_index* idx, const char* name, int value);
