@@ -45,6 +45,7 @@ struct gm_index {
     int64_t last_evaluated = 0;   // K1P: pairs the launch really evaluated (last_pairs = pairs it resolved)
     int64_t last_incomplete = 0;  // K1P: candidates handed to the plain scan afterwards
     int variant = 0;
+    int lk_seg = 0;               // experiments (gm_set_param "lk_seg"): pool segments of K1P's re-scan, 0 = choose
     int lv_seg = 0;               // experiments (gm_set_param "lv_seg"): pool segments of the Levenshtein scan, 0 = choose
     int n_simd = 1024;            // CUs x 4
     gm_pigeon* pg = nullptr;      // K1P: block-sorted pool copies + query workspaces (built on first use)

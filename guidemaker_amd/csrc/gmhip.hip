@@ -175,6 +175,7 @@ int run_hamming_lookup(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
     if (fill > seg_cap) seg_cap = fill < 512 ? fill : 512;
     if (n_seg > seg_cap) n_seg = seg_cap;
     if (idx->variant >= 50 && idx->variant < 100) n_seg = idx->variant - 50;     // A/B knob: force the segment count
+    if (guess_thr > 0 && idx->lk_seg > 0) n_seg = idx->lk_seg < n_tiles / 2 ? idx->lk_seg : n_tiles / 2;
     int rc;
     if (a.kcap == 0 || n_seg < 2 || idx->variant == 9) {           // single pass over the whole pool
         a.n_seg = 1;
@@ -600,6 +601,10 @@ int gm_set_variant(gm_index* idx, int variant) {
 int gm_set_param(gm_index* idx, const char* name, int value) {
     if (check_index(idx)) return GM_ERR_ARG;
     if (!name) return fail(GM_ERR_ARG, "gm_set_param: null name");
+    if (std::strcmp(name, "lk_seg") == 0) {
+        idx->lk_seg = value;
+        return GM_OK;
+    }
     if (std::strcmp(name, "lv_seg") == 0) {
         idx->lv_seg = value;
         return GM_OK;
