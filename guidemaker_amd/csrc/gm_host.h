@@ -49,6 +49,10 @@ struct gm_index {
     int lv_seg = 0;               // experiments (gm_set_param "lv_seg"): pool segments of the Levenshtein scan, 0 = choose
     int n_simd = 1024;            // CUs x 4
     gm_pigeon* pg = nullptr;      // K1P: block-sorted pool copies + query workspaces (built on first use)
+    // the layout planner's last answer (the enumeration costs ~30 us of host time per query otherwise)
+    int64_t plan_nq = -1;
+    int plan_k = -1, plan_found = 0;
+    gm_pg_layout plan_lay{};
 };
 
 int gm_fail(int code, const std::string& msg);   // records the thread-local error message, returns code

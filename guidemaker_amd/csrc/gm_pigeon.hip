@@ -143,30 +143,62 @@ __global__ __launch_bounds__(1024) void k_cand_hist(const uint2* __restrict__ pl
     }
 }
 
-// per block (blockIdx.x = b): exclusive scan of its buckets -> coff[b][0..nb], cursor[entry] = bucket start
-__global__ __launch_bounds__(1024) void k_cand_offsets(PgKeyArg K, const int* __restrict__ hist, int* __restrict__ cursor) {
-    __shared__ int s[1024];
-    const int b = blockIdx.x;
-    const int e0 = K.ebase[b], nb = K.ebase[b + 1] - e0;
-    const int per = (nb + 1023) / 1024;
-    const int lo = threadIdx.x * per, hi = lo + per < nb ? lo + per : nb;
-    int sum = 0;
-    for (int v = lo; v < hi; ++v) sum += hist[e0 + v];
-    s[threadIdx.x] = sum;
+// ONE workgroup: for every block an exclusive scan of its buckets' candidate counts -> coff[b][0..nb] and the scatter
+// cursors, and in the same pass the chunk table's geometry -- chunks per (block, bucket) entry = ceil(count / 64) x the
+// workgroups an entry's target buckets are split over, their exclusive offsets (cbase), the chunk range of every
+// block (ctr->cstart) and the total -- ; it also clears the per-query counters and leaves the histogram zeroed for the
+// next query.  (Count and chunk sums travel through the scan as one 64-bit word.)
+__global__ __launch_bounds__(1024) void k_cand_offsets(PgKeyArg K, const int* __restrict__ nsub, int* __restrict__ hist,
+                                                       int* __restrict__ cursor, int* __restrict__ cbase,
+                                                       int* __restrict__ ctr_words, int ctr_n_words, int* __restrict__ cstart,
+                                                       int* __restrict__ n_chunks) {
+    __shared__ unsigned long long s[1024];
+    __shared__ int s_chunk_base;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < ctr_n_words; i += 1024) ctr_words[i] = 0;
+    if (tid == 0) s_chunk_base = 0;
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        const int t = threadIdx.x >= d ? s[threadIdx.x - d] : 0;
+    for (int b = 0; b < K.B; ++b) {
+        const int e0 = K.ebase[b], nb = K.ebase[b + 1] - e0, ns = nsub[b];
+        const int per = (nb + 1023) / 1024;
+        const int lo = tid * per, hi = lo + per < nb ? lo + per : nb;
+        unsigned long long sum = 0;
+        for (int v = lo; v < hi; ++v) {
+            const unsigned c = (unsigned)hist[e0 + v];
+            sum += (unsigned long long)c | ((unsigned long long)((c + 63u) / 64u * (unsigned)ns) << 32);
+        }
+        s[tid] = sum;
         __syncthreads();
-        s[threadIdx.x] += t;
+        for (int d = 1; d < 1024; d <<= 1) {
+            const unsigned long long t = tid >= d ? s[tid - d] : 0ull;
+            __syncthreads();
+            s[tid] += t;
+            __syncthreads();
+        }
+        const unsigned long long before = tid ? s[tid - 1] : 0ull, total = s[1023];
+        const int chunk_base = s_chunk_base;
+        int run = (int)(unsigned)before, run_ch = chunk_base + (int)(before >> 32);
+        for (int v = lo; v < hi; ++v) {
+            const int c = hist[e0 + v];
+            K.coff[b][v] = run;
+            cursor[e0 + v] = run;
+            cbase[e0 + v] = run_ch;
+            hist[e0 + v] = 0;
+            run += c;
+            run_ch += (c + 63) / 64 * ns;
+        }
+        __syncthreads();
+        if (tid == 1023) {
+            K.coff[b][nb] = (int)(unsigned)total;
+            cstart[b] = chunk_base;
+            s_chunk_base = chunk_base + (int)(total >> 32);
+        }
         __syncthreads();
     }
-    int run = threadIdx.x ? s[threadIdx.x - 1] : 0;
-    for (int v = lo; v < hi; ++v) {
-        K.coff[b][v] = run;
-        cursor[e0 + v] = run;
-        run += hist[e0 + v];
+    if (tid == 0) {
+        cstart[K.B] = s_chunk_base;
+        *n_chunks = s_chunk_base;
     }
-    if (threadIdx.x == 1023) K.coff[b][nb] = s[1023];
 }
 
 // cperm[b][position] = candidate row; positions handed out per bucket: rank inside the workgroup from an
@@ -250,51 +282,45 @@ __device__ __forceinline__ void pg_entry(const PgLayoutArg& A, int e, int& b, in
     v = e - A.ebase[b];
 }
 
-// chunk-table entries of (block, bucket) entry e: one per chunk of <= 64 candidates and per run of target buckets
-__global__ __launch_bounds__(256) void k_chunk_count(PgLayoutArg A, int* __restrict__ nch) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= A.n_entries) return;
-    int b, v;
-    pg_entry(A, e, b, v);
-    const int cnt = A.coff[b][v + 1] - A.coff[b][v];
-    nch[e] = (cnt + 63) / 64 * A.nsub[b];
-}
-
-// n_chunks = last exclusive offset + last count; cstart[b] = first chunk of block b (the table is block-major)
-__global__ void k_chunk_total(PgLayoutArg A, const int* __restrict__ nch, const int* __restrict__ cbase,
-                              PgCounters* __restrict__ ctr) {
-    const int n = A.n_entries;
-    const int total = n > 0 ? cbase[n - 1] + nch[n - 1] : 0;
-    if (threadIdx.x == 0 && blockIdx.x == 0) ctr->n_chunks = total;
-    if (blockIdx.x == 0 && (int)threadIdx.x <= A.B)
-        ctr->cstart[threadIdx.x] = (int)threadIdx.x < A.B ? cbase[A.ebase[threadIdx.x]] : total;
-}
-
 // one thread per ((block, bucket) entry, run of target buckets)
 __global__ __launch_bounds__(256) void k_fill_chunks(PgLayoutArg A, const int* __restrict__ cbase,
                                                      gm_pg_chunk* __restrict__ chunks, PgCounters* __restrict__ ctr) {
+    __shared__ unsigned long long s_pairs[GM_PG_MAXB];      // pairs per block, summed per workgroup first: thousands of
+    if (threadIdx.x < GM_PG_MAXB) s_pairs[threadIdx.x] = 0ull;      // 64-bit atomics on one address take ~150 us
+    __syncthreads();
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int e = t / A.smax, s = t % A.smax;
-    if (e >= A.n_entries) return;
-    int b, v;
-    pg_entry(A, e, b, v);
-    if (s >= A.nsub[b]) return;
-    const int c0 = A.coff[b][v], c1 = A.coff[b][v + 1];
-    if (c1 <= c0) return;
-    const int n_bk = A.nbk[b], per = A.per[b];
-    const int n_ch = (c1 - c0 + 63) / 64;
-    const int e_lo = s * per, e_hi = e_lo + per < n_bk ? e_lo + per : n_bk;
-    const int lst = A.lbase[b] + s;
-    int w = cbase[e] + s * n_ch;
-    for (int c = c0; c < c1; c += 64, ++w)
-        chunks[w] = gm_pg_chunk{b, v, c, c1 - c < 64 ? c1 - c : 64, e_lo, e_hi, lst, 0};
-    // the 64 x 64 groups the scan evaluates for this run
-    unsigned long long groups = 0;
-    for (int u = e_lo; u < e_hi; ++u) {
-        int add;
-        groups += (unsigned long long)A.bdesc[b][gm::pg_target_bucket(v, u, A.blen[b], A.skiplen[b], add)].y;
+    int b = 0, v = 0;
+    bool live = e < A.n_entries;
+    if (live) {
+        pg_entry(A, e, b, v);
+        live = s < A.nsub[b];
     }
-    atomicAdd(&ctr->bpairs[b], (unsigned long long)n_ch * 64ull * groups * gm::LK_GROUP);      // (summed on the host)
+    int c0 = 0, c1 = 0;
+    if (live) {
+        c0 = A.coff[b][v];
+        c1 = A.coff[b][v + 1];
+        live = c1 > c0;
+    }
+    if (live) {
+        const int n_bk = A.nbk[b], per = A.per[b];
+        const int n_ch = (c1 - c0 + 63) / 64;
+        const int e_lo = s * per, e_hi = e_lo + per < n_bk ? e_lo + per : n_bk;
+        const int lst = A.lbase[b] + s;
+        int w = cbase[e] + s * n_ch;
+        for (int c = c0; c < c1; c += 64, ++w)
+            chunks[w] = gm_pg_chunk{b, v, c, c1 - c < 64 ? c1 - c : 64, e_lo, e_hi, lst, 0};
+        // the 64 x 64 groups the scan evaluates for this run
+        unsigned long long groups = 0;
+        for (int u = e_lo; u < e_hi; ++u) {
+            int add;
+            groups += (unsigned long long)A.bdesc[b][gm::pg_target_bucket(v, u, A.blen[b], A.skiplen[b], add)].y;
+        }
+        atomicAdd(&s_pairs[b], (unsigned long long)n_ch * 64ull * groups * gm::LK_GROUP);
+    }
+    __syncthreads();
+    if (threadIdx.x < GM_PG_MAXB && s_pairs[threadIdx.x] != 0ull)
+        atomicAdd(&ctr->bpairs[threadIdx.x], s_pairs[threadIdx.x]);      // (summed over the blocks on the host)
 }
 
 __global__ __launch_bounds__(256) void k_count_incomplete(const int32_t* __restrict__ counts, const int32_t* __restrict__ d1,
@@ -374,11 +400,14 @@ struct gm_pigeon {
     int64_t k0_cap = 0, k1_cap = 0, r0_cap = 0, r1_cap = 0;
     void* sort_tmp = nullptr;
     size_t sort_tmp_cap = 0;
+    bool hist_dirty = true;       // the histogram buffer has not been zeroed yet (the offsets kernel re-zeroes it after use)
     int *nch = nullptr, *cbase = nullptr, *hist = nullptr, *cursor = nullptr;
     int64_t nch_cap = 0, cbase_cap = 0, hist_cap = 0, cursor_cap = 0;
     gm_pg_chunk* chunks = nullptr;
     int64_t chunks_cap = 0;
     PgCounters* ctr = nullptr;
+    PgCounters* h_ctr = nullptr;      // pinned host copy: the per-query read-backs go straight to it (a pageable
+                                      // destination costs a staging blit of ~25 us per copy)
     int64_t grid = 0;
     uint32_t* lists = nullptr;    // hit lists (gm_pg_blocks::loff / lcap)
     int64_t lists_cap = 0;
@@ -669,6 +698,7 @@ void gm_pg_free(gm_index* idx) {
                     pg->lists, pg->raw_off, pg->inc, pg->q2, pg->ids2, pg->dists2, pg->counts2};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
+    if (pg->h_ctr) (void)hipHostFree(pg->h_ctr);
     delete pg;
     idx->pg = nullptr;
 }
@@ -708,6 +738,8 @@ int gm_pg_prepare(gm_index* idx, const gm_pg_layout* lay, hipStream_t st) {
     if ((rc = ensure_sort_buffers(pg, n))) return rc;
     if (!pg->ctr && hipMalloc(reinterpret_cast<void**>(&pg->ctr), sizeof(PgCounters)) != hipSuccess)
         return gm_fail(GM_ERR_ALLOC, "hipMalloc(K1P counters) failed");
+    if (!pg->h_ctr && hipHostMalloc(reinterpret_cast<void**>(&pg->h_ctr), sizeof(PgCounters), hipHostMallocDefault) != hipSuccess)
+        return gm_fail(GM_ERR_ALLOC, "hipHostMalloc(K1P counters) failed");
     // every pair of a bucket agrees on the copy's own block (a neighbour bucket differs there on known positions):
     // each copy's table leaves its own block out and the scan of that copy's chunks runs the kernel instantiated for
     // the remaining positions (at least 10: the look-up kernels start there)
@@ -867,7 +899,12 @@ int gm_pg_candidates(gm_index* idx, int64_t n_q, hipStream_t st) {
     if (n_q >= (int64_t)1 << 31) return gm_fail(GM_ERR_ARG, "gm_pg_candidates: too many candidates");
     int rc;
     const int n_entries = pg->ebase[pg->B];      // (block, bucket) entries = histogram bins
-    if ((rc = ensure(&pg->hist, &pg->hist_cap, n_entries, "bucket histogram"))) return rc;
+    {
+        const int64_t cap_before = pg->hist_cap;
+        const int* ptr_before = pg->hist;
+        if ((rc = ensure(&pg->hist, &pg->hist_cap, n_entries, "bucket histogram"))) return rc;
+        if (pg->hist_cap != cap_before || pg->hist != ptr_before) pg->hist_dirty = true;
+    }
     if ((rc = ensure(&pg->cursor, &pg->cursor_cap, n_entries, "bucket cursors"))) return rc;
     PgLayoutArg A{};
     A.B = pg->B;
@@ -893,37 +930,25 @@ int gm_pg_candidates(gm_index* idx, int64_t n_q, hipStream_t st) {
         pg->bgrid[b] = ((n_q + 63) / 64 + (1 << (2 * pg->blen[b]))) * pg->nsub[b];
         grid += pg->bgrid[b];
     }
-    // counting sort of the candidates by every block's value: histogram, per-block scan, scatter
+    // counting sort of the candidates by every block's value: histogram, scan (+ chunk-table geometry), scatter
     const int use_lds = n_entries <= 8192 ? 1 : 0;
     const size_t lds = use_lds ? sizeof(int) * (size_t)n_entries : 0;
-    HIP_TRY(hipMemsetAsync(pg->hist, 0, sizeof(int) * (size_t)n_entries, st));
-    hipLaunchKernelGGL(k_cand_hist, grid_for(n_q, 1024), dim3(1024), lds, st, idx->d_q, n_q, K, pg->hist, use_lds);
-    hipLaunchKernelGGL(k_cand_offsets, dim3(pg->B), dim3(1024), 0, st, K, pg->hist, pg->cursor);
-    hipLaunchKernelGGL(k_cand_scatter, grid_for(n_q, 1024), dim3(1024), lds, st, idx->d_q, n_q, K, pg->cursor, use_lds);
-    HIP_TRY(hipGetLastError());
-    // chunk table
     A.smax = pg->smax;
     A.n_entries = n_entries;
-    if ((rc = ensure(&pg->nch, &pg->nch_cap, A.n_entries, "chunk counts"))) return rc;
     if ((rc = ensure(&pg->cbase, &pg->cbase_cap, A.n_entries, "chunk offsets"))) return rc;
     if ((rc = ensure(&pg->chunks, &pg->chunks_cap, grid, "chunk table"))) return rc;
-    HIP_TRY(hipMemsetAsync(pg->ctr, 0, sizeof(PgCounters), st));
-    hipLaunchKernelGGL(k_chunk_count, grid_for(A.n_entries), dim3(256), 0, st, A, pg->nch);
-    {      // exclusive scan of the per-entry chunk counts (rocPRIM; a few thousand entries)
-        size_t bytes = 0;
-        HIP_TRY(rocprim::exclusive_scan(nullptr, bytes, pg->nch, pg->cbase, 0, (size_t)A.n_entries, rocprim::plus<int>(), st));
-        if (bytes > pg->sort_tmp_cap || pg->sort_tmp == nullptr) {
-            if (pg->sort_tmp) (void)hipFree(pg->sort_tmp);
-            pg->sort_tmp = nullptr;
-            pg->sort_tmp_cap = 0;
-            if (hipMalloc(&pg->sort_tmp, bytes ? bytes : 1) != hipSuccess)
-                return gm_fail(GM_ERR_ALLOC, "hipMalloc(scan workspace) failed");
-            pg->sort_tmp_cap = bytes;
-        }
-        HIP_TRY(rocprim::exclusive_scan(pg->sort_tmp, bytes, pg->nch, pg->cbase, 0, (size_t)A.n_entries,
-                                        rocprim::plus<int>(), st));
-        hipLaunchKernelGGL(k_chunk_total, dim3(1), dim3(64), 0, st, A, pg->nch, pg->cbase, pg->ctr);
+    if ((rc = ensure(&pg->nch, &pg->nch_cap, GM_PG_MAXB, "workgroups per entry"))) return rc;
+    if (pg->hist_dirty) {      // (the offsets kernel leaves the histogram zeroed: only a fresh buffer needs this)
+        HIP_TRY(hipMemsetAsync(pg->hist, 0, sizeof(int) * (size_t)pg->hist_cap, st));
+        pg->hist_dirty = false;
     }
+    HIP_TRY(hipMemcpyAsync(pg->nch, pg->nsub, sizeof(int) * GM_PG_MAXB, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_cand_hist, grid_for(n_q, 1024), dim3(1024), lds, st, idx->d_q, n_q, K, pg->hist, use_lds);
+    hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(1024), 0, st, K, pg->nch, pg->hist, pg->cursor, pg->cbase,
+                       reinterpret_cast<int*>(pg->ctr), (int)(sizeof(PgCounters) / sizeof(int)), pg->ctr->cstart,
+                       &pg->ctr->n_chunks);
+    hipLaunchKernelGGL(k_cand_scatter, grid_for(n_q, 1024), dim3(1024), lds, st, idx->d_q, n_q, K, pg->cursor, use_lds);
+    HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_fill_chunks, grid_for((int64_t)A.n_entries * A.smax), dim3(256), 0, st, A, pg->cbase, pg->chunks, pg->ctr);
     HIP_TRY(hipGetLastError());
     pg->grid = grid;
@@ -1052,7 +1077,7 @@ int gm_pg_merge(gm_index* idx, int kcap, int64_t n_q, int k, int32_t* ids, int32
 // number of rows the merge listed as incomplete + the pairs the scan evaluated (one 32-byte read-back; synchronises)
 int gm_pg_incomplete(gm_index* idx, int64_t* n_inc, int64_t* pairs_evaluated, hipStream_t st) {
     gm_pigeon* pg = idx->pg;
-    PgCounters h{};
+    PgCounters& h = *pg->h_ctr;
     HIP_TRY(hipMemcpyAsync(&h, pg->ctr, sizeof(PgCounters), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     *n_inc = h.n_inc;
@@ -1078,10 +1103,9 @@ int gm_pg_count_incomplete(gm_index* idx, int64_t n, int need, const int32_t* co
     HIP_TRY(hipMemsetAsync(&pg->ctr->n_bad, 0, sizeof(int), st));
     hipLaunchKernelGGL(k_count_incomplete, grid_for(n), dim3(256), 0, st, counts, d1, n, need, &pg->ctr->n_bad);
     HIP_TRY(hipGetLastError());
-    int h = 0;
-    HIP_TRY(hipMemcpyAsync(&h, &pg->ctr->n_bad, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&pg->h_ctr->n_bad, &pg->ctr->n_bad, sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    *n_bad = h;
+    *n_bad = pg->h_ctr->n_bad;
     return GM_OK;
 }
 

@@ -317,8 +317,14 @@ int run_hamming_pigeon(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
         if (!gm_pg_layout_make(idx->L, B, expand, len0, vcode >= 8 ? 1 : 0, &lay)) return GM_OK;
     } else if (gm_pg_layout_forced(idx, &lay)) {
         // (gm_set_param "pg_layout": experiments)
-    } else if (!gm_pg_plan(idx->n_db, n_q, idx->L, keff, p_match, &lay)) {
-        return GM_OK;
+    } else {
+        if (idx->plan_nq != n_q || idx->plan_k != keff) {      // (the pool and its composition belong to the handle)
+            idx->plan_found = gm_pg_plan(idx->n_db, n_q, idx->L, keff, p_match, &idx->plan_lay);
+            idx->plan_nq = n_q;
+            idx->plan_k = keff;
+        }
+        if (!idx->plan_found) return GM_OK;
+        lay = idx->plan_lay;
     }
     if ((rc = gm_pg_prepare(idx, &lay, st))) {
         if (forced && rc == GM_ERR_ARG) return GM_OK;      // forced layout not usable for this length
