@@ -15,6 +15,7 @@ MAX_GUIDELEN = 27
 MAX_K = 64
 
 _lib = None
+_torch_lib_dir = None      # set when the HIP runtime in use is the copy shipped with PyTorch
 
 
 class GmHipError(RuntimeError):
@@ -29,6 +30,38 @@ def build(force=False):
     subprocess.check_call(args)
 
 
+def _share_torch_hip_runtime():
+    """PyTorch's ROCm wheels ship their own libamdhip64.so.7 and HSA runtime.  A process that loads the SYSTEM copy
+    first (through libgmhip.so) and imports torch afterwards leaves torch's libraries bound to a runtime they were not
+    built with, and torch then reports "No HIP GPUs are available" (seen on the GPU box: `from guidemaker_amd import
+    _lib; _lib.device_count(); import torch; torch.zeros(1).cuda()`).  When torch is installed, load ITS copy of the
+    runtime before libgmhip.so -- same SONAME, so libgmhip.so binds to it and a later `import torch` finds its own
+    runtime already in place -- without importing torch.  GMHIP_SYSTEM_RUNTIME=1 keeps the system's runtime (for
+    processes that will never import torch)."""
+    global _torch_lib_dir
+    import sys
+    if os.environ.get("GMHIP_SYSTEM_RUNTIME", "0") not in ("", "0"):
+        return
+    if "torch" in sys.modules:      # torch is already in: its runtime is the one loaded
+        _torch_lib_dir = os.path.join(os.path.dirname(sys.modules["torch"].__file__), "lib")
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    d = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    rt = os.path.join(d, "libamdhip64.so")
+    if os.path.exists(rt):
+        try:
+            ctypes.CDLL(rt, mode=ctypes.RTLD_GLOBAL)
+            _torch_lib_dir = d
+        except OSError:
+            pass
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -38,6 +71,7 @@ def lib():
             "guidemaker_amd: %s not found. Build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()' or make -C guidemaker_amd/csrc). "
             "There is no CPU fallback." % LIB_PATH)
+    _share_torch_hip_runtime()
     L = ctypes.CDLL(LIB_PATH)
     c = ctypes
     vp, i64, i32 = c.c_void_p, c.c_int64, c.c_int
@@ -304,7 +338,15 @@ class MultiIndex:
         devs = (ctypes.c_int * len(devices))(*devices)
         self._h = ctypes.c_void_p()
         self.n = int(packed.shape[0])
-        _check(lib().gm_multi_create(_ptr(packed), self.n, guidelen, metric, devs, len(devices), ctypes.byref(self._h)))
+        L = lib()
+        # one RCCL per process, and the one built for the HIP runtime in use: with PyTorch's runtime shared
+        # (_share_torch_hip_runtime) that is PyTorch's librccl.so -- load it before gm_multi_create looks for a copy
+        if _torch_lib_dir and os.path.exists(os.path.join(_torch_lib_dir, "librccl.so")):
+            try:
+                ctypes.CDLL(os.path.join(_torch_lib_dir, "librccl.so"), mode=ctypes.RTLD_LOCAL)
+            except OSError:
+                pass
+        _check(L.gm_multi_create(_ptr(packed), self.n, guidelen, metric, devs, len(devices), ctypes.byref(self._h)))
 
     def devices(self):
         return int(lib().gm_multi_devices(self._h))

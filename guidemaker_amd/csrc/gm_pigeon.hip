@@ -19,7 +19,10 @@
 // host round trip per query is the read-back of the incomplete-row count.
 #include "gm_host.h"
 
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -53,6 +56,29 @@ struct PgCounters {               // device-resident
     int n_bad;                    // re-scanned rows that did not fill under the guessed bound
     int pad;
 };
+
+// The two per-query read-backs (rows left incomplete by the merge; re-scanned rows that did not fill) go through a
+// mailbox in pinned, host-coherent memory: a one-wave kernel copies the counters into it and then raises a sequence
+// number; the host polls that word.  A hipMemcpyAsync + hipStreamSynchronize pair costs ~25 us of idle GPU per
+// read-back on this platform (copy kernel, interrupt, wake-up, next launch), the mailbox ~15.
+struct PgMailbox {
+    PgCounters c;
+    volatile unsigned seq;
+    unsigned pad[3];
+};
+
+__global__ __launch_bounds__(64) void k_publish(const PgCounters* __restrict__ src, PgMailbox* __restrict__ box, unsigned seq) {
+    constexpr int W = (int)(sizeof(PgCounters) / sizeof(int));
+    const int* s = reinterpret_cast<const int*>(src);
+    volatile int* d = reinterpret_cast<volatile int*>(&box->c);
+    for (int i = threadIdx.x; i < W; i += 64) d[i] = s[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        box->seq = seq;
+    }
+}
 
 __global__ __launch_bounds__(256) void k_block_keys(const uint2* __restrict__ planes, int64_t n, int start, int len,
                                                     uint32_t* __restrict__ keys, uint32_t* __restrict__ rows) {
@@ -119,7 +145,11 @@ __device__ __forceinline__ int pg_key(const uint2 e, int start, int len) {
     return key;
 }
 
-// hist[entry] += candidates with that (block, value); LDS-privatised per workgroup when the table fits
+// hist[entry] += candidates with that (block, value); LDS-privatised per workgroup when the table fits.  A workgroup
+// takes T tiles of 1024 candidates: what reaches the device-wide histogram is one atomic per (workgroup, non-empty
+// bucket), and with a few thousand buckets a single tile hardly shares any (1024 candidates touch ~900 of the 4096
+// buckets of a 6-base block) -- T = 4 cuts those atomics by a third and the launch from 19 to 13 us on S1 (the scatter: 53 to 34).
+template <int T>
 __global__ __launch_bounds__(1024) void k_cand_hist(const uint2* __restrict__ planes, int64_t n, PgKeyArg K,
                                                     int* __restrict__ hist, int use_lds) {
     extern __shared__ int s_hist[];
@@ -128,12 +158,15 @@ __global__ __launch_bounds__(1024) void k_cand_hist(const uint2* __restrict__ pl
         for (int e = threadIdx.x; e < n_entries; e += blockDim.x) s_hist[e] = 0;
         __syncthreads();
     }
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        const uint2 e = planes[i];
-        for (int b = 0; b < K.B; ++b) {
-            const int ent = K.ebase[b] + pg_key(e, K.bstart[b], K.blen[b]);
-            if (use_lds) atomicAdd(&s_hist[ent], 1); else atomicAdd(&hist[ent], 1);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int64_t i = ((int64_t)blockIdx.x * T + t) * blockDim.x + threadIdx.x;
+        if (i < n) {
+            const uint2 e = planes[i];
+            for (int b = 0; b < K.B; ++b) {
+                const int ent = K.ebase[b] + pg_key(e, K.bstart[b], K.blen[b]);
+                if (use_lds) atomicAdd(&s_hist[ent], 1); else atomicAdd(&hist[ent], 1);
+            }
         }
     }
     if (use_lds) {
@@ -148,7 +181,10 @@ __global__ __launch_bounds__(1024) void k_cand_hist(const uint2* __restrict__ pl
 // workgroups an entry's target buckets are split over, their exclusive offsets (cbase), the chunk range of every
 // block (ctr->cstart) and the total -- ; it also clears the per-query counters and leaves the histogram zeroed for the
 // next query.  (Count and chunk sums travel through the scan as one 64-bit word.)
-__global__ __launch_bounds__(1024) void k_cand_offsets(PgKeyArg K, const int* __restrict__ nsub, int* __restrict__ hist,
+struct PgSubArg {
+    int n[GM_PG_MAXB];      // workgroups an entry's target buckets are split over, per block
+};
+__global__ __launch_bounds__(1024) void k_cand_offsets(PgKeyArg K, PgSubArg nsub, int* __restrict__ hist,
                                                        int* __restrict__ cursor, int* __restrict__ cbase,
                                                        int* __restrict__ ctr_words, int ctr_n_words, int* __restrict__ cstart,
                                                        int* __restrict__ n_chunks) {
@@ -159,7 +195,7 @@ __global__ __launch_bounds__(1024) void k_cand_offsets(PgKeyArg K, const int* __
     if (tid == 0) s_chunk_base = 0;
     __syncthreads();
     for (int b = 0; b < K.B; ++b) {
-        const int e0 = K.ebase[b], nb = K.ebase[b + 1] - e0, ns = nsub[b];
+        const int e0 = K.ebase[b], nb = K.ebase[b + 1] - e0, ns = nsub.n[b];
         const int per = (nb + 1023) / 1024;
         const int lo = tid * per, hi = lo + per < nb ? lo + per : nb;
         unsigned long long sum = 0;
@@ -202,24 +238,29 @@ __global__ __launch_bounds__(1024) void k_cand_offsets(PgKeyArg K, const int* __
 }
 
 // cperm[b][position] = candidate row; positions handed out per bucket: rank inside the workgroup from an
-// LDS counter, one global atomic per (workgroup, non-empty bucket) for the workgroup's base
+// LDS counter, one global atomic per (workgroup, non-empty bucket) for the workgroup's base; T tiles of 1024
+// candidates per workgroup (see k_cand_hist)
+template <int T>
 __global__ __launch_bounds__(1024) void k_cand_scatter(const uint2* __restrict__ planes, int64_t n, PgKeyArg K,
                                                        int* __restrict__ cursor, int use_lds) {
     extern __shared__ int s_cnt[];      // [n_entries] counts, then reused as bases
     const int n_entries = K.ebase[K.B];
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int ent[GM_PG_MAXB], rank[GM_PG_MAXB];
+    int ent[T][GM_PG_MAXB], rank[T][GM_PG_MAXB];
     if (use_lds) {
         for (int e = threadIdx.x; e < n_entries; e += blockDim.x) s_cnt[e] = 0;
         __syncthreads();
     }
-    if (i < n) {
-        const uint2 e = planes[i];
 #pragma unroll
-        for (int b = 0; b < GM_PG_MAXB; ++b) {
-            if (b < K.B) {
-                ent[b] = K.ebase[b] + pg_key(e, K.bstart[b], K.blen[b]);
-                rank[b] = use_lds ? atomicAdd(&s_cnt[ent[b]], 1) : atomicAdd(&cursor[ent[b]], 1);
+    for (int t = 0; t < T; ++t) {
+        const int64_t i = ((int64_t)blockIdx.x * T + t) * blockDim.x + threadIdx.x;
+        if (i < n) {
+            const uint2 e = planes[i];
+#pragma unroll
+            for (int b = 0; b < GM_PG_MAXB; ++b) {
+                if (b < K.B) {
+                    ent[t][b] = K.ebase[b] + pg_key(e, K.bstart[b], K.blen[b]);
+                    rank[t][b] = use_lds ? atomicAdd(&s_cnt[ent[t][b]], 1) : atomicAdd(&cursor[ent[t][b]], 1);
+                }
             }
         }
     }
@@ -231,12 +272,16 @@ __global__ __launch_bounds__(1024) void k_cand_scatter(const uint2* __restrict__
         }
         __syncthreads();
     }
-    if (i < n) {
 #pragma unroll
-        for (int b = 0; b < GM_PG_MAXB; ++b) {
-            if (b < K.B) {
-                const int pos = use_lds ? s_cnt[ent[b]] + rank[b] : rank[b];
-                K.cperm[b][pos] = (uint32_t)i;
+    for (int t = 0; t < T; ++t) {
+        const int64_t i = ((int64_t)blockIdx.x * T + t) * blockDim.x + threadIdx.x;
+        if (i < n) {
+#pragma unroll
+            for (int b = 0; b < GM_PG_MAXB; ++b) {
+                if (b < K.B) {
+                    const int pos = use_lds ? s_cnt[ent[t][b]] + rank[t][b] : rank[t][b];
+                    K.cperm[b][pos] = (uint32_t)i;
+                }
             }
         }
     }
@@ -384,6 +429,7 @@ struct gm_pigeon {
     int tune_layout = 0;               // experiments: forced layout, decimal digit pairs (len, radius) per block
     int tune_gap = 0;                  // table gaps: 0 = choose, 1 = common gap (one launch), 2 = per-block gaps
     int tune_run = 128;                // chunk-table entries per XCD run (gm_set_param "pg_run")
+    int tune_msplit = 0;               // lanes per candidate in the merge, 0 = choose (gm_set_param "pg_msplit")
     int bstart[GM_PG_MAXB]{}, blen[GM_PG_MAXB]{};
     int ebase[GM_PG_MAXB + 1]{};
     // pool side
@@ -406,8 +452,9 @@ struct gm_pigeon {
     gm_pg_chunk* chunks = nullptr;
     int64_t chunks_cap = 0;
     PgCounters* ctr = nullptr;
-    PgCounters* h_ctr = nullptr;      // pinned host copy: the per-query read-backs go straight to it (a pageable
-                                      // destination costs a staging blit of ~25 us per copy)
+    PgMailbox* box = nullptr;         // pinned, host-coherent mailbox of the per-query read-backs (k_publish)
+    PgMailbox* box_dev = nullptr;     // ... its device address
+    unsigned box_seq = 0;
     int64_t grid = 0;
     uint32_t* lists = nullptr;    // hit lists (gm_pg_blocks::loff / lcap)
     int64_t lists_cap = 0;
@@ -680,6 +727,11 @@ int gm_pg_set_param(gm_index* idx, const char* name, int value) {
         idx->pg->tune_debug = value;
         return GM_OK;
     }
+    if (std::strcmp(name, "pg_msplit") == 0) {
+        if (value != 0 && value != 1 && value != 2 && value != 4) return gm_fail(GM_ERR_ARG, "pg_msplit: 0, 1, 2 or 4");
+        idx->pg->tune_msplit = value;
+        return GM_OK;
+    }
     if (std::strcmp(name, "pg_run") == 0) {
         if (value < 1 || value > 65536) return gm_fail(GM_ERR_ARG, "pg_run: 1..65536");
         idx->pg->tune_run = value;
@@ -698,7 +750,7 @@ void gm_pg_free(gm_index* idx) {
                     pg->lists, pg->raw_off, pg->inc, pg->q2, pg->ids2, pg->dists2, pg->counts2};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
-    if (pg->h_ctr) (void)hipHostFree(pg->h_ctr);
+    if (pg->box) (void)hipHostFree(pg->box);
     delete pg;
     idx->pg = nullptr;
 }
@@ -738,8 +790,13 @@ int gm_pg_prepare(gm_index* idx, const gm_pg_layout* lay, hipStream_t st) {
     if ((rc = ensure_sort_buffers(pg, n))) return rc;
     if (!pg->ctr && hipMalloc(reinterpret_cast<void**>(&pg->ctr), sizeof(PgCounters)) != hipSuccess)
         return gm_fail(GM_ERR_ALLOC, "hipMalloc(K1P counters) failed");
-    if (!pg->h_ctr && hipHostMalloc(reinterpret_cast<void**>(&pg->h_ctr), sizeof(PgCounters), hipHostMallocDefault) != hipSuccess)
-        return gm_fail(GM_ERR_ALLOC, "hipHostMalloc(K1P counters) failed");
+    if (!pg->box) {
+        if (hipHostMalloc(reinterpret_cast<void**>(&pg->box), sizeof(PgMailbox), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
+            return gm_fail(GM_ERR_ALLOC, "hipHostMalloc(K1P mailbox) failed");
+        std::memset(pg->box, 0, sizeof(PgMailbox));
+        if (hipHostGetDevicePointer(reinterpret_cast<void**>(&pg->box_dev), pg->box, 0) != hipSuccess)
+            return gm_fail(GM_ERR_ALLOC, "hipHostGetDevicePointer(K1P mailbox) failed");
+    }
     // every pair of a bucket agrees on the copy's own block (a neighbour bucket differs there on known positions):
     // each copy's table leaves its own block out and the scan of that copy's chunks runs the kernel instantiated for
     // the remaining positions (at least 10: the look-up kernels start there)
@@ -937,17 +994,24 @@ int gm_pg_candidates(gm_index* idx, int64_t n_q, hipStream_t st) {
     A.n_entries = n_entries;
     if ((rc = ensure(&pg->cbase, &pg->cbase_cap, A.n_entries, "chunk offsets"))) return rc;
     if ((rc = ensure(&pg->chunks, &pg->chunks_cap, grid, "chunk table"))) return rc;
-    if ((rc = ensure(&pg->nch, &pg->nch_cap, GM_PG_MAXB, "workgroups per entry"))) return rc;
     if (pg->hist_dirty) {      // (the offsets kernel leaves the histogram zeroed: only a fresh buffer needs this)
         HIP_TRY(hipMemsetAsync(pg->hist, 0, sizeof(int) * (size_t)pg->hist_cap, st));
         pg->hist_dirty = false;
     }
-    HIP_TRY(hipMemcpyAsync(pg->nch, pg->nsub, sizeof(int) * GM_PG_MAXB, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_cand_hist, grid_for(n_q, 1024), dim3(1024), lds, st, idx->d_q, n_q, K, pg->hist, use_lds);
-    hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(1024), 0, st, K, pg->nch, pg->hist, pg->cursor, pg->cbase,
+    PgSubArg nsub{};
+    for (int b = 0; b < pg->B; ++b) nsub.n[b] = pg->nsub[b];
+    // tiles of 1024 candidates per workgroup: as many as leave ~128 workgroups
+    const int tiles = n_q >= (int64_t)1024 * 128 * 4 ? 4 : (n_q >= (int64_t)1024 * 128 * 2 ? 2 : 1);
+    const dim3 cgrid = grid_for(n_q, 1024 * tiles);
+    if (tiles == 4) hipLaunchKernelGGL(k_cand_hist<4>, cgrid, dim3(1024), lds, st, idx->d_q, n_q, K, pg->hist, use_lds);
+    else if (tiles == 2) hipLaunchKernelGGL(k_cand_hist<2>, cgrid, dim3(1024), lds, st, idx->d_q, n_q, K, pg->hist, use_lds);
+    else hipLaunchKernelGGL(k_cand_hist<1>, cgrid, dim3(1024), lds, st, idx->d_q, n_q, K, pg->hist, use_lds);
+    hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(1024), 0, st, K, nsub, pg->hist, pg->cursor, pg->cbase,
                        reinterpret_cast<int*>(pg->ctr), (int)(sizeof(PgCounters) / sizeof(int)), pg->ctr->cstart,
                        &pg->ctr->n_chunks);
-    hipLaunchKernelGGL(k_cand_scatter, grid_for(n_q, 1024), dim3(1024), lds, st, idx->d_q, n_q, K, pg->cursor, use_lds);
+    if (tiles == 4) hipLaunchKernelGGL(k_cand_scatter<4>, cgrid, dim3(1024), lds, st, idx->d_q, n_q, K, pg->cursor, use_lds);
+    else if (tiles == 2) hipLaunchKernelGGL(k_cand_scatter<2>, cgrid, dim3(1024), lds, st, idx->d_q, n_q, K, pg->cursor, use_lds);
+    else hipLaunchKernelGGL(k_cand_scatter<1>, cgrid, dim3(1024), lds, st, idx->d_q, n_q, K, pg->cursor, use_lds);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_fill_chunks, grid_for((int64_t)A.n_entries * A.smax), dim3(256), 0, st, A, pg->cbase, pg->chunks, pg->ctr);
     HIP_TRY(hipGetLastError());
@@ -1061,25 +1125,64 @@ int gm_pg_merge(gm_index* idx, int kcap, int64_t n_q, int k, int32_t* ids, int32
     gm_pigeon* pg = idx->pg;
     int rc;
     if ((rc = ensure(&pg->inc, &pg->inc_cap, n_q, "incomplete rows"))) return rc;
-    const dim3 grid = grid_for(n_q * gm::PG_MERGE_SPLIT), block(256);
     const int nr = nearest ? 1 : 0;
     int* n_inc = &pg->ctr->n_inc;
+    int split = kcap >= 20 ? 2 : 4;      // (S4, k = 20: 15.3 / 15.0 / 15.8 ms per query with 1 / 2 / 4; S1, k = 10: 1.23 / 1.15 / 1.13)
+    if (pg->tune_msplit > 0) split = pg->tune_msplit;
+    const dim3 grid = grid_for(n_q * split), block(256);
+#define GM_MERGE(KC, SP) hipLaunchKernelGGL((gm::k_merge_hits<KC, SP>), grid, block, 0, st, pg->blocks, pg->lists, n_q, k, ids, dists, counts, nr, pg->inc, n_inc)
+#define GM_MERGE_KC(KC) do { if (split == 1) GM_MERGE(KC, 1); else if (split == 2) GM_MERGE(KC, 2); else GM_MERGE(KC, 4); } while (0)
     switch (kcap) {
-        case 1: hipLaunchKernelGGL(gm::k_merge_hits<1>, grid, block, 0, st, pg->blocks, pg->lists, n_q, k, ids, dists, counts, nr, pg->inc, n_inc); break;
-        case 5: hipLaunchKernelGGL(gm::k_merge_hits<5>, grid, block, 0, st, pg->blocks, pg->lists, n_q, k, ids, dists, counts, nr, pg->inc, n_inc); break;
-        case 10: hipLaunchKernelGGL(gm::k_merge_hits<10>, grid, block, 0, st, pg->blocks, pg->lists, n_q, k, ids, dists, counts, nr, pg->inc, n_inc); break;
-        default: hipLaunchKernelGGL(gm::k_merge_hits<20>, grid, block, 0, st, pg->blocks, pg->lists, n_q, k, ids, dists, counts, nr, pg->inc, n_inc); break;
+        case 1: GM_MERGE_KC(1); break;
+        case 5: GM_MERGE_KC(5); break;
+        case 10: GM_MERGE_KC(10); break;
+        default: GM_MERGE_KC(20); break;
     }
+#undef GM_MERGE_KC
+#undef GM_MERGE
     HIP_TRY(hipGetLastError());
     return GM_OK;
 }
 
-// number of rows the merge listed as incomplete + the pairs the scan evaluated (one 32-byte read-back; synchronises)
+// the counters as of this point of the stream, in pg->box->c: publish + poll (falls back to a stream synchronisation
+// when the word does not arrive within a second -- a failed launch upstream, or a platform that does not make the
+// store visible while the stream runs)
+static int pg_read_counters(gm_pigeon* pg, hipStream_t st) {
+    static const bool polled = [] {      // GM_PG_MAILBOX=0: plain copy + stream synchronisation
+        const char* e = std::getenv("GM_PG_MAILBOX");
+        return !(e && e[0] == '0');
+    }();
+    if (!polled) {
+        HIP_TRY(hipMemcpyAsync(&pg->box->c, pg->ctr, sizeof(PgCounters), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return GM_OK;
+    }
+    const unsigned seq = ++pg->box_seq;
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, pg->ctr, pg->box_dev, seq);
+    HIP_TRY(hipGetLastError());
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0; pg->box->seq != seq; ++spins) {
+        if ((spins & 0x3ff) == 0x3ff &&
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 1.0) {
+            HIP_TRY(hipStreamSynchronize(st));
+            if (pg->box->seq != seq) {
+                HIP_TRY(hipMemcpy(&pg->box->c, pg->ctr, sizeof(PgCounters), hipMemcpyDeviceToHost));
+                pg->box->seq = seq;
+            }
+            break;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return GM_OK;
+}
+
+// number of rows the merge listed as incomplete + the pairs the scan evaluated (one read-back; waits for the stream
+// to reach this point)
 int gm_pg_incomplete(gm_index* idx, int64_t* n_inc, int64_t* pairs_evaluated, hipStream_t st) {
     gm_pigeon* pg = idx->pg;
-    PgCounters& h = *pg->h_ctr;
-    HIP_TRY(hipMemcpyAsync(&h, pg->ctr, sizeof(PgCounters), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    int rc;
+    if ((rc = pg_read_counters(pg, st))) return rc;
+    const PgCounters h = pg->box->c;
     *n_inc = h.n_inc;
     *pairs_evaluated = 0;
     for (int b = 0; b < GM_PG_MAXB; ++b) {
@@ -1103,9 +1206,9 @@ int gm_pg_count_incomplete(gm_index* idx, int64_t n, int need, const int32_t* co
     HIP_TRY(hipMemsetAsync(&pg->ctr->n_bad, 0, sizeof(int), st));
     hipLaunchKernelGGL(k_count_incomplete, grid_for(n), dim3(256), 0, st, counts, d1, n, need, &pg->ctr->n_bad);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(&pg->h_ctr->n_bad, &pg->ctr->n_bad, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    *n_bad = pg->h_ctr->n_bad;
+    int rc;
+    if ((rc = pg_read_counters(pg, st))) return rc;
+    *n_bad = pg->box->c.n_bad;
     return GM_OK;
 }
 

@@ -36,7 +36,6 @@
 namespace gm {
 
 constexpr int PG_QCAP = 128;          // ring of queued hit words per wave (a flush takes 64, a group adds <= 64)
-constexpr int PG_MERGE_SPLIT = 4;     // threads per candidate in k_merge_hits
 
 // dynamic LDS of k_hamming_scan_pg<L>: two DMA buffers of two groups each, the ring, per-candidate state
 __host__ __device__ constexpr int pg_pair_words(int L) { return 2 * lk_group_words(L); }
@@ -288,24 +287,25 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
     if (valid) lists[qi * row_words + ch.lst] = (uint32_t)Q.cnt[lane];      // every (list, candidate) pair has exactly one writer
 }
 
-// K1P merge: PG_MERGE_SPLIT adjacent lanes per candidate, each folding every PG_MERGE_SPLIT-th hit list into its
+// K1P merge: SPLIT adjacent lanes per candidate (4 for lists of <= 10 keys, where the kernel waits for memory; fewer
+// for 20 keys, where the sorted-insert ripples of a divergent wave are the cost), each folding every SPLIT-th hit list into its
 // own register list (duplicates taken once), then lane 0 of the group takes the other lists over by shuffles and
 // writes the row.  A row that is not exact -- fewer than k entries, or a list that overflowed -- is written as
 // incomplete (count 0 / distance -1) and its index appended to `inc` (inc_count) for the plain scan.
-template <int KCAP>
+template <int KCAP, int SPLIT>
 __global__ void k_merge_hits(gm_pg_blocks P, const uint32_t* __restrict__ lists, int64_t n_q, int k,
                              int32_t* __restrict__ ids, int32_t* __restrict__ dists, int32_t* __restrict__ counts,
                              int nearest, int32_t* __restrict__ inc, int* __restrict__ inc_count) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int sub = (int)(t % PG_MERGE_SPLIT);
-    const int64_t qi_raw = t / PG_MERGE_SPLIT;
+    const int sub = (int)(t % SPLIT);
+    const int64_t qi_raw = t / SPLIT;
     const bool valid = qi_raw < n_q;
     const int64_t qi = valid ? qi_raw : n_q - 1;      // (whole groups stay in the shuffles)
     RegList<KCAP> list;
     list.init(k, nullptr, 0);
     int overflow = 0;
     const uint32_t* __restrict__ row = lists + qi * P.row_words;      // [counts][keys of list 0][keys of list 1] ...
-    for (int l = sub; l < P.n_lists; l += PG_MERGE_SPLIT) {
+    for (int l = sub; l < P.n_lists; l += SPLIT) {
         const int lcap = P.lcap[l];                    // multiple of 4
         int c = (int)row[l];
         if (c > lcap) {
@@ -321,13 +321,13 @@ __global__ void k_merge_hits(gm_pg_blocks P, const uint32_t* __restrict__ lists,
                 if (base + j < c && kk[j] + 1u < list.v[KCAP - 1]) list.insert_unique(kk[j]);
         }
     }
-    // shuffle tree over the PG_MERGE_SPLIT lanes of a candidate: lane s takes the list of lane s + off over
+    // shuffle tree over the SPLIT lanes of a candidate: lane s takes the list of lane s + off over
 #pragma unroll
-    for (int off = PG_MERGE_SPLIT / 2; off >= 1; off >>= 1) {
-        overflow |= __shfl_down(overflow, off, PG_MERGE_SPLIT);
+    for (int off = SPLIT / 2; off >= 1; off >>= 1) {
+        overflow |= __shfl_down(overflow, off, SPLIT);
 #pragma unroll
         for (int i = 0; i < KCAP; ++i) {
-            const uint32_t v = __shfl_down(list.v[i], off, PG_MERGE_SPLIT);
+            const uint32_t v = __shfl_down(list.v[i], off, SPLIT);
             // (a partner's entries ascend: nothing that cannot beat the current k-th needs the 3 KCAP-op insert)
             if (sub < off && v != 0u && v < list.v[KCAP - 1]) list.insert_unique(v - 1u);
         }

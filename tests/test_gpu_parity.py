@@ -738,6 +738,35 @@ def test_multi_device_entry_matches_single_device():
     assert out.returncode == 0 and "multi ok" in out.stdout, out.stdout + out.stderr
 
 
+_ORDER_CHILD = r"""
+import sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from guidemaker_amd import _lib
+idx = _lib.Index(np.arange(5000, dtype=np.uint64) * 977, 20, _lib.METRIC_HAMMING, 0)
+ids, dists, counts = idx.knn(np.arange(10, dtype=np.uint64) * 977, 2)
+assert (dists[:, 0] == 0).all()
+import torch                                   # AFTER libgmhip.so has initialised the GPU
+x = torch.arange(4).cuda() + 1
+assert x.cpu().tolist() == [1, 2, 3, 4]
+ids2, _, _ = idx.knn(np.arange(10, dtype=np.uint64) * 977, 2)
+assert (ids2 == ids).all()
+print("order ok")
+"""
+
+
+def test_library_first_then_torch_in_one_process():
+    """`import guidemaker_amd` (libgmhip.so -> HIP runtime) BEFORE `import torch`: PyTorch ships its own copy of the
+    runtime under the same SONAME, and with the system copy loaded first torch reported "No HIP GPUs are available"
+    (_lib._share_torch_hip_runtime loads torch's copy first when torch is installed)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _ORDER_CHILD, root], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "order ok" in out.stdout, out.stdout + out.stderr
+
+
 # ------------------------------------------------------------------ every guide length, both metrics (SURVEY.md 4(iii))
 @pytest.mark.parametrize("L", list(range(10, 28)))
 def test_every_guide_length_matches_oracle(oracle, L):
