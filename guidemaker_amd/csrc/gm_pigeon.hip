@@ -203,15 +203,27 @@ __global__ __launch_bounds__(1024) void k_cand_offsets(PgKeyArg K, PgSubArg nsub
             const unsigned c = (unsigned)hist[e0 + v];
             sum += (unsigned long long)c | ((unsigned long long)((c + 63u) / 64u * (unsigned)ns) << 32);
         }
-        s[tid] = sum;
-        __syncthreads();
-        for (int d = 1; d < 1024; d <<= 1) {
-            const unsigned long long t = tid >= d ? s[tid - d] : 0ull;
-            __syncthreads();
-            s[tid] += t;
-            __syncthreads();
+        // inclusive scan over the 1024 threads: shuffles inside a wave, the 16 wave totals through LDS
+        unsigned long long inc = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long t = __shfl_up(inc, d, 64);
+            if ((tid & 63) >= d) inc += t;
         }
-        const unsigned long long before = tid ? s[tid - 1] : 0ull, total = s[1023];
+        if ((tid & 63) == 63) s[tid >> 6] = inc;
+        __syncthreads();
+        if (tid < 64) {
+            unsigned long long w = tid < 16 ? s[tid] : 0ull;
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) {
+                const unsigned long long t = __shfl_up(w, d, 64);
+                if (tid >= d) w += t;
+            }
+            if (tid < 16) s[32 + tid] = w;      // inclusive totals of waves 0 .. tid
+        }
+        __syncthreads();
+        const unsigned long long wave_before = (tid >> 6) ? s[32 + (tid >> 6) - 1] : 0ull;
+        const unsigned long long before = wave_before + inc - sum, total = s[32 + 15];
         const int chunk_base = s_chunk_base;
         int run = (int)(unsigned)before, run_ch = chunk_base + (int)(before >> 32);
         for (int v = lo; v < hi; ++v) {
@@ -266,9 +278,20 @@ __global__ __launch_bounds__(1024) void k_cand_scatter(const uint2* __restrict__
     }
     if (use_lds) {
         __syncthreads();
-        for (int e = threadIdx.x; e < n_entries; e += blockDim.x) {
-            const int c = s_cnt[e];
-            s_cnt[e] = c != 0 ? atomicAdd(&cursor[e], c) : 0;
+        // the workgroup's base in every bucket it touched: the returning atomics of a thread's (up to 8) entries are
+        // independent -- issue them back to back instead of one memory round trip per loop iteration
+        int cs[8], bs[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = threadIdx.x + j * 1024;
+            cs[j] = e < n_entries ? s_cnt[e] : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bs[j] = cs[j] != 0 ? atomicAdd(&cursor[threadIdx.x + j * 1024], cs[j]) : 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = threadIdx.x + j * 1024;
+            if (e < n_entries) s_cnt[e] = bs[j];
         }
         __syncthreads();
     }
