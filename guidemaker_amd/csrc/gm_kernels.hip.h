@@ -406,43 +406,64 @@ __global__ __launch_bounds__(WAVE) void k_leven_nearest(const uint2* __restrict_
 // ---------------------------------------------------------------------------------------------
 constexpr int CFD_PER_THREAD = 4;      // pairs per thread: all eight operand loads are in flight before the products
 
-__device__ __forceinline__ double cfd_product(uint64_t a, uint64_t b, int L, const double* __restrict__ smm) {
-    double score = 1.0;
-    const int p0 = L > 20 ? L - 20 : 0;
-    // only mismatching positions contribute (the reference multiplies only where wt[i] != off[i],
-    // cfd_score_calculator.py:79-83); walk them in ascending position = the reference's product order
-    const uint64_t x = a ^ b;
-    uint64_t m = (x | (x >> 1)) & 0x5555555555555555ull;
-    m &= ~0ull << (2 * p0);
-    if (L < 32) m &= (1ull << (2 * L)) - 1ull;
-    while (m != 0ull) {
-        const int bit = __builtin_ctzll(m);
-        m &= m - 1ull;
+// one 32-bit half of the packed pair: positions pos0 .. pos0 + 15 (2 bits each), mismatch flags m at the even bits
+__device__ __forceinline__ double cfd_half(double score, uint32_t a, uint32_t b, uint32_t m, int tbase,
+                                           const double* __restrict__ smm) {
+    while (m != 0u) {
+        const int bit = __builtin_ctz(m);      // = 2 x (position - pos0)
+        m &= m - 1u;
         const int r = (int)((a >> bit) & 3u);
         const int o = (int)((b >> bit) & 3u);
-        score *= smm[(20 + (bit >> 1) - L) * 16 + r * 4 + (3 - o)];
+        score *= smm[tbase + bit * 8 + r * 4 - o];      // ((20 + p - L) * 16 + r * 4 + 3 - o), p * 16 = bit * 8
     }
     return score;
 }
 
+__device__ __forceinline__ double cfd_product(uint64_t a, uint64_t b, int L, const double* __restrict__ smm) {
+    const int p0 = L > 20 ? L - 20 : 0;
+    // only mismatching positions contribute (the reference multiplies only where wt[i] != off[i],
+    // cfd_score_calculator.py:79-83); walk them in ascending position = the reference's product order.  The walk runs
+    // on the two 32-bit halves of the words (positions 0-15, then 16-31): 64-bit ctz / shifts cost twice the instructions.
+    const uint64_t x = a ^ b;
+    uint64_t m = (x | (x >> 1)) & 0x5555555555555555ull;
+    m &= ~0ull << (2 * p0);
+    if (L < 32) m &= (1ull << (2 * L)) - 1ull;
+    const int tbase = (20 - L) * 16 + 3;
+    double score = cfd_half(1.0, (uint32_t)a, (uint32_t)b, (uint32_t)m, tbase, smm);
+    return cfd_half(score, (uint32_t)(a >> 32), (uint32_t)(b >> 32), (uint32_t)(m >> 32), tbase + 16 * 16, smm);
+}
+
+// The score table sits in LDS GM_CFD_COPIES times, every copy shifted by 16 banks against the one before, and a lane
+// reads the copy (lane & (COPIES - 1)): the 64 look-ups of a wave are random 8-byte entries of a 2.5 KB table -- ten
+// entries per bank pair -- and with one copy a ds_read_b64 serialises ~5 ways.
+#ifndef GM_CFD_COPIES
+#define GM_CFD_COPIES 4
+#endif
+constexpr int CFD_COPY_STRIDE = 320 + 8;      // doubles: 2 624 bytes = 10 x 256 + 64: each copy starts 16 banks further on
+
 static __global__ __launch_bounds__(256) void k_cfd(const uint64_t* __restrict__ guides, const uint64_t* __restrict__ offs,
                                                     int64_t n, int L, const double* __restrict__ mm,
                                                     double* __restrict__ out) {
-    __shared__ double smm[320];
-    for (int i = threadIdx.x; i < 320; i += blockDim.x) smm[i] = mm[i];
+    __shared__ double smm_all[GM_CFD_COPIES * CFD_COPY_STRIDE];
+    for (int i = threadIdx.x; i < 320; i += blockDim.x) {
+        const double v = mm[i];
+#pragma unroll
+        for (int c = 0; c < GM_CFD_COPIES; ++c) smm_all[c * CFD_COPY_STRIDE + i] = v;
+    }
     __syncthreads();
+    const double* smm = smm_all + (threadIdx.x & (GM_CFD_COPIES - 1)) * CFD_COPY_STRIDE;
     const int64_t base = (int64_t)blockIdx.x * (256 * CFD_PER_THREAD) + threadIdx.x;
     uint64_t a[CFD_PER_THREAD], b[CFD_PER_THREAD];
 #pragma unroll
     for (int j = 0; j < CFD_PER_THREAD; ++j) {
         const int64_t idx = base + j * 256;
-        a[j] = idx < n ? guides[idx] : 0ull;
-        b[j] = idx < n ? offs[idx] : 0ull;
+        a[j] = idx < n ? __builtin_nontemporal_load(guides + idx) : 0ull;
+        b[j] = idx < n ? __builtin_nontemporal_load(offs + idx) : 0ull;
     }
 #pragma unroll
     for (int j = 0; j < CFD_PER_THREAD; ++j) {
         const int64_t idx = base + j * 256;
-        if (idx < n) out[idx] = cfd_product(a[j], b[j], L, smm);
+        if (idx < n) __builtin_nontemporal_store(cfd_product(a[j], b[j], L, smm), out + idx);
     }
 }
 
