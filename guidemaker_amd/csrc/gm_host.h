@@ -36,6 +36,7 @@ struct gm_index {
     void* d_stage = nullptr;      // host-pointer API: packed queries in / results out
     int64_t stage_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t last_ev0 = nullptr, last_ev1 = nullptr;      // the pair the last timed launch was bracketed with
     hipEvent_t evq0 = nullptr, evq1 = nullptr;   // around the whole query (all kernels of one gm_*_dev call)
     bool timed = false;
     std::vector<hipEvent_t> hist0, hist1;   // optional per-launch history (gm_timing_reserve)

@@ -67,7 +67,7 @@ struct PgMailbox {
     unsigned pad[3];
 };
 
-__global__ __launch_bounds__(64) void k_publish(const PgCounters* __restrict__ src, PgMailbox* __restrict__ box, unsigned seq) {
+__global__ __launch_bounds__(64) void k_publish(PgCounters* __restrict__ src, PgMailbox* __restrict__ box, unsigned seq) {
     constexpr int W = (int)(sizeof(PgCounters) / sizeof(int));
     const int* s = reinterpret_cast<const int*>(src);
     volatile int* d = reinterpret_cast<volatile int*>(&box->c);
@@ -77,6 +77,7 @@ __global__ __launch_bounds__(64) void k_publish(const PgCounters* __restrict__ s
     if (threadIdx.x == 0) {
         __threadfence_system();
         box->seq = seq;
+        src->n_bad = 0;      // (read: the next count starts from zero without a memset of its own)
     }
 }
 
@@ -1177,6 +1178,7 @@ static int pg_read_counters(gm_pigeon* pg, hipStream_t st) {
     }();
     if (!polled) {
         HIP_TRY(hipMemcpyAsync(&pg->box->c, pg->ctr, sizeof(PgCounters), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemsetAsync(&pg->ctr->n_bad, 0, sizeof(int), st));
         HIP_TRY(hipStreamSynchronize(st));
         return GM_OK;
     }
@@ -1190,6 +1192,7 @@ static int pg_read_counters(gm_pigeon* pg, hipStream_t st) {
             HIP_TRY(hipStreamSynchronize(st));
             if (pg->box->seq != seq) {
                 HIP_TRY(hipMemcpy(&pg->box->c, pg->ctr, sizeof(PgCounters), hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemset(&pg->ctr->n_bad, 0, sizeof(int)));
                 pg->box->seq = seq;
             }
             break;
@@ -1226,7 +1229,7 @@ int gm_pg_block_info(const gm_index* idx, int b, int* positions, int64_t* pairs)
 int gm_pg_count_incomplete(gm_index* idx, int64_t n, int need, const int32_t* counts, const int32_t* d1,
                            int64_t* n_bad, hipStream_t st) {
     gm_pigeon* pg = idx->pg;
-    HIP_TRY(hipMemsetAsync(&pg->ctr->n_bad, 0, sizeof(int), st));
+    // (n_bad is zero here: the candidate tables' offsets kernel clears the counters, every read-back re-zeroes it)
     hipLaunchKernelGGL(k_count_incomplete, grid_for(n), dim3(256), 0, st, counts, d1, n, need, &pg->ctr->n_bad);
     HIP_TRY(hipGetLastError());
     int rc;
