@@ -53,6 +53,9 @@ struct gm_index {
     // the layout planner's last answer (the enumeration costs ~30 us of host time per query otherwise)
     int64_t plan_nq = -1;
     int plan_k = -1, plan_found = 0;
+    // k (+ 1) for which the planner's layout left more than a third of the candidates incomplete on this pool (repeat
+    // families flood the hit lists): later queries with that k go straight to the plain scan
+    int pg_flooded_k1 = 0;
     gm_pg_layout plan_lay{};
 };
 

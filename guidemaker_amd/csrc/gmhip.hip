@@ -307,6 +307,7 @@ int run_hamming_pigeon(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
         if ((rc = gm_pg_pool_stats(idx, st, &p_match))) return rc;
     }
     gm_pg_layout lay{};
+    bool planned = false;      // the layout is the planner's own (not a test / experiment override)
     if (forced) {
         const int B = idx->variant % 100;
         int expand = vcode == 1 ? 0 : (vcode <= 3 ? 1 : (vcode <= 5 ? vcode - 2 : (vcode <= 7 ? vcode - 4 : vcode - 7)));
@@ -324,7 +325,9 @@ int run_hamming_pigeon(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
             idx->plan_k = keff;
         }
         if (!idx->plan_found) return GM_OK;
+        if (idx->pg_flooded_k1 == keff + 1) return GM_OK;
         lay = idx->plan_lay;
+        planned = true;
     }
     if ((rc = gm_pg_prepare(idx, &lay, st))) {
         if (forced && rc == GM_ERR_ARG) return GM_OK;      // forced layout not usable for this length
@@ -346,6 +349,9 @@ int run_hamming_pigeon(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
         idx->last_evaluated = pairs;
         idx->last_incomplete = n_inc;
     }
+    // A pool of repeat families floods the hit lists and K1P ends up handing most rows to the plain scan: twice the
+    // work of the plain scan alone.  The answer of this query stands (exact either way); remember it for the next.
+    if (planned && n_inc > n_q / 3 && n_q >= 4096) idx->pg_flooded_k1 = keff + 1;
     if (n_inc > 0) {
         const uint2* q2 = nullptr;
         int32_t *ids2 = nullptr, *dists2 = nullptr, *counts2 = nullptr;

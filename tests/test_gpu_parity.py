@@ -695,6 +695,50 @@ def test_fuzz_against_oracle_time_boxed(oracle):
     assert n_cases >= 20
 
 
+def test_repeat_flooded_pool_falls_back_to_plain_scan_next_time(oracle):
+    """A genome made largely of repeat families (40 segments of 5 kb, 60 copies each at 3 % divergence, in 4.6 Mb --
+    tools/repeat_genome_check.py): the hit lists of the pigeonhole-partitioned scan overflow for half the candidates,
+    which then take the plain scan anyway.  The first query is exact all the same; the handle remembers and the second
+    one goes straight to the plain scan -- same answer."""
+    from guidemaker_amd import workloads
+    L, k, size, seglen = 20, 10, 4_641_652, 5000
+    rng = np.random.Generator(np.random.PCG64(99))
+    codes = workloads.synth_genome(size, 0.508, rng)
+    for _ in range(40):
+        src = rng.integers(0, size - seglen)
+        seg = codes[src:src + seglen].copy()
+        for _ in range(60):
+            dst = rng.integers(0, size - seglen)
+            cp = seg.copy()
+            mut = rng.random(seglen) < 0.03
+            cp[mut] = rng.integers(0, 4, size=int(mut.sum()), dtype=np.uint8)
+            codes[dst:dst + seglen] = cp
+    seq = np.frombuffer(b"ACGT", np.uint8)[codes].tobytes().decode()
+    q = core.scan_targets_gpu(seq, "NGG", "3prime", L)["packed"]
+    db = q[np.sort(np.unique(q, return_index=True)[1])]      # first-occurrence order (create_index's dedup)
+    idx = _lib.Index(db, L, _lib.METRIC_HAMMING)
+    try:
+        i1, d1, c1 = idx.knn(q, k)
+        first, rescanned = idx.last_kernel()[0], idx.last_evaluated()[1]
+        i2, d2, c2 = idx.knn(q, k)
+        second = idx.last_kernel()[0]
+        assert (i1 == i2).all() and (d1 == d2).all() and (c1 == c2).all()
+        assert first == "k_hamming_scan_pg" and rescanned > q.shape[0] // 3, (first, rescanned)
+        assert second.startswith("k_hamming_knn_lk"), second
+        rows = rng.choice(q.shape[0], size=400, replace=False)
+        oi, od, oc = oracle.knn(_packed_to_bytes(db, L), _packed_to_bytes(q[rows], L), L, "hamming", k)
+        od = np.where(od >= 0, od // 2, -1)
+        assert (oc == c1[rows]).all() and (od == d1[rows]).all() and (oi == i1[rows]).all()
+    finally:
+        idx.close()
+
+
+def _packed_to_bytes(packed, L):
+    asc = np.frombuffer(b"ACGT", np.uint8)
+    shifts = (2 * np.arange(L, dtype=np.uint64))[None, :]
+    return np.ascontiguousarray(asc[((packed[:, None] >> shifts) & np.uint64(3)).astype(np.uint8)])
+
+
 # ------------------------------------------------------------------ in-library multi-device entry
 _MULTI_CHILD = r"""
 import sys
