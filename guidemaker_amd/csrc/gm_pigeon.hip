@@ -1187,6 +1187,9 @@ static int pg_read_counters(gm_pigeon* pg, hipStream_t st) {
     HIP_TRY(hipGetLastError());
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 0; pg->box->seq != seq; ++spins) {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
         if ((spins & 0x3ff) == 0x3ff &&
             std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 1.0) {
             HIP_TRY(hipStreamSynchronize(st));
