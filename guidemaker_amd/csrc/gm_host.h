@@ -89,6 +89,7 @@ struct gm_lk_args {
     uint32_t* out_keys = nullptr;
     int32_t *ids = nullptr, *dists = nullptr, *counts = nullptr;
     const uint2* q = nullptr;     // candidate planes (nullptr: idx->d_q)
+    int n_tiles = 0;              // scan only the first n_tiles tiles of the pool (0: all) -- K1P's prefix re-scan
 };
 #define GM_DECL_LK(LEN) int gm_launch_lk_L##LEN(gm_index* idx, const gm_lk_args* a, hipStream_t st);
 GM_FOR_EACH_LEN(GM_DECL_LK)
@@ -123,6 +124,17 @@ int gm_pg_gather(gm_index* idx, int64_t n_inc, int k, bool nearest, const uint2*
                  int32_t** dists2, int32_t** counts2, hipStream_t st);
 int gm_pg_scatter(gm_index* idx, int64_t n_inc, int k, bool nearest, int32_t* ids, int32_t* dists, int32_t* counts,
                   hipStream_t st);
+// prefix re-scan of the incomplete rows (gmhip.hip run_hamming_pigeon): fraction of the pool (in id order) that
+// almost surely holds the r + 1 neighbours such a row still needs (1.0: not worth it); the rows' partial K1P lists in
+// the raw list format of the K1L segment lists; fold segment lists + partial list into pg->ids2 / dists2 / counts2
+// (rows that stay short, and rows whose lists had overflowed, come out with count 0); collect those into pg->inc
+double gm_pg_prefix_fraction(const gm_index* idx, int k);
+int gm_pg_partial_keys(gm_index* idx, int64_t n_inc, int kcap, int k, bool nearest, const int32_t* ids, const int32_t* dists,
+                       const int32_t* counts, uint32_t* out_keys, hipStream_t st);
+int gm_pg_merge_prefix(gm_index* idx, int kcap, const uint32_t* keys, int n_lists, int64_t n_inc, int k, bool nearest,
+                       hipStream_t st);
+int gm_pg_collect_bad(gm_index* idx, int64_t n_inc, int need, bool nearest, hipStream_t st);
+int gm_pg_read_bad(gm_index* idx, int64_t* n_bad, hipStream_t st);
 int gm_pg_blocks_of(const gm_index* idx);
 int gm_pg_block_info(const gm_index* idx, int b, int* positions, int64_t* pairs);
 int gm_pg_radius(const gm_index* idx);      // r of the layout in use: every pair within r is enumerated

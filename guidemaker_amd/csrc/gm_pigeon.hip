@@ -24,6 +24,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <utility>
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -54,7 +55,8 @@ struct PgCounters {               // device-resident
     unsigned long long pairs;     // pairs the last K1P launch evaluates (chunks x 64 x scanned groups x 64)
     unsigned long long bpairs[GM_PG_MAXB];      // ... per block
     int n_bad;                    // re-scanned rows that did not fill under the guessed bound
-    int pad;
+    int n_over;                   // incomplete rows whose hit lists overflowed (nothing about them is known)
+    int chist[24];                // the other incomplete rows by the number c < k of neighbours they have within r
 };
 
 // The two per-query read-backs (rows left incomplete by the merge; re-scanned rows that did not fill) go through a
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(256) void k_count_incomplete(const int32_t* __restr
 __global__ __launch_bounds__(256) void k_gather_rows(const uint2* __restrict__ q, const int32_t* __restrict__ inc, int64_t n,
                                                      uint2* __restrict__ q2) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < n) q2[j] = q[inc[j]];
+    if (j < n) q2[j] = q[(uint32_t)inc[j] & ~gm::PG_INC_OVERFLOW];
 }
 
 __global__ __launch_bounds__(256) void k_scatter_rows(const int32_t* __restrict__ inc, int64_t n, int k,
@@ -413,10 +415,44 @@ __global__ __launch_bounds__(256) void k_scatter_rows(const int32_t* __restrict_
     if (t >= n * k) return;
     const int64_t j = t / k;
     const int s = (int)(t % k);
-    const int64_t row = inc[j];
+    const int64_t row = (int64_t)((uint32_t)inc[j] & ~gm::PG_INC_OVERFLOW);
     if (ids != nullptr) ids[row * k + s] = ids2[t];
     dists[row * k + s] = dists2[t];
     if (counts != nullptr && s == 0) counts[row] = counts2[j];
+}
+
+
+// the partial K1P list of every incomplete row (result arrays of its original row) in the raw format of the K1L
+// segment lists: KCAP slots, keys + 1 ascending, unused leading slots 0, empty slots 0xffffffff
+__global__ __launch_bounds__(256) void k_partial_keys(const int32_t* __restrict__ inc, int64_t n, int kcap, int k, int nearest,
+                                                      const int32_t* __restrict__ ids, const int32_t* __restrict__ dists,
+                                                      const int32_t* __restrict__ counts, uint32_t* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * kcap) return;
+    const int64_t j = t / kcap;
+    const int s = (int)(t % kcap) - (kcap - k);      // position in the row's result list
+    uint32_t v;
+    if (s < 0) {
+        v = 0u;
+    } else {
+        const uint32_t e = (uint32_t)inc[j];
+        const int64_t row = (int64_t)(e & ~gm::PG_INC_OVERFLOW);
+        // (nearest-distance mode keeps no ids: an incomplete row there has no hit within r at all)
+        const int c = (e & gm::PG_INC_OVERFLOW) != 0u || nearest ? 0 : counts[row];
+        v = s < c ? ((((uint32_t)dists[row * k + s]) << gm::ID_BITS) | (uint32_t)ids[row * k + s]) + 1u : 0xffffffffu;
+    }
+    out[t] = v;
+}
+
+// rows that are still short after the prefix re-scan (count below `need` / no distance): their ORIGINAL row numbers,
+// compacted into out (order irrelevant), counted in *n_out
+__global__ __launch_bounds__(256) void k_collect_bad(const int32_t* __restrict__ inc, int64_t n, int need,
+                                                     const int32_t* __restrict__ counts2, const int32_t* __restrict__ d1,
+                                                     int32_t* __restrict__ out, int* __restrict__ n_out) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    if (counts2 != nullptr ? counts2[j] < need : d1[j] < 0)
+        out[atomicAdd(n_out, 1)] = (int32_t)((uint32_t)inc[j] & ~gm::PG_INC_OVERFLOW);
 }
 
 template <class T>
@@ -454,6 +490,7 @@ struct gm_pigeon {
     int tune_gap = 0;                  // table gaps: 0 = choose, 1 = common gap (one launch), 2 = per-block gaps
     int tune_run = 128;                // chunk-table entries per XCD run (gm_set_param "pg_run")
     int tune_msplit = 0;               // lanes per candidate in the merge, 0 = choose (gm_set_param "pg_msplit")
+    int tune_prefix = 1;               // 0 = the incomplete rows go straight to the plain re-scan (gm_set_param "pg_prefix")
     int bstart[GM_PG_MAXB]{}, blen[GM_PG_MAXB]{};
     int ebase[GM_PG_MAXB + 1]{};
     // pool side
@@ -489,6 +526,8 @@ struct gm_pigeon {
     gm_pg_blocks blocks{};
     int32_t* inc = nullptr;
     int64_t inc_cap = 0;
+    int32_t* inc_b = nullptr;     // second list of incomplete rows (the prefix re-scan's leftovers; swapped with inc)
+    int64_t inc_b_cap = 0;
     uint2* q2 = nullptr;
     int64_t q2_cap = 0;
     int32_t *ids2 = nullptr, *dists2 = nullptr, *counts2 = nullptr;
@@ -751,6 +790,10 @@ int gm_pg_set_param(gm_index* idx, const char* name, int value) {
         idx->pg->tune_debug = value;
         return GM_OK;
     }
+    if (std::strcmp(name, "pg_prefix") == 0) {
+        idx->pg->tune_prefix = value;
+        return GM_OK;
+    }
     if (std::strcmp(name, "pg_msplit") == 0) {
         if (value != 0 && value != 1 && value != 2 && value != 4) return gm_fail(GM_ERR_ARG, "pg_msplit: 0, 1, 2 or 4");
         idx->pg->tune_msplit = value;
@@ -771,7 +814,7 @@ void gm_pg_free(gm_index* idx) {
     for (int b = 0; b < GM_PG_MAXB; ++b)
         if (pg->cperm[b]) (void)hipFree(pg->cperm[b]);
     void* bufs[] = {pg->k0, pg->k1, pg->r0, pg->r1, pg->sort_tmp, pg->nch, pg->cbase, pg->hist, pg->cursor, pg->chunks, pg->ctr,
-                    pg->lists, pg->raw_off, pg->inc, pg->q2, pg->ids2, pg->dists2, pg->counts2};
+                    pg->lists, pg->raw_off, pg->inc, pg->inc_b, pg->q2, pg->ids2, pg->dists2, pg->counts2};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     if (pg->box) (void)hipHostFree(pg->box);
@@ -1154,7 +1197,7 @@ int gm_pg_merge(gm_index* idx, int kcap, int64_t n_q, int k, int32_t* ids, int32
     int split = kcap >= 20 ? 2 : 4;      // (S4, k = 20: 15.3 / 15.0 / 15.8 ms per query with 1 / 2 / 4; S1, k = 10: 1.23 / 1.15 / 1.13)
     if (pg->tune_msplit > 0) split = pg->tune_msplit;
     const dim3 grid = grid_for(n_q * split), block(256);
-#define GM_MERGE(KC, SP) hipLaunchKernelGGL((gm::k_merge_hits<KC, SP>), grid, block, 0, st, pg->blocks, pg->lists, n_q, k, ids, dists, counts, nr, pg->inc, n_inc)
+#define GM_MERGE(KC, SP) hipLaunchKernelGGL((gm::k_merge_hits<KC, SP>), grid, block, 0, st, pg->blocks, pg->lists, n_q, k, ids, dists, counts, nr, pg->inc, n_inc, &pg->ctr->n_over, pg->ctr->chist)
 #define GM_MERGE_KC(KC) do { if (split == 1) GM_MERGE(KC, 1); else if (split == 2) GM_MERGE(KC, 2); else GM_MERGE(KC, 4); } while (0)
     switch (kcap) {
         case 1: GM_MERGE_KC(1); break;
@@ -1255,6 +1298,105 @@ int gm_pg_gather(gm_index* idx, int64_t n_inc, int k, bool nearest, const uint2*
     *ids2 = nearest ? nullptr : pg->ids2;
     *dists2 = pg->dists2;
     *counts2 = nearest ? nullptr : pg->counts2;
+    return GM_OK;
+}
+
+// Prefix re-scan.  A row the merge left incomplete WITHOUT an overflow knows every target within r (its c < k hits);
+// what it lacks are the k - c targets at distance r + 1 with the smallest ids.  The plain pool is in id order, so a
+// scan of the first fraction f of it finds exactly those as soon as the prefix holds k - c such targets (92 at r + 1
+// in all of S1's pool per row on average; fewer around a row that is short, hence the c-dependent estimate below).
+// f is chosen from the rows at hand -- the merge counts them by c -- so that the prefix pass plus the plain re-scan of
+// what it is expected to leave (overflowed rows included) is cheapest; 1.0 = the plain re-scan of everything is.
+double gm_pg_prefix_fraction(const gm_index* idx, int k) {
+    const gm_pigeon* pg = idx->pg;
+    if (!pg || pg->B < 2 || !pg->tune_prefix || !pg->box) return 1.0;
+    const PgCounters& h = pg->box->c;      // as read back by gm_pg_incomplete
+    const double pm = pg->p_match >= 0.25 ? pg->p_match : 0.25;
+    const int r = gm_pg_radius(idx);
+    const double within = (double)idx->n_db * tail_within(idx->L, r, pm);
+    const double next = (double)idx->n_db * (tail_within(idx->L, r + 1, pm) - tail_within(idx->L, r, pm));
+    if (within <= 0.0 || next <= 0.0) return 1.0;
+    const double ratio = next / within;      // neighbours at r + 1 per neighbour within r
+    int64_t n_short = 0;
+    for (int c = 0; c < k && c < 24; ++c) n_short += h.chist[c];
+    const int64_t n_inc = n_short + h.n_over;
+    if (n_short < 64) return 1.0;
+    // cost model (us; measured on S1 / S3 / S4, scaled by the pool): a plain re-scan of n rows ~ 60 + B n, the prefix
+    // pass ~ 45 + f B n, and whatever it leaves (overflowed rows, rows whose prefix was too thin) pays a plain re-scan
+    const double B = 0.023 * ((double)idx->n_db / 600000.0) * ((double)idx->L / 20.0);
+    const double plain = 60.0 + B * (double)n_inc;
+    double best = 1.0, best_cost = plain;
+    for (double f = 0.05; f <= 0.6001; f += 0.05) {
+        // a row with c neighbours within r sits in a neighbourhood about c / (mean within r) as dense as the average:
+        // it expects f c ratio targets at r + 1 in the prefix and needs k - c of them
+        double left = (double)h.n_over;
+        for (int c = 0; c < k && c < 24; ++c) {
+            if (h.chist[c] == 0) continue;
+            const double mean = f * (c > 0 ? (double)c : 0.5) * ratio;
+            double p_short = 0.0, term = std::exp(-mean);      // P(Poisson(mean) < k - c)
+            for (int j = 0; j < k - c; ++j) {
+                p_short += term;
+                term *= mean / (j + 1);
+            }
+            left += (double)h.chist[c] * (p_short < 1.0 ? p_short : 1.0);
+        }
+        const double cost = 45.0 + f * B * (double)n_inc + (left >= 0.5 ? 60.0 + B * left : 0.0);
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = f;
+        }
+    }
+    return best;
+}
+
+int gm_pg_partial_keys(gm_index* idx, int64_t n_inc, int kcap, int k, bool nearest, const int32_t* ids, const int32_t* dists,
+                       const int32_t* counts, uint32_t* out_keys, hipStream_t st) {
+    gm_pigeon* pg = idx->pg;
+    hipLaunchKernelGGL(k_partial_keys, grid_for(n_inc * kcap), dim3(256), 0, st, pg->inc, n_inc, kcap, k, nearest ? 1 : 0, ids,
+                       dists, counts, out_keys);
+    HIP_TRY(hipGetLastError());
+    return GM_OK;
+}
+
+int gm_pg_merge_prefix(gm_index* idx, int kcap, const uint32_t* keys, int n_lists, int64_t n_inc, int k, bool nearest,
+                       hipStream_t st) {
+    gm_pigeon* pg = idx->pg;
+    constexpr int SP = 16;
+    const dim3 grid = grid_for(n_inc * SP), block(256);
+    const int nr = nearest ? 1 : 0;
+    int32_t* ids2 = nearest ? nullptr : pg->ids2;
+    int32_t* counts2 = nearest ? nullptr : pg->counts2;
+    switch (kcap) {
+        case 1: hipLaunchKernelGGL((gm::k_merge_prefix<1, SP>), grid, block, 0, st, keys, n_lists, pg->inc, n_inc, k, ids2, pg->dists2, counts2, nr); break;
+        case 5: hipLaunchKernelGGL((gm::k_merge_prefix<5, SP>), grid, block, 0, st, keys, n_lists, pg->inc, n_inc, k, ids2, pg->dists2, counts2, nr); break;
+        case 10: hipLaunchKernelGGL((gm::k_merge_prefix<10, SP>), grid, block, 0, st, keys, n_lists, pg->inc, n_inc, k, ids2, pg->dists2, counts2, nr); break;
+        default: hipLaunchKernelGGL((gm::k_merge_prefix<20, SP>), grid, block, 0, st, keys, n_lists, pg->inc, n_inc, k, ids2, pg->dists2, counts2, nr); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return GM_OK;
+}
+
+// the rows the prefix re-scan left short -> pg->inc (the old list becomes the spare); their number arrives in
+// ctr->n_bad with the caller's next read-back (gm_pg_count_incomplete is NOT needed after this)
+int gm_pg_collect_bad(gm_index* idx, int64_t n_inc, int need, bool nearest, hipStream_t st) {
+    gm_pigeon* pg = idx->pg;
+    int rc;
+    if ((rc = ensure(&pg->inc_b, &pg->inc_b_cap, pg->inc_cap > n_inc ? pg->inc_cap : n_inc, "incomplete rows (second list)")))
+        return rc;
+    hipLaunchKernelGGL(k_collect_bad, grid_for(n_inc), dim3(256), 0, st, pg->inc, n_inc, need, nearest ? nullptr : pg->counts2,
+                       nearest ? pg->dists2 : nullptr, pg->inc_b, &pg->ctr->n_bad);
+    HIP_TRY(hipGetLastError());
+    std::swap(pg->inc, pg->inc_b);
+    std::swap(pg->inc_cap, pg->inc_b_cap);
+    return GM_OK;
+}
+
+// ctr->n_bad as of this point of the stream (read-back; re-zeroes it)
+int gm_pg_read_bad(gm_index* idx, int64_t* n_bad, hipStream_t st) {
+    gm_pigeon* pg = idx->pg;
+    int rc;
+    if ((rc = pg_read_counters(pg, st))) return rc;
+    *n_bad = pg->box->c.n_bad;
     return GM_OK;
 }
 

@@ -35,6 +35,7 @@
 
 namespace gm {
 
+constexpr uint32_t PG_INC_OVERFLOW = 0x80000000u;      // flag on an entry of the incomplete-row list: a hit list overflowed
 constexpr int PG_QCAP = 128;          // ring of queued hit words per wave (a flush takes 64, a group adds <= 64)
 
 // dynamic LDS of k_hamming_scan_pg<L>: two DMA buffers of two groups each, the ring, per-candidate state
@@ -295,7 +296,8 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
 template <int KCAP, int SPLIT>
 __global__ void k_merge_hits(gm_pg_blocks P, const uint32_t* __restrict__ lists, int64_t n_q, int k,
                              int32_t* __restrict__ ids, int32_t* __restrict__ dists, int32_t* __restrict__ counts,
-                             int nearest, int32_t* __restrict__ inc, int* __restrict__ inc_count) {
+                             int nearest, int32_t* __restrict__ inc, int* __restrict__ inc_count,
+                             int* __restrict__ over_count, int* __restrict__ chist) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int sub = (int)(t % SPLIT);
     const int64_t qi_raw = t / SPLIT;
@@ -334,11 +336,55 @@ __global__ void k_merge_hits(gm_pg_blocks P, const uint32_t* __restrict__ lists,
     }
     if (sub != 0 || !valid) return;
     const bool full = list.v[KCAP - 1] != RegList<KCAP>::EMPTY;
-    if (overflow || !full) {
+    if (overflow) {      // hits were lost: nothing about this row is known
         list.init(k, nullptr, 0);
+        inc[atomicAdd(inc_count, 1)] = (int32_t)((uint32_t)qi | PG_INC_OVERFLOW);
+        atomicAdd(over_count, 1);
+    } else if (!full) {      // every target within r is in the list (there are fewer than k): kept for the re-scan
         inc[atomicAdd(inc_count, 1)] = (int32_t)qi;
+        int c = 0;
+#pragma unroll
+        for (int s = 0; s < KCAP; ++s) c += (list.v[s] != 0u && list.v[s] != RegList<KCAP>::EMPTY) ? 1 : 0;
+        atomicAdd(&chist[c < 23 ? c : 23], 1);      // (the host sizes the prefix re-scan from this)
     }
     list.store(k, qi, ids, dists, counts, nearest != 0);
+}
+
+// K1P prefix re-scan: fold the n_lists raw lists of a row (the K1L segment lists of the scanned pool prefix and, last,
+// the row's partial K1P list -- they share entries, hence insert_unique) into the top k.  SPLIT lanes per row.  A row
+// that does not reach k entries, or whose K1P lists had overflowed (flag on its inc entry), is written with count 0 /
+// distance -1: it goes on to the plain re-scan.
+template <int KCAP, int SPLIT>
+__global__ void k_merge_prefix(const uint32_t* __restrict__ keys, int n_lists, const int32_t* __restrict__ inc, int64_t n,
+                               int k, int32_t* __restrict__ ids, int32_t* __restrict__ dists, int32_t* __restrict__ counts,
+                               int nearest) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int sub = (int)(t % SPLIT);
+    const int64_t row_raw = t / SPLIT;
+    const bool valid = row_raw < n;
+    const int64_t row = valid ? row_raw : n - 1;
+    RegList<KCAP> list;
+    list.init(k, nullptr, 0);
+    for (int s = sub; s < n_lists; s += SPLIT) {
+        const uint32_t* in = keys + ((int64_t)s * n + row) * KCAP;
+#pragma unroll
+        for (int i = 0; i < KCAP; ++i) {
+            const uint32_t v = in[i];
+            if (v != 0u && v < list.v[KCAP - 1]) list.insert_unique(v - 1u);
+        }
+    }
+#pragma unroll
+    for (int off = SPLIT / 2; off >= 1; off >>= 1) {
+#pragma unroll
+        for (int i = 0; i < KCAP; ++i) {
+            const uint32_t v = __shfl_down(list.v[i], off, SPLIT);
+            if (sub < off && v != 0u && v < list.v[KCAP - 1]) list.insert_unique(v - 1u);
+        }
+    }
+    if (sub != 0 || !valid) return;
+    const bool full = list.v[KCAP - 1] != RegList<KCAP>::EMPTY;
+    if (!full || ((uint32_t)inc[row] & PG_INC_OVERFLOW) != 0u) list.init(k, nullptr, 0);
+    list.store(k, row, ids, dists, counts, nearest != 0);
 }
 
 }  // namespace gm

@@ -111,6 +111,18 @@ int ensure_u32(uint32_t** buf, int64_t* cap, int64_t need) {
 int launch_merge(int kcap, const uint32_t* keys, int n_seg, int64_t n_q, int k, int32_t* ids, int32_t* dists,
                  int32_t* counts, bool nearest, hipStream_t st) {
     const int nr = nearest ? 1 : 0;
+    if (n_seg >= 128 && n_q <= 2048) {      // a handful of candidates, hundreds of lists: a whole wave per candidate
+        constexpr int SP = 64;
+        const dim3 grid((unsigned)((n_q * SP + 255) / 256)), block(256);
+        switch (kcap) {
+            case 1: hipLaunchKernelGGL((gm::k_merge_lists_split<1, SP>), grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
+            case 5: hipLaunchKernelGGL((gm::k_merge_lists_split<5, SP>), grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
+            case 10: hipLaunchKernelGGL((gm::k_merge_lists_split<10, SP>), grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
+            default: hipLaunchKernelGGL((gm::k_merge_lists_split<20, SP>), grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
+        }
+        HIP_TRY(hipGetLastError());
+        return GM_OK;
+    }
     if (n_seg >= 16 && n_q <= 65536) {      // few candidates, many lists: 16 lanes per candidate
         constexpr int SP = 16;
         const dim3 grid((unsigned)((n_q * SP + 255) / 256)), block(256);
@@ -286,6 +298,44 @@ int run_leven_lookup(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* d
                    : launch_merge(kcap, idx->d_keys2, n_seg, n_q, k, ids, dists, counts, false, st);
 }
 
+// K1P prefix re-scan (gm_pg_prefix_fraction): K1L over the first `frac` of the pool (id order) for the n compacted rows
+// under the bound guess_thr, its segment lists + the rows' partial K1P lists folded into pg->ids2 / dists2 / counts2.
+int run_hamming_prefix(gm_index* idx, bool nearest, int64_t n, int k, int kcap, const uint2* q2, int guess_thr, double frac,
+                       const int32_t* ids, const int32_t* dists, const int32_t* counts, hipStream_t st) {
+    gm_lk_args a;
+    a.q = q2;
+    a.kcap = kcap;
+    a.n_q = n;
+    a.k = nearest ? 1 : k;
+    const int64_t chunks = (n + gm::WAVE - 1) / gm::WAVE;
+    int64_t n_tiles_p = (int64_t)std::ceil((double)idx->n_lk_tiles * frac);
+    n_tiles_p += n_tiles_p & 1;
+    if (n_tiles_p < 2) n_tiles_p = 2;
+    if (n_tiles_p > idx->n_lk_tiles) n_tiles_p = idx->n_lk_tiles;
+    int64_t n_seg = ((int64_t)idx->n_simd * 8 + chunks - 1) / chunks;      // about one workgroup per wave slot
+    if (n_seg > 64) n_seg = 64;
+    if (n_seg > n_tiles_p / 2) n_seg = n_tiles_p / 2;
+    if (n_seg < 1) n_seg = 1;
+    int64_t tps = (n_tiles_p + n_seg - 1) / n_seg;
+    tps += tps & 1;
+    n_seg = (n_tiles_p + tps - 1) / tps;
+    int rc;
+    if ((rc = ensure_u32(&idx->d_keys, &idx->keys_cap, (n_seg + 2) * n * kcap))) return rc;
+    uint32_t* seeds = idx->d_keys + (n_seg + 1) * n * kcap;
+    hipLaunchKernelGGL(k_fill_seeds, dim3((unsigned)((n * kcap + 255) / 256)), dim3(256), 0, st, seeds, n, kcap,
+                       ((uint32_t)guess_thr << 27) + 1u);
+    HIP_TRY(hipGetLastError());
+    a.n_seg = (int)n_seg;
+    a.seg_base = 0;
+    a.tiles_per_seg = (int)tps;
+    a.seed_keys = seeds;
+    a.out_keys = idx->d_keys;
+    a.n_tiles = (int)n_tiles_p;
+    if ((rc = launch_lk_len(idx, a, st))) return rc;
+    if ((rc = gm_pg_partial_keys(idx, n, kcap, a.k, nearest, ids, dists, counts, idx->d_keys + n_seg * n * kcap, st))) return rc;
+    return gm_pg_merge_prefix(idx, kcap, idx->d_keys, (int)n_seg + 1, n, a.k, nearest, st);
+}
+
 // K1P (gm_pigeon.hip): exact Hamming k-NN from B block-sorted pool copies, then the plain scan for the few
 // candidates whose merged list did not fill.  Returns through *used whether K1P ran (the layout planner
 // may decide that the plain scan is the better choice for this pool / k).
@@ -356,6 +406,27 @@ int run_hamming_pigeon(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
         const uint2* q2 = nullptr;
         int32_t *ids2 = nullptr, *dists2 = nullptr, *counts2 = nullptr;
         if ((rc = gm_pg_gather(idx, n_inc, keff, nearest, &q2, &ids2, &dists2, &counts2, st))) return rc;
+        // A row that is short without an overflow knows all its neighbours within r; the k - c it lacks are the targets
+        // at r + 1 with the smallest ids, and the first part of the pool (id order) almost surely holds them: scan only
+        // that prefix, fold in the partial lists, and hand the plain re-scan just the rows that are still short (and
+        // those whose lists overflowed).
+        const double frac = gm_pg_prefix_fraction(idx, keff);
+        if (frac <= 0.6) {
+            if ((rc = run_hamming_prefix(idx, nearest, n_inc, keff, kcap, q2, gm_pg_radius(idx) + 2, frac, ids, dists, counts, st)))
+                return rc;
+            if ((rc = gm_pg_scatter(idx, n_inc, keff, nearest, ids, dists, counts, st))) return rc;
+            if ((rc = gm_pg_collect_bad(idx, n_inc, keff, nearest, st))) return rc;
+            int64_t n_left = 0;
+            if ((rc = gm_pg_read_bad(idx, &n_left, st))) return rc;
+            if (std::getenv("GM_DEBUG"))
+                fprintf(stderr, "[gm] prefix re-scan: %lld rows, fraction %.3f, %lld left\n", (long long)n_inc, frac, (long long)n_left);
+            if (n_left == 0) {
+                *used = true;
+                return GM_OK;
+            }
+            n_inc = n_left;
+            if ((rc = gm_pg_gather(idx, n_inc, keff, nearest, &q2, &ids2, &dists2, &counts2, st))) return rc;
+        }
         // these rows have fewer than k neighbours within r (or a flooded slot list): their k-th neighbour is
         // almost surely at r + 1, so scan under the bound d < r + 2 first and fall back to the unseeded scan
         // only if a list still does not fill

@@ -80,6 +80,12 @@ def test_hamming_workload_full_size(oracle, name):
         assert 0 < evaluated < 0.15 * q.shape[0] * db.shape[0]
         _check_properties(pool, ids, dists, counts)
         assert (_hamming_of(pool, ids) == dists).all()                  # reported distances are the true ones
+        # the rows that did not fill within the layout's radius: prefix re-scan by default -- the same answer with
+        # all of them sent to the plain re-scan instead
+        idx.set_param("pg_prefix", 0)
+        ids2, dists2, counts2 = idx.knn(q, k)
+        assert (ids2 == ids).all() and (dists2 == dists).all() and (counts2 == counts).all()
+        idx.set_param("pg_prefix", 1)
         # idempotence
         ids2, dists2, counts2 = idx.knn(q, k)
         assert (ids2 == ids).all() and (dists2 == dists).all() and (counts2 == counts).all()

@@ -695,6 +695,78 @@ def test_fuzz_against_oracle_time_boxed(oracle):
     assert n_cases >= 20
 
 
+def _random_packed(n, L, seed, planted=0.0):
+    rng = np.random.default_rng(seed)
+    codes = rng.integers(0, 4, size=(n, L), dtype=np.uint8)
+    if planted > 0:
+        m = int(n * planted)
+        dst, src = rng.integers(0, n, size=m), rng.integers(0, n, size=m)
+        codes[dst] = codes[src]
+        for _ in range(3):
+            hit = rng.random(m) < 0.67
+            codes[dst[hit], rng.integers(0, L, size=int(hit.sum()))] = rng.integers(0, 4, size=int(hit.sum()))
+    db = np.unique(core.pack_codes(codes))
+    rng.shuffle(db)
+    return db
+
+
+@pytest.mark.parametrize("n,L,k,planted,layout", [(200_000, 20, 3, 0.0, 61515140), (200_000, 20, 3, 0.02, 61515140),
+                                                   (400_000, 20, 6, 0.01, 61515140), (300_000, 20, 10, 0.0, 61515140),
+                                                   (260_000, 23, 5, 0.01, 0), (150_000, 17, 3, 0.0, 0)])
+def test_prefix_rescan_matches_plain_rescan_and_oracle(oracle, n, L, k, planted, layout):
+    """Rows that do not fill within the layout's radius: prefix re-scan (their partial lists + a scan of the pool's first
+    part) against the plain re-scan of all of them ("pg_prefix" = 0), the plain scan (variant 8) and the oracle on the
+    rows with the farthest k-th neighbours (the re-scanned ones are among them)."""
+    db = _random_packed(n, L, seed=400 + L + k, planted=planted)
+    rng = np.random.default_rng(9)
+    q = np.concatenate([db[: n // 2], _random_packed(5000, L, seed=77)])      # pool members + strangers
+    idx = _lib.Index(db, L, _lib.METRIC_HAMMING)
+    try:
+        if layout:      # blocks (6,5,5,4), radii (1,1,1,0) -- bench.py's S1 layout; on these pools it leaves 1 .. 60 % of the rows
+            idx.set_param("pg_layout", layout)
+        ids, dists, counts = idx.knn(q, k)
+        name, rescanned = idx.last_kernel()[0], idx.last_evaluated()[1]
+        if layout:
+            assert name == "k_hamming_scan_pg" and rescanned >= 256, (name, rescanned)
+        idx.set_param("pg_prefix", 0)
+        i0, d0, c0 = idx.knn(q, k)
+        assert (i0 == ids).all() and (d0 == dists).all() and (c0 == counts).all()
+        idx.set_param("pg_prefix", 1)
+        d1 = idx.nearest(q)
+        assert (d1 == dists[:, 0]).all()
+        idx.set_variant(8)
+        i8, d8, c8 = idx.knn(q, k)
+        assert (i8 == ids).all() and (d8 == dists).all() and (c8 == counts).all()
+        far = np.flatnonzero(dists[:, k - 1] >= np.sort(dists[:, k - 1])[-2000])[:1500]
+        rows = np.unique(np.concatenate([far, rng.choice(q.shape[0], size=300, replace=False)]))
+        oi, od, oc = oracle.knn(_packed_to_bytes(db, L), _packed_to_bytes(q[rows], L), L, "hamming", k)
+        od = np.where(od >= 0, od // 2, -1)
+        assert (oc == counts[rows]).all() and (od == dists[rows]).all() and (oi == ids[rows]).all()
+    finally:
+        idx.close()
+
+
+def test_prefix_rescan_nearest_distance(oracle):
+    """Nearest-distance entry (controls): random strangers against a genome-sized pool; rows without a hit inside the
+    layout's radius take the re-scan -- same distances as the plain scan."""
+    L = 20
+    db = _random_packed(600_000, L, seed=31)
+    q = _random_packed(120_000, L, seed=32)
+    idx = _lib.Index(db, L, _lib.METRIC_HAMMING)
+    try:
+        d1 = idx.nearest(q)
+        idx.set_param("pg_prefix", 0)
+        d0 = idx.nearest(q)
+        idx.set_variant(8)
+        d8 = idx.nearest(q)
+        assert (d1 == d8).all() and (d0 == d8).all()
+        rows = np.random.default_rng(3).choice(q.shape[0], size=200, replace=False)
+        _, od, _ = oracle.knn(_packed_to_bytes(db, L), _packed_to_bytes(q[rows], L), L, "hamming", 1)
+        assert (od[:, 0] // 2 == d1[rows]).all()
+    finally:
+        idx.close()
+
+
 def test_repeat_flooded_pool_falls_back_to_plain_scan_next_time(oracle):
     """A genome made largely of repeat families (40 segments of 5 kb, 60 copies each at 3 % divergence, in 4.6 Mb --
     tools/repeat_genome_check.py): the hit lists of the pigeonhole-partitioned scan overflow for half the candidates,
