@@ -53,8 +53,12 @@ int launch_pg_cfg(gm_index* idx, const gm_pg_blocks* blocks, const gm_pg_chunk* 
                   const int* c_end, int64_t grid, int64_t n_q, int k, int thr0, uint32_t* lists, hipStream_t st) {
     (void)idx;
     const size_t lds = gm::pg_lds_bytes(L);
-    hipLaunchKernelGGL((gm::k_hamming_scan_pg<L>), dim3((unsigned)grid), dim3(gm::WAVE), lds, st, *blocks, chunks,
-                       c_begin, c_end, idx->d_q, n_q, k, thr0, lists);
+    if (blocks->cut_id != 0xffffffffu)
+        hipLaunchKernelGGL((gm::k_hamming_scan_pg<L, true>), dim3((unsigned)grid), dim3(gm::WAVE), lds, st, *blocks, chunks,
+                           c_begin, c_end, idx->d_q, n_q, k, thr0, lists);
+    else
+        hipLaunchKernelGGL((gm::k_hamming_scan_pg<L, false>), dim3((unsigned)grid), dim3(gm::WAVE), lds, st, *blocks, chunks,
+                           c_begin, c_end, idx->d_q, n_q, k, thr0, lists);
     HIP_TRY(hipGetLastError());
     return GM_OK;
 }

@@ -455,6 +455,23 @@ __global__ __launch_bounds__(256) void k_collect_bad(const int32_t* __restrict__
         out[atomicAdd(n_out, 1)] = (int32_t)((uint32_t)inc[j] & ~gm::PG_INC_OVERFLOW);
 }
 
+
+// id cut-off: per bucket of a pool copy, the number of its 64-target groups that hold a target with id < cut_id (ids
+// ascend inside a bucket: binary search for the first id >= cut_id)
+__global__ __launch_bounds__(256) void k_bucket_cut(const uint4* __restrict__ recs, const int2* __restrict__ bdesc, int nb,
+                                                    uint32_t cut_id, int* __restrict__ bcut) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nb) return;
+    const int2 d = bdesc[v];
+    const int64_t base = (int64_t)d.x * gm::LK_GROUP;
+    int lo = 0, hi = d.y * gm::LK_GROUP;      // positions of the bucket (padding = id 0xffffffff sorts last)
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (recs[base + mid].z < cut_id) lo = mid + 1; else hi = mid;
+    }
+    bcut[v] = (lo + gm::LK_GROUP - 1) / gm::LK_GROUP;      // lo = targets below the cut-off
+}
+
 template <class T>
 int ensure(T** p, int64_t* cap, int64_t need, const char* what) {
     if (need <= *cap && *p != nullptr) return GM_OK;
@@ -491,6 +508,12 @@ struct gm_pigeon {
     int tune_run = 128;                // chunk-table entries per XCD run (gm_set_param "pg_run")
     int tune_msplit = 0;               // lanes per candidate in the merge, 0 = choose (gm_set_param "pg_msplit")
     int tune_prefix = 1;               // 0 = the incomplete rows go straight to the plain re-scan (gm_set_param "pg_prefix")
+    int tune_cut = 0;                  // id cut-off: 0 = choose, 1 .. 99 = that percentage of the ids, 100 = off ("pg_cut")
+    bool cut_dropped = false;          // the cut-off left more than 1 % of the candidates short on this pool: not used again
+    double cut_f = 1.0;                // fraction of the ids whose distance-r targets are taken (1.0 = no cut-off)
+    uint32_t cut_id = 0xffffffffu;     // ... as an id
+    int* bcut[GM_PG_MAXB]{};           // per copy: groups per bucket that hold an id below the cut-off
+    uint32_t bcut_for = 0xffffffffu;   // the cut-off id the bcut arrays were built for
     int bstart[GM_PG_MAXB]{}, blen[GM_PG_MAXB]{};
     int ebase[GM_PG_MAXB + 1]{};
     // pool side
@@ -565,6 +588,8 @@ void free_pool_side(gm_pigeon* pg) {
         if (pg->recs[b]) (void)hipFree(pg->recs[b]);
         if (pg->bdesc[b]) (void)hipFree(pg->bdesc[b]);
         if (pg->coff[b]) (void)hipFree(pg->coff[b]);
+        if (pg->bcut[b]) (void)hipFree(pg->bcut[b]);
+        pg->bcut[b] = nullptr;
         pg->table[b] = nullptr;
         pg->recs[b] = nullptr;
         pg->bdesc[b] = nullptr;
@@ -572,6 +597,7 @@ void free_pool_side(gm_pigeon* pg) {
     }
     pg->B = 0;
     pg->cap_nq = -1;
+    pg->bcut_for = 0xffffffffu;
 }
 
 double log_choose(int n, int r) { return std::lgamma(n + 1.0) - std::lgamma(r + 1.0) - std::lgamma(n - r + 1.0); }
@@ -788,6 +814,11 @@ int gm_pg_set_param(gm_index* idx, const char* name, int value) {
     }
     if (std::strcmp(name, "pg_debug") == 0) {
         idx->pg->tune_debug = value;
+        return GM_OK;
+    }
+    if (std::strcmp(name, "pg_cut") == 0) {
+        if (value < 0 || value > 100) return gm_fail(GM_ERR_ARG, "pg_cut: 0 (choose), 1..99 (percent of the ids), 100 (off)");
+        idx->pg->tune_cut = value;
         return GM_OK;
     }
     if (std::strcmp(name, "pg_prefix") == 0) {
@@ -1102,7 +1133,10 @@ static void pg_list_capacity(const gm_index* idx, gm_pigeon* pg, int64_t n_q) {
         // expected hits from an own / one-substitution / two-substitution bucket (the pair already has 0 / 1 / 2
         // mismatches on the block)
         double h[3];
-        for (int j = 0; j < 3; ++j) h[j] = (double)pg->max_bucket[b] * tail_within(L - len, r - j, pm);
+        // (id cut-off: of the targets at distance exactly r only the fraction cut_f is taken)
+        for (int j = 0; j < 3; ++j)
+            h[j] = (double)pg->max_bucket[b] * (tail_within(L - len, r - j - 1, pm) +
+                                                pg->cut_f * (tail_within(L - len, r - j, pm) - tail_within(L - len, r - j - 1, pm)));
         for (int s = 0; s < pg->nsub[b]; ++s) {
             const int e_lo = s * pg->per[b], e_hi = e_lo + pg->per[b] < pg->nbk[b] ? e_lo + pg->per[b] : pg->nbk[b];
             double m = 0.0;
@@ -1142,6 +1176,42 @@ int gm_pg_scan(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
     int rc;
     uint64_t lkey = 0;      // the radii of the layout in use (the block lengths are fixed while the copies live)
     for (int b = 0; b < pg->B; ++b) lkey = lkey * 4 + (uint64_t)pg->trad[b] + 1;
+    // Id cut-off.  lam_r targets sit at distance exactly r of a candidate on average, lam_lt closer; the k best need
+    // about k - lam_lt of the former, and ties go to the smaller id: take distance-r hits only from ids below f n_db with
+    // f lam_r = (k - lam_lt)+ + 4 sqrt(k) + 3 (a candidate for which that is not enough ends incomplete and is re-scanned).
+    // Not for k = 1 (the bound follows the best distance there) and not when it would keep most of them anyway.
+    {
+        const double pm = pg->p_match >= 0.25 ? pg->p_match : 0.25;
+        const int r = gm_pg_radius(idx);
+        const double lam_lt = (double)idx->n_db * tail_within(idx->L, r - 1, pm) + 1.0;
+        const double lam_r = (double)idx->n_db * (tail_within(idx->L, r, pm) - tail_within(idx->L, r - 1, pm));
+        double f = 1.0;
+        if (k > 1 && lam_r > 0.0) {
+            const double need = (double)k - lam_lt > 0.0 ? (double)k - lam_lt : 0.0;
+            f = (need + 4.0 * std::sqrt((double)k) + 3.0) / lam_r;
+        }
+        // The estimate is the pool AVERAGE.  With a skewed base composition the candidates differ by orders of magnitude
+        // in how many neighbours they have (S3, gc 0.38: f = 0.44 left 3.5 % of the candidates short instead of 0.13 %):
+        // only near-uniform pools take the cut-off, and a handle on which it still leaves too many rows short drops it.
+        if (pm > 0.2515 || pg->cut_dropped) f = 1.0;
+        if (pg->tune_cut >= 100) f = 1.0;
+        else if (pg->tune_cut > 0 && k > 1) f = pg->tune_cut / 100.0;
+        if (f > 0.75 || f <= 0.0) f = 1.0;
+        const uint32_t cut_id = f < 1.0 ? (uint32_t)std::ceil(f * (double)idx->n_db) : 0xffffffffu;
+        if (f != pg->cut_f) pg->cap_nq = -1;      // the list capacities depend on it
+        pg->cut_f = f;
+        pg->cut_id = cut_id;
+        if (cut_id != 0xffffffffu && pg->bcut_for != cut_id) {
+            for (int b = 0; b < pg->B; ++b) {
+                const int nb = 1 << (2 * pg->blen[b]);
+                if (!pg->bcut[b] && hipMalloc(reinterpret_cast<void**>(&pg->bcut[b]), sizeof(int) * (size_t)nb) != hipSuccess)
+                    return gm_fail(GM_ERR_ALLOC, "hipMalloc(K1P cut-off table) failed");
+                hipLaunchKernelGGL(k_bucket_cut, grid_for(nb), dim3(256), 0, st, pg->recs[b], pg->bdesc[b], nb, cut_id, pg->bcut[b]);
+            }
+            HIP_TRY(hipGetLastError());
+            pg->bcut_for = cut_id;
+        }
+    }
     if (pg->cap_nq != n_q || pg->cap_layout_for != lkey || pg->cap_sub_for != pg->tune_sub) {
         pg_list_capacity(idx, pg, n_q);
         pg->cap_nq = n_q;
@@ -1156,10 +1226,12 @@ int gm_pg_scan(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
         blocks.recs[b] = pg->recs[b];
         blocks.bdesc[b] = pg->bdesc[b];
         blocks.cperm[b] = pg->cperm[b];
+        blocks.bcut[b] = pg->bcut[b];
         blocks.skip[b] = pg->bstart[b];
         blocks.skiplen[b] = pg->skiplen[b];
     }
     blocks.n_blocks = pg->B;
+    blocks.cut_id = pg->cut_id;
     const int thr0 = gm_pg_radius(idx) + 1;      // accept d < thr0, i.e. d <= r
     blocks.run = pg->tune_run;
     blocks.debug = pg->tune_debug;
@@ -1256,6 +1328,7 @@ int gm_pg_incomplete(gm_index* idx, int64_t* n_inc, int64_t* pairs_evaluated, hi
     if ((rc = pg_read_counters(pg, st))) return rc;
     const PgCounters h = pg->box->c;
     *n_inc = h.n_inc;
+    if (pg->cut_id != 0xffffffffu && pg->tune_cut == 0 && pg->cap_nq > 0 && (int64_t)h.n_inc * 100 > pg->cap_nq) pg->cut_dropped = true;
     *pairs_evaluated = 0;
     for (int b = 0; b < GM_PG_MAXB; ++b) {
         pg->last_bpairs[b] = (int64_t)h.bpairs[b];
@@ -1310,6 +1383,9 @@ int gm_pg_gather(gm_index* idx, int64_t n_inc, int k, bool nearest, const uint2*
 double gm_pg_prefix_fraction(const gm_index* idx, int k) {
     const gm_pigeon* pg = idx->pg;
     if (!pg || pg->B < 2 || !pg->tune_prefix || !pg->box) return 1.0;
+    // under the id cut-off a short row does NOT know all its neighbours at distance r (only those with ids below the
+    // cut-off), and the prefix argument needs them all: such rows take the plain re-scan
+    if (pg->cut_id != 0xffffffffu) return 1.0;
     const PgCounters& h = pg->box->c;      // as read back by gm_pg_incomplete
     const double pm = pg->p_match >= 0.25 ? pg->p_match : 0.25;
     const int r = gm_pg_radius(idx);

@@ -26,6 +26,12 @@
 //     merge reads one header and only the key runs that are not empty.
 // Bound tightening needs no sorted list: per candidate the flush counts the hits closer than r and closer than
 // r - 1; once k of them are known nothing at distance r (r - 1) can enter the top k.  k = 1 follows the best distance.
+// Id cut-off (CUT = true; gm_pigeon.hip pg_cut_fraction): when the pool holds many more targets at distance exactly r than a
+// candidate needs (k = 20 of 80 on S4), only those with id < cut_id can be among the k best -- ties go to the smaller id --
+// as long as enough of them exist.  Buckets are in id order, so the groups of a bucket behind its last id < cut_id are
+// evaluated under the bound r instead of r + 1 (their distance-r targets never become hits), and the flush drops
+// what the boundary group lets through.  A list that fills is exact as before (everything below its k-th key was
+// enumerated); one that does not makes the row incomplete, and such rows take the plain re-scan.
 // k_merge_hits folds the lists of a candidate (duplicates -- pairs that share several blocks -- taken once) into
 // the top k; a candidate whose merged list is full is exact (every target within r was enumerated); the others,
 // and those with an overflowed list, are collected for the plain scan (gmhip.hip).
@@ -75,10 +81,12 @@ __host__ __device__ __forceinline__ int pg_target_bucket(int v, int e, int len, 
 
 // walks the 2-group DMA units ("pairs") of the non-empty target buckets of a chunk, in order
 struct PgIter {
-    int e, g0, gc, pi, add;
+    int e, g0, gc, pi, add, cutg;
 };
+// uncut (CUT only) = how many of the unit's groups still hold an id below the cut-off (they come first)
+template <bool CUT>
 __device__ __forceinline__ bool pg_next(const gm_pg_blocks& P, const gm_pg_chunk& ch, PgIter& it, int& g, int& ng,
-                                        int& add) {
+                                        int& add, int& uncut) {
     if (2 * (it.pi + 1) < it.gc) {
         ++it.pi;
     } else {
@@ -88,12 +96,19 @@ __device__ __forceinline__ bool pg_next(const gm_pg_blocks& P, const gm_pg_chunk
             const int2 d = P.bdesc[ch.b][vt];      // one scalar 8-byte load
             it.g0 = d.x;
             it.gc = d.y;
+            if constexpr (CUT) it.cutg = P.bcut[ch.b][vt];
         } while (it.gc <= 0);
         it.pi = 0;
     }
     g = it.g0 + 2 * it.pi;
     ng = it.gc - 2 * it.pi < 2 ? it.gc - 2 * it.pi : 2;
     add = it.add;
+    if constexpr (CUT) {
+        const int left = it.cutg - 2 * it.pi;
+        uncut = left < 0 ? 0 : (left > 2 ? 2 : left);
+    } else {
+        uncut = 2;
+    }
     return true;
 }
 
@@ -102,11 +117,22 @@ template <int L>
 __device__ __forceinline__ void pg_stage(const uint32_t* __restrict__ table, int g, uint32_t* dst, int lane) {
     constexpr int UNITS = pg_pair_words(L) / 4;       // 16-byte units
     constexpr int ROUNDS = (UNITS + WAVE - 1) / WAVE;
-    const uint32_t* src = table + (int64_t)g * lk_group_words(L);
+    // wave-uniform base + a 32-bit unsigned lane offset: the load takes the base from SGPRs (saddr form) and no per-lane
+    // 64-bit pointer has to live across the scan loop
+    const uint64_t p64 = reinterpret_cast<uint64_t>(table + (int64_t)g * lk_group_words(L));
+    const uint32_t p_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(p64 >> 32));      // (the builtin returns int:
+    const uint32_t p_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)p64);                // no sign extension)
+    const char* src = reinterpret_cast<const char*>(((uint64_t)p_hi << 32) | (uint64_t)p_lo);
+    // (formed by an opaque instruction at every call: left to itself the compiler hoists the zero-extended 64-bit
+    // offset out of the scan loop as a register pair, and at 64 VGPRs that pair is spilled and reloaded per stage)
+    uint32_t lane_off;
+    asm volatile("v_lshlrev_b32 %0, 4, %1" : "=v"(lane_off) : "v"(lane));
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
         const int u = r * WAVE + lane;
-        if (u < UNITS) __builtin_amdgcn_global_load_lds(src + u * 4, dst + r * WAVE * 4, 16, 0, 0);
+        if (u < UNITS)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t*>(src + r * WAVE * 16 + lane_off),
+                                             dst + r * WAVE * 4, 16, 0, 0);
     }
 }
 
@@ -124,7 +150,7 @@ struct PgQueue {
 // FLUSH: n (<= 64, wave-uniform) queued hit words are turned into list entries, one per lane.
 __device__ __forceinline__ void pg_flush(PgQueue& Q, int n, int lane, const uint4* __restrict__ recs,
                                          uint32_t* __restrict__ lists, int lcap, int row_words, int k, int thr0,
-                                         int debug = 0) {
+                                         int debug = 0, uint32_t cut_id = 0xffffffffu) {
     uint32_t tg = 0;
     uint2 m = make_uint2(0u, 0u);
     if (lane < n) {
@@ -143,6 +169,7 @@ __device__ __forceinline__ void pg_flush(PgQueue& Q, int n, int lane, const uint
         hm &= hm - 1ull;
         const uint4 t = recs[pos0 + j];
         const int d = __popc((cq.x ^ t.x) | (cq.y ^ t.y));
+        if (d == thr0 - 1 && t.z >= cut_id) continue;      // id cut-off: at distance r only ids below it count
         if (k == 1) {
             atomicMin(&Q.c1[cl], d);
         } else {
@@ -184,7 +211,7 @@ __device__ __forceinline__ void pg_group(const uint32_t* const (&ptr)[L], const 
 }
 
 // lists: the hit buffer (see gm_pg_blocks::loff / lcap)
-template <int L>
+template <int L, bool CUT>
 __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
     gm_pg_blocks P, const gm_pg_chunk* __restrict__ chunks, const int* __restrict__ c_begin,
     const int* __restrict__ c_end, const uint2* __restrict__ q, int64_t n_q, int k, int thr0,
@@ -238,54 +265,65 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
     int thr = valid && !(P.debug & 2) ? thr0 : 0;              // accept d < thr  (debug bit 1: no hits at all, timing only)
     uint32_t Tb[5];
 
-    PgIter it{ch.e_lo - 1, 0, 0, 0, 0};
-    int gA = 0, ngA = 0, addA = 0, gB = 0, ngB = 0, addB = 0;
-    bool okA = pg_next(P, ch, it, gA, ngA, addA), okB = false;
+    PgIter it{ch.e_lo - 1, 0, 0, 0, 0, 0};
+    int gA = 0, ngA = 0, addA = 0, ucA = 2, gB = 0, ngB = 0, addB = 0, ucB = 2;
+    bool okA = pg_next<CUT>(P, ch, it, gA, ngA, addA, ucA), okB = false;
     if (okA) pg_stage<L>(table, gA, tiles, lane);
-    int add_cur = -1;
+    const uint32_t cut_id = CUT ? P.cut_id : 0xffffffffu;
+    // comparator bound of the next group: the lane's bound, minus the mismatches the copy's table cannot see (add), and
+    // behind a bucket's cut-off point at most r (thr0 - 1): distance-r targets there have ids that cannot matter
+    int cur = -1;      // (add << 1 | cut) the comparator words were formed for; -1 = stale
+#define GM_PG_BOUND(ADD, CUTF)                                                              \
+    {                                                                                     \
+        const int want = ((ADD) << 1) | ((CUTF) ? 1 : 0);                                 \
+        if (want != cur) {                                                                \
+            cur = want;                                                                   \
+            const int t_ = (CUT && (CUTF) && thr > thr0 - 1) ? thr0 - 1 : thr;             \
+            lk_set_bound(Tb, L, t_ - (ADD));                                              \
+        }                                                                                 \
+    }
     // flush when a full wave of entries is queued; afterwards the bounds may have tightened
-#define GM_PG_AFTER_GROUP(ADD)                                                    \
+#define GM_PG_AFTER_GROUP()                                                       \
     if (Q.tail - Q.head >= WAVE) {                                                \
-        pg_flush(Q, WAVE, lane, recs, mylists, lcap, row_words, k, thr0, P.debug);                    \
+        pg_flush(Q, WAVE, lane, recs, mylists, lcap, row_words, k, thr0, P.debug, cut_id);            \
         const int nt = pg_bound(Q, lane, k, thr0);                                \
         if (valid && nt < thr) thr = nt;                                          \
-        lk_set_bound(Tb, L, thr - (ADD));                                         \
+        cur = -1;                                                                 \
     }
     while (okA) {
-        okB = pg_next(P, ch, it, gB, ngB, addB);
+        okB = pg_next<CUT>(P, ch, it, gB, ngB, addB, ucB);
         lk_stage_wait();                                        // unit A has landed in buffer 0
         if (okB) pg_stage<L>(table, gB, tiles + PW, lane);
-        if (addA != add_cur) {
-            add_cur = addA;
-            lk_set_bound(Tb, L, thr - add_cur);
-        }
+        GM_PG_BOUND(addA, ucA < 1)
         pg_group<L, 0>(ptr, Tb, gA, lane, Q);
-        GM_PG_AFTER_GROUP(add_cur)
+        GM_PG_AFTER_GROUP()
         if (ngA > 1) {
+            GM_PG_BOUND(addA, ucA < 2)
             pg_group<L, GW>(ptr, Tb, gA + 1, lane, Q);
-            GM_PG_AFTER_GROUP(add_cur)
+            GM_PG_AFTER_GROUP()
         }
         if (!okB) break;
-        okA = pg_next(P, ch, it, gA, ngA, addA);
+        okA = pg_next<CUT>(P, ch, it, gA, ngA, addA, ucA);
         lk_stage_wait();                                        // unit B has landed in buffer 1
         if (okA) pg_stage<L>(table, gA, tiles, lane);
-        if (addB != add_cur) {
-            add_cur = addB;
-            lk_set_bound(Tb, L, thr - add_cur);
-        }
+        GM_PG_BOUND(addB, ucB < 1)
         pg_group<L, PW>(ptr, Tb, gB, lane, Q);
-        GM_PG_AFTER_GROUP(add_cur)
+        GM_PG_AFTER_GROUP()
         if (ngB > 1) {
+            GM_PG_BOUND(addB, ucB < 2)
             pg_group<L, PW + GW>(ptr, Tb, gB + 1, lane, Q);
-            GM_PG_AFTER_GROUP(add_cur)
+            GM_PG_AFTER_GROUP()
         }
     }
 #undef GM_PG_AFTER_GROUP
+#undef GM_PG_BOUND
     while (Q.tail - Q.head > 0) {
         const int n_take = Q.tail - Q.head < WAVE ? Q.tail - Q.head : WAVE;
-        pg_flush(Q, n_take, lane, recs, mylists, lcap, row_words, k, thr0, P.debug);
+        pg_flush(Q, n_take, lane, recs, mylists, lcap, row_words, k, thr0, P.debug, cut_id);
     }
-    if (valid) lists[qi * row_words + ch.lst] = (uint32_t)Q.cnt[lane];      // every (list, candidate) pair has exactly one writer
+    // every (list, candidate) pair has exactly one writer (the row number comes back from LDS: a 64-bit index kept in
+    // registers across the scan loop is two VGPRs the loop does not have)
+    if (lane < ch.cn) lists[(int64_t)Q.qrow[lane] * row_words + ch.lst] = (uint32_t)Q.cnt[lane];
 }
 
 // K1P merge: SPLIT adjacent lanes per candidate (4 for lists of <= 10 keys, where the kernel waits for memory; fewer

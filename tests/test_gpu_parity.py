@@ -746,6 +746,35 @@ def test_prefix_rescan_matches_plain_rescan_and_oracle(oracle, n, L, k, planted,
         idx.close()
 
 
+@pytest.mark.parametrize("n,k,cut", [(500_000, 20, 0), (500_000, 20, 25), (500_000, 20, 4), (300_000, 5, 30), (300_000, 2, 10)])
+def test_id_cutoff_is_exact(oracle, n, k, cut):
+    """Hits at the layout's radius only from targets with ids below a cut-off ("pg_cut": 0 = the library's choice, else
+    that percentage of the ids) -- a tight cut leaves rows short, and those take the re-scan: same answer as without
+    (pg_cut = 100), as the plain scan, and as the oracle on the rows with the farthest k-th neighbours."""
+    L = 20
+    db = _random_packed(n, L, seed=900 + k, planted=0.01)
+    rng = np.random.default_rng(4)
+    q = np.concatenate([db[: n // 3], _random_packed(4000, L, seed=78)])
+    idx = _lib.Index(db, L, _lib.METRIC_HAMMING)
+    try:
+        idx.set_param("pg_cut", cut)
+        ids, dists, counts = idx.knn(q, k)
+        assert idx.last_kernel()[0] == "k_hamming_scan_pg"
+        idx.set_param("pg_cut", 100)
+        i0, d0, c0 = idx.knn(q, k)
+        assert (i0 == ids).all() and (d0 == dists).all() and (c0 == counts).all()
+        idx.set_variant(8)
+        i8, d8, c8 = idx.knn(q, k)
+        assert (i8 == ids).all() and (d8 == dists).all() and (c8 == counts).all()
+        far = np.flatnonzero(dists[:, k - 1] >= np.sort(dists[:, k - 1])[-1500])[:1000]
+        rows = np.unique(np.concatenate([far, rng.choice(q.shape[0], size=300, replace=False)]))
+        oi, od, oc = oracle.knn(_packed_to_bytes(db, L), _packed_to_bytes(q[rows], L), L, "hamming", k)
+        od = np.where(od >= 0, od // 2, -1)
+        assert (oc == counts[rows]).all() and (od == dists[rows]).all() and (oi == ids[rows]).all()
+    finally:
+        idx.close()
+
+
 def test_prefix_rescan_nearest_distance(oracle):
     """Nearest-distance entry (controls): random strangers against a genome-sized pool; rows without a hit inside the
     layout's radius take the re-scan -- same distances as the plain scan."""
