@@ -17,6 +17,7 @@ struct gm_pg_blocks {
     const uint32_t* cperm[GM_PG_MAXB];   // candidates sorted by block b: sorted position -> candidate row
     int skip[GM_PG_MAXB];                // copy b's table leaves out sequence positions [skip[b], skip[b] + skiplen[b]):
     int skiplen[GM_PG_MAXB];             // its own block (all of it unless fewer than 10 positions would remain)
+    const uint8_t* cflag;                // id cut-off: 1 = candidate row takes it (dense enough neighbourhood), 0 = it does not
     const int* bcut[GM_PG_MAXB];         // id cut-off (k_hamming_scan_pg<L, true>): groups of bucket v that hold an id < cut_id
     uint32_t cut_id;                     // hits at distance exactly r are taken only from targets with id < cut_id
                                          // (0xffffffff: no cut-off)

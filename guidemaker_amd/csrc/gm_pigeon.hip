@@ -472,6 +472,40 @@ __global__ __launch_bounds__(256) void k_bucket_cut(const uint4* __restrict__ re
     bcut[v] = (lo + gm::LK_GROUP - 1) / gm::LK_GROUP;      // lo = targets below the cut-off
 }
 
+
+// id cut-off, per candidate: under the independent-position model with the pool's base frequencies, a candidate with
+// bases b_p mismatches a random target at position p with probability 1 - freq[b_p]; lam_lt / lam_r = expected targets
+// closer than r / at exactly r.  The candidate takes the cut-off (hits at r only from ids below f n_db) when that still
+// leaves it f lam_r >= (k - lam_lt)+ + 2 sqrt(k) + 1 of them.
+struct PgFreqArg {
+    float miss[4];      // 1 - frequency of base b in the pool
+};
+__global__ __launch_bounds__(256) void k_cand_cutflag(const uint2* __restrict__ planes, int64_t n, int L, PgFreqArg F, float n_db,
+                                                      int r, int k, float f, uint8_t* __restrict__ flag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint2 e = planes[i];
+    float dp[9];      // P(j mismatches so far), j = 0 .. 8 (r <= 8: three blocks of radius 2)
+#pragma unroll
+    for (int j = 0; j < 9; ++j) dp[j] = j == 0 ? 1.0f : 0.0f;
+    for (int p = 0; p < L; ++p) {
+        const int b = (int)(((e.x >> p) & 1u) | (((e.y >> p) & 1u) << 1));
+        const float m = F.miss[b];
+#pragma unroll
+        for (int j = 8; j >= 1; --j) dp[j] = dp[j] * (1.0f - m) + dp[j - 1] * m;
+        dp[0] *= 1.0f - m;
+    }
+    float lt = 0.0f, at = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        if (j < r) lt += dp[j];
+        if (j == r) at = dp[j];
+    }
+    const float lam_lt = n_db * lt + 1.0f, lam_r = n_db * at;
+    const float need = (float)k - lam_lt > 0.0f ? (float)k - lam_lt : 0.0f;
+    flag[i] = f * lam_r >= need + 2.0f * sqrtf((float)k) + 1.0f ? 1 : 0;
+}
+
 template <class T>
 int ensure(T** p, int64_t* cap, int64_t need, const char* what) {
     if (need <= *cap && *p != nullptr) return GM_OK;
@@ -510,6 +544,9 @@ struct gm_pigeon {
     int tune_prefix = 1;               // 0 = the incomplete rows go straight to the plain re-scan (gm_set_param "pg_prefix")
     int tune_cut = 0;                  // id cut-off: 0 = choose, 1 .. 99 = that percentage of the ids, 100 = off ("pg_cut")
     bool cut_dropped = false;          // the cut-off left more than 1 % of the candidates short on this pool: not used again
+    double base_freq[4] = {0.25, 0.25, 0.25, 0.25};      // base composition of the pool (gm_pg_pool_stats)
+    uint8_t* cflag = nullptr;          // per candidate: takes the id cut-off
+    int64_t cflag_cap = 0;
     double cut_f = 1.0;                // fraction of the ids whose distance-r targets are taken (1.0 = no cut-off)
     uint32_t cut_id = 0xffffffffu;     // ... as an id
     int* bcut[GM_PG_MAXB]{};           // per copy: groups per bucket that hold an id below the cut-off
@@ -781,7 +818,10 @@ int gm_pg_pool_stats(gm_index* idx, hipStream_t st, double* p_match) {
         if (e != hipSuccess) return gm_fail(GM_ERR_DEVICE, std::string("pool composition: ") + hipGetErrorString(e));
         const double total = (double)(h[0] + h[1] + h[2] + h[3]);
         double pm = 0.0;
-        for (int b = 0; b < 4; ++b) pm += (h[b] / total) * (h[b] / total);
+        for (int b = 0; b < 4; ++b) {
+            pm += (h[b] / total) * (h[b] / total);
+            pg->base_freq[b] = h[b] / total;
+        }
         pg->p_match = pm;
     }
     *p_match = pg->p_match;
@@ -845,7 +885,7 @@ void gm_pg_free(gm_index* idx) {
     for (int b = 0; b < GM_PG_MAXB; ++b)
         if (pg->cperm[b]) (void)hipFree(pg->cperm[b]);
     void* bufs[] = {pg->k0, pg->k1, pg->r0, pg->r1, pg->sort_tmp, pg->nch, pg->cbase, pg->hist, pg->cursor, pg->chunks, pg->ctr,
-                    pg->lists, pg->raw_off, pg->inc, pg->inc_b, pg->q2, pg->ids2, pg->dists2, pg->counts2};
+                    pg->lists, pg->raw_off, pg->inc, pg->inc_b, pg->cflag, pg->q2, pg->ids2, pg->dists2, pg->counts2};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     if (pg->box) (void)hipHostFree(pg->box);
@@ -1191,9 +1231,10 @@ int gm_pg_scan(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
             f = (need + 4.0 * std::sqrt((double)k) + 3.0) / lam_r;
         }
         // The estimate is the pool AVERAGE.  With a skewed base composition the candidates differ by orders of magnitude
-        // in how many neighbours they have (S3, gc 0.38: f = 0.44 left 3.5 % of the candidates short instead of 0.13 %):
-        // only near-uniform pools take the cut-off, and a handle on which it still leaves too many rows short drops it.
-        if (pm > 0.2515 || pg->cut_dropped) f = 1.0;
+        // in how many neighbours they have (S3, gc 0.38: f = 0.44 for everybody left 3.5 % of the candidates short instead
+        // of 0.13 %), so every candidate decides for itself from its own bases (k_cand_cutflag): the sparse ones keep
+        // all their hits at r.  A handle on which the cut-off still leaves too many rows short drops it.
+        if (pg->cut_dropped) f = 1.0;
         if (pg->tune_cut >= 100) f = 1.0;
         else if (pg->tune_cut > 0 && k > 1) f = pg->tune_cut / 100.0;
         if (f > 0.75 || f <= 0.0) f = 1.0;
@@ -1210,6 +1251,14 @@ int gm_pg_scan(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
             }
             HIP_TRY(hipGetLastError());
             pg->bcut_for = cut_id;
+        }
+        if (cut_id != 0xffffffffu) {
+            if ((rc = ensure(&pg->cflag, &pg->cflag_cap, n_q, "cut-off flags"))) return rc;
+            PgFreqArg F{};
+            for (int b = 0; b < 4; ++b) F.miss[b] = (float)(1.0 - pg->base_freq[b]);
+            hipLaunchKernelGGL(k_cand_cutflag, grid_for(n_q), dim3(256), 0, st, idx->d_q, n_q, idx->L, F, (float)idx->n_db, r, k,
+                               (float)f, pg->cflag);
+            HIP_TRY(hipGetLastError());
         }
     }
     if (pg->cap_nq != n_q || pg->cap_layout_for != lkey || pg->cap_sub_for != pg->tune_sub) {
@@ -1232,6 +1281,7 @@ int gm_pg_scan(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
     }
     blocks.n_blocks = pg->B;
     blocks.cut_id = pg->cut_id;
+    blocks.cflag = pg->cflag;
     const int thr0 = gm_pg_radius(idx) + 1;      // accept d < thr0, i.e. d <= r
     blocks.run = pg->tune_run;
     blocks.debug = pg->tune_debug;
@@ -1269,7 +1319,7 @@ int gm_pg_merge(gm_index* idx, int kcap, int64_t n_q, int k, int32_t* ids, int32
     int split = kcap >= 20 ? 2 : 4;      // (S4, k = 20: 15.3 / 15.0 / 15.8 ms per query with 1 / 2 / 4; S1, k = 10: 1.23 / 1.15 / 1.13)
     if (pg->tune_msplit > 0) split = pg->tune_msplit;
     const dim3 grid = grid_for(n_q * split), block(256);
-#define GM_MERGE(KC, SP) hipLaunchKernelGGL((gm::k_merge_hits<KC, SP>), grid, block, 0, st, pg->blocks, pg->lists, n_q, k, ids, dists, counts, nr, pg->inc, n_inc, &pg->ctr->n_over, pg->ctr->chist)
+#define GM_MERGE(KC, SP) hipLaunchKernelGGL((gm::k_merge_hits<KC, SP>), grid, block, 0, st, pg->blocks, pg->lists, n_q, k, ids, dists, counts, nr, pg->inc, n_inc, &pg->ctr->n_over, pg->ctr->chist, pg->cut_id != 0xffffffffu ? pg->cflag : nullptr)
 #define GM_MERGE_KC(KC) do { if (split == 1) GM_MERGE(KC, 1); else if (split == 2) GM_MERGE(KC, 2); else GM_MERGE(KC, 4); } while (0)
     switch (kcap) {
         case 1: GM_MERGE_KC(1); break;
@@ -1383,9 +1433,8 @@ int gm_pg_gather(gm_index* idx, int64_t n_inc, int k, bool nearest, const uint2*
 double gm_pg_prefix_fraction(const gm_index* idx, int k) {
     const gm_pigeon* pg = idx->pg;
     if (!pg || pg->B < 2 || !pg->tune_prefix || !pg->box) return 1.0;
-    // under the id cut-off a short row does NOT know all its neighbours at distance r (only those with ids below the
-    // cut-off), and the prefix argument needs them all: such rows take the plain re-scan
-    if (pg->cut_id != 0xffffffffu) return 1.0;
+    // (under the id cut-off a short row that took it does NOT know all its neighbours at distance r: the merge files it
+    // with the overflowed rows -- n_over -- and only the others, which kept all their hits, count here)
     const PgCounters& h = pg->box->c;      // as read back by gm_pg_incomplete
     const double pm = pg->p_match >= 0.25 ? pg->p_match : 0.25;
     const int r = gm_pg_radius(idx);

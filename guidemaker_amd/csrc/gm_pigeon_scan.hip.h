@@ -162,14 +162,16 @@ __device__ __forceinline__ void pg_flush(PgQueue& Q, int n, int lane, const uint
     const int cl = (int)(tg & 63u);
     const int64_t pos0 = (int64_t)(tg >> 6) * LK_GROUP;
     const uint2 cq = Q.qpl[cl];
-    const int64_t row = Q.qrow[cl];
+    const uint32_t rw = (uint32_t)Q.qrow[cl];      // row number; top bit = the candidate takes the id cut-off
+    const int64_t row = (int64_t)(rw & 0x7fffffffu);
+    const uint32_t cut_c = (rw >> 31) != 0u ? cut_id : 0xffffffffu;
     uint64_t hm = ((uint64_t)m.y << 32) | (uint64_t)m.x;
     while (hm != 0ull) {
         const int j = __builtin_ctzll(hm);
         hm &= hm - 1ull;
         const uint4 t = recs[pos0 + j];
         const int d = __popc((cq.x ^ t.x) | (cq.y ^ t.y));
-        if (d == thr0 - 1 && t.z >= cut_id) continue;      // id cut-off: at distance r only ids below it count
+        if (d == thr0 - 1 && t.z >= cut_c) continue;      // id cut-off: at distance r only ids below it count
         if (k == 1) {
             atomicMin(&Q.c1[cl], d);
         } else {
@@ -243,8 +245,10 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
     const bool valid = lane < ch.cn;
     const int64_t qi = valid ? (int64_t)P.cperm[ch.b][ch.c0 + lane] : 0;
     const uint2 qv = valid ? q[qi] : make_uint2(0u, 0u);
+    // id cut-off per candidate: only rows whose neighbourhood is dense enough take it (cflag, k_cand_cutflag)
+    const bool lane_cut = CUT && valid && P.cflag[qi] != 0;
     Q.qpl[lane] = qv;
-    Q.qrow[lane] = (int)qi;
+    Q.qrow[lane] = (int)((uint32_t)qi | (lane_cut ? 0x80000000u : 0u));
     Q.cnt[lane] = 0;
     Q.c1[lane] = k == 1 ? thr0 : 0;
     Q.c2[lane] = 0;
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
         const int want = ((ADD) << 1) | ((CUTF) ? 1 : 0);                                 \
         if (want != cur) {                                                                \
             cur = want;                                                                   \
-            const int t_ = (CUT && (CUTF) && thr > thr0 - 1) ? thr0 - 1 : thr;             \
+            const int t_ = (CUT && (CUTF) && lane_cut && thr > thr0 - 1) ? thr0 - 1 : thr; \
             lk_set_bound(Tb, L, t_ - (ADD));                                              \
         }                                                                                 \
     }
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
     }
     // every (list, candidate) pair has exactly one writer (the row number comes back from LDS: a 64-bit index kept in
     // registers across the scan loop is two VGPRs the loop does not have)
-    if (lane < ch.cn) lists[(int64_t)Q.qrow[lane] * row_words + ch.lst] = (uint32_t)Q.cnt[lane];
+    if (lane < ch.cn) lists[(int64_t)((uint32_t)Q.qrow[lane] & 0x7fffffffu) * row_words + ch.lst] = (uint32_t)Q.cnt[lane];
 }
 
 // K1P merge: SPLIT adjacent lanes per candidate (4 for lists of <= 10 keys, where the kernel waits for memory; fewer
@@ -335,7 +339,7 @@ template <int KCAP, int SPLIT>
 __global__ void k_merge_hits(gm_pg_blocks P, const uint32_t* __restrict__ lists, int64_t n_q, int k,
                              int32_t* __restrict__ ids, int32_t* __restrict__ dists, int32_t* __restrict__ counts,
                              int nearest, int32_t* __restrict__ inc, int* __restrict__ inc_count,
-                             int* __restrict__ over_count, int* __restrict__ chist) {
+                             int* __restrict__ over_count, int* __restrict__ chist, const uint8_t* __restrict__ cflag) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int sub = (int)(t % SPLIT);
     const int64_t qi_raw = t / SPLIT;
@@ -374,6 +378,8 @@ __global__ void k_merge_hits(gm_pg_blocks P, const uint32_t* __restrict__ lists,
     }
     if (sub != 0 || !valid) return;
     const bool full = list.v[KCAP - 1] != RegList<KCAP>::EMPTY;
+    // (a short row that took the id cut-off does not know all its neighbours at r either)
+    if (!overflow && !full && cflag != nullptr && cflag[qi] != 0) overflow = 1;
     if (overflow) {      // hits were lost: nothing about this row is known
         list.init(k, nullptr, 0);
         inc[atomicAdd(inc_count, 1)] = (int32_t)((uint32_t)qi | PG_INC_OVERFLOW);
