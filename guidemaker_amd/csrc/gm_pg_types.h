@@ -23,6 +23,7 @@ struct gm_pg_blocks {
                                          // (0xffffffff: no cut-off)
     int n_blocks;                        // B
     int blen[GM_PG_MAXB];                // bases of block b (the kernel decodes neighbour buckets with it)
+    int trad[GM_PG_MAXB];                // search radius of block b (a pair is REPORTED by the first block that finds it)
     int n_lists;
     int run;                             // consecutive chunk-table entries executed on the same XCD
     int debug;                           // timing experiments only (gm_set_param "pg_debug"): bit 0 = skip the list stores

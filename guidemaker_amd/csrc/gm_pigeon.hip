@@ -1271,6 +1271,7 @@ int gm_pg_scan(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
     gm_pg_blocks& blocks = pg->blocks;
     for (int b = 0; b < pg->B; ++b) {
         blocks.blen[b] = pg->blen[b];
+        blocks.trad[b] = pg->trad[b];
         blocks.table[b] = pg->table[b];
         blocks.recs[b] = pg->recs[b];
         blocks.bdesc[b] = pg->bdesc[b];

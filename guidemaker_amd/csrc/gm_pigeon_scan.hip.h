@@ -24,6 +24,10 @@
 //     counter in LDS and stores (distance << 27 | pool id) to the list in HBM.  A list has one writer (this
 //     workgroup); a candidate's row of the hit buffer holds the counts of all its lists first, then their keys, so the
 //     merge reads one header and only the key runs that are not empty.
+// A pair that several blocks find (it has few mismatches on more than one of them) is REPORTED once, by the first of
+// those blocks: the flush counts, on the mismatch word it has anyway, the mismatches on every earlier block, and leaves
+// the entry out of the list if one of them is within that block's radius (S1: 25 -> 17.7 list entries per candidate;
+// the merge sees no duplicates).  It still counts for the bounds below -- it is a real target at that distance.
 // Bound tightening needs no sorted list: per candidate the flush counts the hits closer than r and closer than
 // r - 1; once k of them are known nothing at distance r (r - 1) can enter the top k.  k = 1 follows the best distance.
 // Id cut-off (CUT = true; gm_pigeon.hip pg_cut_fraction): when the pool holds many more targets at distance exactly r than a
@@ -150,7 +154,8 @@ struct PgQueue {
 // FLUSH: n (<= 64, wave-uniform) queued hit words are turned into list entries, one per lane.
 __device__ __forceinline__ void pg_flush(PgQueue& Q, int n, int lane, const uint4* __restrict__ recs,
                                          uint32_t* __restrict__ lists, int lcap, int row_words, int k, int thr0,
-                                         int debug = 0, uint32_t cut_id = 0xffffffffu) {
+                                         int debug = 0, uint32_t cut_id = 0xffffffffu, int n_before = 0,
+                                         const uint32_t* bmask = nullptr, const int* brad = nullptr) {
     uint32_t tg = 0;
     uint2 m = make_uint2(0u, 0u);
     if (lane < n) {
@@ -170,14 +175,18 @@ __device__ __forceinline__ void pg_flush(PgQueue& Q, int n, int lane, const uint
         const int j = __builtin_ctzll(hm);
         hm &= hm - 1ull;
         const uint4 t = recs[pos0 + j];
-        const int d = __popc((cq.x ^ t.x) | (cq.y ^ t.y));
+        const uint32_t mism = (cq.x ^ t.x) | (cq.y ^ t.y);      // one bit per mismatching position
+        const int d = __popc(mism);
         if (d == thr0 - 1 && t.z >= cut_c) continue;      // id cut-off: at distance r only ids below it count
+        bool owned = true;      // no earlier block finds this pair
+        for (int b = 0; b < n_before; ++b) owned = owned && __popc(mism & bmask[b]) > brad[b];
         if (k == 1) {
             atomicMin(&Q.c1[cl], d);
         } else {
             if (d < thr0 - 1) atomicAdd(&Q.c1[cl], 1);
             if (d < thr0 - 2) atomicAdd(&Q.c2[cl], 1);
         }
+        if (!owned) continue;
         const int slot = atomicAdd(&Q.cnt[cl], 1);
         if (slot < lcap && !(debug & 1)) lists[row * row_words + slot] = ((uint32_t)d << ID_BITS) | t.z;
     }
@@ -186,7 +195,7 @@ __device__ __forceinline__ void pg_flush(PgQueue& Q, int n, int lane, const uint
 
 // bound of this lane's candidate from the counters the flushes keep
 __device__ __forceinline__ int pg_bound(const PgQueue& Q, int lane, int k, int thr0) {
-    if (k == 1) return Q.c1[lane];
+    if (k == 1) return Q.c1[lane] + 1;      // ties at the best distance stay in: the smallest id among them wins in the merge
     return thr0 - (Q.c1[lane] >= k ? 1 : 0) - (Q.c2[lane] >= k ? 1 : 0);
 }
 
@@ -268,6 +277,14 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
     uint32_t* __restrict__ mylists = lists + P.loff[ch.lst];     // keys of candidate row: mylists + row * row_words
     int thr = valid && !(P.debug & 2) ? thr0 : 0;              // accept d < thr  (debug bit 1: no hits at all, timing only)
     uint32_t Tb[5];
+    // the blocks before this one (position masks, radii): a pair one of them finds is theirs to report
+    uint32_t bmask[GM_PG_MAXB];
+    int brad[GM_PG_MAXB];
+#pragma unroll
+    for (int b = 0; b < GM_PG_MAXB; ++b) {
+        bmask[b] = b < ch.b ? ((1u << P.blen[b]) - 1u) << P.skip[b] : 0u;
+        brad[b] = b < ch.b ? P.trad[b] : 64;
+    }
 
     PgIter it{ch.e_lo - 1, 0, 0, 0, 0, 0};
     int gA = 0, ngA = 0, addA = 0, ucA = 2, gB = 0, ngB = 0, addB = 0, ucB = 2;
@@ -289,7 +306,7 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
     // flush when a full wave of entries is queued; afterwards the bounds may have tightened
 #define GM_PG_AFTER_GROUP()                                                       \
     if (Q.tail - Q.head >= WAVE) {                                                \
-        pg_flush(Q, WAVE, lane, recs, mylists, lcap, row_words, k, thr0, P.debug, cut_id);            \
+        pg_flush(Q, WAVE, lane, recs, mylists, lcap, row_words, k, thr0, P.debug, cut_id, ch.b, bmask, brad); \
         const int nt = pg_bound(Q, lane, k, thr0);                                \
         if (valid && nt < thr) thr = nt;                                          \
         cur = -1;                                                                 \
@@ -323,7 +340,7 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
 #undef GM_PG_BOUND
     while (Q.tail - Q.head > 0) {
         const int n_take = Q.tail - Q.head < WAVE ? Q.tail - Q.head : WAVE;
-        pg_flush(Q, n_take, lane, recs, mylists, lcap, row_words, k, thr0, P.debug, cut_id);
+        pg_flush(Q, n_take, lane, recs, mylists, lcap, row_words, k, thr0, P.debug, cut_id, ch.b, bmask, brad);
     }
     // every (list, candidate) pair has exactly one writer (the row number comes back from LDS: a 64-bit index kept in
     // registers across the scan loop is two VGPRs the loop does not have)
@@ -362,7 +379,7 @@ __global__ void k_merge_hits(gm_pg_blocks P, const uint32_t* __restrict__ lists,
             const uint32_t kk[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (base + j < c && kk[j] + 1u < list.v[KCAP - 1]) list.insert_unique(kk[j]);
+                if (base + j < c && kk[j] + 1u < list.v[KCAP - 1]) list.insert(kk[j]);
         }
     }
     // shuffle tree over the SPLIT lanes of a candidate: lane s takes the list of lane s + off over
@@ -373,7 +390,7 @@ __global__ void k_merge_hits(gm_pg_blocks P, const uint32_t* __restrict__ lists,
         for (int i = 0; i < KCAP; ++i) {
             const uint32_t v = __shfl_down(list.v[i], off, SPLIT);
             // (a partner's entries ascend: nothing that cannot beat the current k-th needs the 3 KCAP-op insert)
-            if (sub < off && v != 0u && v < list.v[KCAP - 1]) list.insert_unique(v - 1u);
+            if (sub < off && v != 0u && v < list.v[KCAP - 1]) list.insert(v - 1u);
         }
     }
     if (sub != 0 || !valid) return;
