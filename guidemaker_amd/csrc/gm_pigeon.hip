@@ -154,11 +154,11 @@ __device__ __forceinline__ int pg_key(const uint2 e, int start, int len) {
 // buckets of a 6-base block) -- T = 4 cuts those atomics by a third and the launch from 19 to 13 us on S1 (the scatter: 53 to 34).
 template <int T>
 __global__ __launch_bounds__(1024) void k_cand_hist(const uint2* __restrict__ planes, int64_t n, PgKeyArg K,
-                                                    int* __restrict__ hist, int use_lds) {
-    extern __shared__ int s_hist[];
-    const int n_entries = K.ebase[K.B];
+                                                    int* __restrict__ hist, int use_lds, int b_lo, int b_hi) {
+    extern __shared__ int s_hist[];      // the (block, bucket) entries of blocks [b_lo, b_hi)
+    const int e_lo = K.ebase[b_lo], n_ent = K.ebase[b_hi] - e_lo;
     if (use_lds) {
-        for (int e = threadIdx.x; e < n_entries; e += blockDim.x) s_hist[e] = 0;
+        for (int e = threadIdx.x; e < n_ent; e += blockDim.x) s_hist[e] = 0;
         __syncthreads();
     }
 #pragma unroll
@@ -166,103 +166,105 @@ __global__ __launch_bounds__(1024) void k_cand_hist(const uint2* __restrict__ pl
         const int64_t i = ((int64_t)blockIdx.x * T + t) * blockDim.x + threadIdx.x;
         if (i < n) {
             const uint2 e = planes[i];
-            for (int b = 0; b < K.B; ++b) {
+            for (int b = b_lo; b < b_hi; ++b) {
                 const int ent = K.ebase[b] + pg_key(e, K.bstart[b], K.blen[b]);
-                if (use_lds) atomicAdd(&s_hist[ent], 1); else atomicAdd(&hist[ent], 1);
+                if (use_lds) atomicAdd(&s_hist[ent - e_lo], 1); else atomicAdd(&hist[ent], 1);
             }
         }
     }
     if (use_lds) {
         __syncthreads();
-        for (int e = threadIdx.x; e < n_entries; e += blockDim.x)
-            if (s_hist[e] != 0) atomicAdd(&hist[e], s_hist[e]);
+        for (int e = threadIdx.x; e < n_ent; e += blockDim.x)
+            if (s_hist[e] != 0) atomicAdd(&hist[e_lo + e], s_hist[e]);
     }
 }
 
-// ONE workgroup: for every block an exclusive scan of its buckets' candidate counts -> coff[b][0..nb] and the scatter
-// cursors, and in the same pass the chunk table's geometry -- chunks per (block, bucket) entry = ceil(count / 64) x the
-// workgroups an entry's target buckets are split over, their exclusive offsets (cbase), the chunk range of every
-// block (ctr->cstart) and the total -- ; it also clears the per-query counters and leaves the histogram zeroed for the
-// next query.  (Count and chunk sums travel through the scan as one 64-bit word.)
+// One workgroup per block: exclusive scan of its buckets' candidate counts -> coff[b][0..nb] and the scatter cursors,
+// and in the same pass the chunk table's geometry -- chunks per (block, bucket) entry = ceil(count / 64) x the
+// workgroups an entry's target buckets are split over, their exclusive offsets INSIDE the block (cbase) and the block's
+// total (btot) --; it leaves the histogram zeroed for the next query.  (Count and chunk sums travel through the scan as
+// one 64-bit word.)  k_chunk_starts then turns the totals into the blocks' chunk ranges.
 struct PgSubArg {
     int n[GM_PG_MAXB];      // workgroups an entry's target buckets are split over, per block
 };
 __global__ __launch_bounds__(1024) void k_cand_offsets(PgKeyArg K, PgSubArg nsub, int* __restrict__ hist,
                                                        int* __restrict__ cursor, int* __restrict__ cbase,
-                                                       int* __restrict__ ctr_words, int ctr_n_words, int* __restrict__ cstart,
-                                                       int* __restrict__ n_chunks) {
-    __shared__ unsigned long long s[1024];
-    __shared__ int s_chunk_base;
+                                                       int* __restrict__ btot) {
+    __shared__ unsigned long long s[64];
     const int tid = threadIdx.x;
-    for (int i = tid; i < ctr_n_words; i += 1024) ctr_words[i] = 0;
-    if (tid == 0) s_chunk_base = 0;
-    __syncthreads();
-    for (int b = 0; b < K.B; ++b) {
-        const int e0 = K.ebase[b], nb = K.ebase[b + 1] - e0, ns = nsub.n[b];
-        const int per = (nb + 1023) / 1024;
-        const int lo = tid * per, hi = lo + per < nb ? lo + per : nb;
-        unsigned long long sum = 0;
-        for (int v = lo; v < hi; ++v) {
-            const unsigned c = (unsigned)hist[e0 + v];
-            sum += (unsigned long long)c | ((unsigned long long)((c + 63u) / 64u * (unsigned)ns) << 32);
-        }
-        // inclusive scan over the 1024 threads: shuffles inside a wave, the 16 wave totals through LDS
-        unsigned long long inc = sum;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const unsigned long long t = __shfl_up(inc, d, 64);
-            if ((tid & 63) >= d) inc += t;
-        }
-        if ((tid & 63) == 63) s[tid >> 6] = inc;
-        __syncthreads();
-        if (tid < 64) {
-            unsigned long long w = tid < 16 ? s[tid] : 0ull;
-#pragma unroll
-            for (int d = 1; d < 16; d <<= 1) {
-                const unsigned long long t = __shfl_up(w, d, 64);
-                if (tid >= d) w += t;
-            }
-            if (tid < 16) s[32 + tid] = w;      // inclusive totals of waves 0 .. tid
-        }
-        __syncthreads();
-        const unsigned long long wave_before = (tid >> 6) ? s[32 + (tid >> 6) - 1] : 0ull;
-        const unsigned long long before = wave_before + inc - sum, total = s[32 + 15];
-        const int chunk_base = s_chunk_base;
-        int run = (int)(unsigned)before, run_ch = chunk_base + (int)(before >> 32);
-        for (int v = lo; v < hi; ++v) {
-            const int c = hist[e0 + v];
-            K.coff[b][v] = run;
-            cursor[e0 + v] = run;
-            cbase[e0 + v] = run_ch;
-            hist[e0 + v] = 0;
-            run += c;
-            run_ch += (c + 63) / 64 * ns;
-        }
-        __syncthreads();
-        if (tid == 1023) {
-            K.coff[b][nb] = (int)(unsigned)total;
-            cstart[b] = chunk_base;
-            s_chunk_base = chunk_base + (int)(total >> 32);
-        }
-        __syncthreads();
+    const int b = blockIdx.x;
+    const int e0 = K.ebase[b], nb = K.ebase[b + 1] - e0, ns = nsub.n[b];
+    const int per = (nb + 1023) / 1024;
+    const int lo = tid * per, hi = lo + per < nb ? lo + per : nb;
+    unsigned long long sum = 0;
+    for (int v = lo; v < hi; ++v) {
+        const unsigned c = (unsigned)hist[e0 + v];
+        sum += (unsigned long long)c | ((unsigned long long)((c + 63u) / 64u * (unsigned)ns) << 32);
     }
-    if (tid == 0) {
-        cstart[K.B] = s_chunk_base;
-        *n_chunks = s_chunk_base;
+    // inclusive scan over the 1024 threads: shuffles inside a wave, the 16 wave totals through LDS
+    unsigned long long inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long t = __shfl_up(inc, d, 64);
+        if ((tid & 63) >= d) inc += t;
+    }
+    if ((tid & 63) == 63) s[tid >> 6] = inc;
+    __syncthreads();
+    if (tid < 64) {
+        unsigned long long w = tid < 16 ? s[tid] : 0ull;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            const unsigned long long t = __shfl_up(w, d, 64);
+            if (tid >= d) w += t;
+        }
+        if (tid < 16) s[32 + tid] = w;      // inclusive totals of waves 0 .. tid
+    }
+    __syncthreads();
+    const unsigned long long wave_before = (tid >> 6) ? s[32 + (tid >> 6) - 1] : 0ull;
+    const unsigned long long before = wave_before + inc - sum, total = s[32 + 15];
+    int run = (int)(unsigned)before, run_ch = (int)(before >> 32);
+    for (int v = lo; v < hi; ++v) {
+        const int c = hist[e0 + v];
+        K.coff[b][v] = run;
+        cursor[e0 + v] = run;
+        cbase[e0 + v] = run_ch;
+        hist[e0 + v] = 0;
+        run += c;
+        run_ch += (c + 63) / 64 * ns;
+    }
+    if (tid == 1023) {
+        K.coff[b][nb] = (int)(unsigned)total;
+        btot[b] = (int)(total >> 32);
+    }
+}
+
+// the chunk range of every block (ctr->cstart) and the total; also clears the per-query counters
+__global__ __launch_bounds__(64) void k_chunk_starts(const int* __restrict__ btot, int B, int* __restrict__ ctr_words,
+                                                     int ctr_n_words, int* __restrict__ cstart, int* __restrict__ n_chunks) {
+    for (int i = threadIdx.x; i < ctr_n_words; i += 64) ctr_words[i] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int b = 0; b < B; ++b) {
+            cstart[b] = run;
+            run += btot[b];
+        }
+        cstart[B] = run;
+        *n_chunks = run;
     }
 }
 
 // cperm[b][position] = candidate row; positions handed out per bucket: rank inside the workgroup from an
 // LDS counter, one global atomic per (workgroup, non-empty bucket) for the workgroup's base; T tiles of 1024
-// candidates per workgroup (see k_cand_hist)
+// candidates per workgroup (see k_cand_hist); blocks [b_lo, b_hi) per launch (their entries fit the LDS table)
 template <int T>
 __global__ __launch_bounds__(1024) void k_cand_scatter(const uint2* __restrict__ planes, int64_t n, PgKeyArg K,
-                                                       int* __restrict__ cursor, int use_lds) {
-    extern __shared__ int s_cnt[];      // [n_entries] counts, then reused as bases
-    const int n_entries = K.ebase[K.B];
+                                                       int* __restrict__ cursor, int use_lds, int b_lo, int b_hi) {
+    extern __shared__ int s_cnt[];      // [entries of the blocks] counts, then reused as bases
+    const int e_lo = K.ebase[b_lo], n_ent = K.ebase[b_hi] - e_lo;
     int ent[T][GM_PG_MAXB], rank[T][GM_PG_MAXB];
     if (use_lds) {
-        for (int e = threadIdx.x; e < n_entries; e += blockDim.x) s_cnt[e] = 0;
+        for (int e = threadIdx.x; e < n_ent; e += blockDim.x) s_cnt[e] = 0;
         __syncthreads();
     }
 #pragma unroll
@@ -272,29 +274,29 @@ __global__ __launch_bounds__(1024) void k_cand_scatter(const uint2* __restrict__
             const uint2 e = planes[i];
 #pragma unroll
             for (int b = 0; b < GM_PG_MAXB; ++b) {
-                if (b < K.B) {
-                    ent[t][b] = K.ebase[b] + pg_key(e, K.bstart[b], K.blen[b]);
-                    rank[t][b] = use_lds ? atomicAdd(&s_cnt[ent[t][b]], 1) : atomicAdd(&cursor[ent[t][b]], 1);
+                if (b >= b_lo && b < b_hi) {
+                    ent[t][b] = K.ebase[b] + pg_key(e, K.bstart[b], K.blen[b]) - e_lo;
+                    rank[t][b] = use_lds ? atomicAdd(&s_cnt[ent[t][b]], 1) : atomicAdd(&cursor[e_lo + ent[t][b]], 1);
                 }
             }
         }
     }
     if (use_lds) {
         __syncthreads();
-        // the workgroup's base in every bucket it touched: the returning atomics of a thread's (up to 8) entries are
+        // the workgroup's base in every bucket it touched: the returning atomics of a thread's (up to 16) entries are
         // independent -- issue them back to back instead of one memory round trip per loop iteration
-        int cs[8], bs[8];
+        int cs[16], bs[16];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 16; ++j) {
             const int e = threadIdx.x + j * 1024;
-            cs[j] = e < n_entries ? s_cnt[e] : 0;
+            cs[j] = e < n_ent ? s_cnt[e] : 0;
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) bs[j] = cs[j] != 0 ? atomicAdd(&cursor[threadIdx.x + j * 1024], cs[j]) : 0;
+        for (int j = 0; j < 16; ++j) bs[j] = cs[j] != 0 ? atomicAdd(&cursor[e_lo + threadIdx.x + j * 1024], cs[j]) : 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 16; ++j) {
             const int e = threadIdx.x + j * 1024;
-            if (e < n_entries) s_cnt[e] = bs[j];
+            if (e < n_ent) s_cnt[e] = bs[j];
         }
         __syncthreads();
     }
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(1024) void k_cand_scatter(const uint2* __restrict__
         if (i < n) {
 #pragma unroll
             for (int b = 0; b < GM_PG_MAXB; ++b) {
-                if (b < K.B) {
+                if (b >= b_lo && b < b_hi) {
                     const int pos = use_lds ? s_cnt[ent[t][b]] + rank[t][b] : rank[t][b];
                     K.cperm[b][pos] = (uint32_t)i;
                 }
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(256) void k_fill_chunks(PgLayoutArg A, const int* _
         const int n_ch = (c1 - c0 + 63) / 64;
         const int e_lo = s * per, e_hi = e_lo + per < n_bk ? e_lo + per : n_bk;
         const int lst = A.lbase[b] + s;
-        int w = cbase[e] + s * n_ch;
+        int w = ctr->cstart[b] + cbase[e] + s * n_ch;      // (cbase: offset inside the block)
         for (int c = c0; c < c1; c += 64, ++w)
             chunks[w] = gm_pg_chunk{b, v, c, c1 - c < 64 ? c1 - c : 64, e_lo, e_hi, lst, 0};
         // the 64 x 64 groups the scan evaluates for this run
@@ -1125,13 +1127,15 @@ int gm_pg_candidates(gm_index* idx, int64_t n_q, hipStream_t st) {
         pg->bgrid[b] = ((n_q + 63) / 64 + (1 << (2 * pg->blen[b]))) * pg->nsub[b];
         grid += pg->bgrid[b];
     }
-    // counting sort of the candidates by every block's value: histogram, scan (+ chunk-table geometry), scatter
-    const int use_lds = n_entries <= 8192 ? 1 : 0;
-    const size_t lds = use_lds ? sizeof(int) * (size_t)n_entries : 0;
+    // counting sort of the candidates by every block's value: histogram, scan (+ chunk-table geometry), scatter.  The
+    // histogram / scatter kernels privatise the (block, bucket) counters in LDS: one launch covers a run of blocks whose
+    // buckets fit 64 KiB (S1: all four blocks, 6 400 buckets; S4's 7 / 7 / 6 bases: 16 384 buckets per launch); a block of
+    // 8 bases (65 536 buckets) goes through device-wide atomics.
     A.smax = pg->smax;
     A.n_entries = n_entries;
     if ((rc = ensure(&pg->cbase, &pg->cbase_cap, A.n_entries, "chunk offsets"))) return rc;
     if ((rc = ensure(&pg->chunks, &pg->chunks_cap, grid, "chunk table"))) return rc;
+    if ((rc = ensure(&pg->nch, &pg->nch_cap, GM_PG_MAXB, "chunks per block"))) return rc;
     if (pg->hist_dirty) {      // (the offsets kernel leaves the histogram zeroed: only a fresh buffer needs this)
         HIP_TRY(hipMemsetAsync(pg->hist, 0, sizeof(int) * (size_t)pg->hist_cap, st));
         pg->hist_dirty = false;
@@ -1141,15 +1145,40 @@ int gm_pg_candidates(gm_index* idx, int64_t n_q, hipStream_t st) {
     // tiles of 1024 candidates per workgroup: as many as leave ~128 workgroups
     const int tiles = n_q >= (int64_t)1024 * 128 * 4 ? 4 : (n_q >= (int64_t)1024 * 128 * 2 ? 2 : 1);
     const dim3 cgrid = grid_for(n_q, 1024 * tiles);
-    if (tiles == 4) hipLaunchKernelGGL(k_cand_hist<4>, cgrid, dim3(1024), lds, st, idx->d_q, n_q, K, pg->hist, use_lds);
-    else if (tiles == 2) hipLaunchKernelGGL(k_cand_hist<2>, cgrid, dim3(1024), lds, st, idx->d_q, n_q, K, pg->hist, use_lds);
-    else hipLaunchKernelGGL(k_cand_hist<1>, cgrid, dim3(1024), lds, st, idx->d_q, n_q, K, pg->hist, use_lds);
-    hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(1024), 0, st, K, nsub, pg->hist, pg->cursor, pg->cbase,
-                       reinterpret_cast<int*>(pg->ctr), (int)(sizeof(PgCounters) / sizeof(int)), pg->ctr->cstart,
-                       &pg->ctr->n_chunks);
-    if (tiles == 4) hipLaunchKernelGGL(k_cand_scatter<4>, cgrid, dim3(1024), lds, st, idx->d_q, n_q, K, pg->cursor, use_lds);
-    else if (tiles == 2) hipLaunchKernelGGL(k_cand_scatter<2>, cgrid, dim3(1024), lds, st, idx->d_q, n_q, K, pg->cursor, use_lds);
-    else hipLaunchKernelGGL(k_cand_scatter<1>, cgrid, dim3(1024), lds, st, idx->d_q, n_q, K, pg->cursor, use_lds);
+    constexpr int LDS_ENTRIES = 16384;
+    struct Run { int lo, hi, lds; };
+    Run runs[GM_PG_MAXB];
+    int n_runs = 0;
+    for (int b = 0; b < pg->B;) {
+        const int nb = pg->ebase[b + 1] - pg->ebase[b];
+        if (nb > LDS_ENTRIES) {
+            runs[n_runs++] = Run{b, b + 1, 0};
+            ++b;
+            continue;
+        }
+        int hi = b + 1;
+        while (hi < pg->B && pg->ebase[hi + 1] - pg->ebase[b] <= LDS_ENTRIES) ++hi;
+        runs[n_runs++] = Run{b, hi, 1};
+        b = hi;
+    }
+#define GM_LAUNCH_T(KERN, ...)                                                                          \
+    do {                                                                                                \
+        if (tiles == 4) hipLaunchKernelGGL(KERN<4>, cgrid, dim3(1024), lds, st, __VA_ARGS__);            \
+        else if (tiles == 2) hipLaunchKernelGGL(KERN<2>, cgrid, dim3(1024), lds, st, __VA_ARGS__);       \
+        else hipLaunchKernelGGL(KERN<1>, cgrid, dim3(1024), lds, st, __VA_ARGS__);                       \
+    } while (0)
+    for (int i = 0; i < n_runs; ++i) {
+        const size_t lds = runs[i].lds ? sizeof(int) * (size_t)(pg->ebase[runs[i].hi] - pg->ebase[runs[i].lo]) : 0;
+        GM_LAUNCH_T(k_cand_hist, idx->d_q, n_q, K, pg->hist, runs[i].lds, runs[i].lo, runs[i].hi);
+    }
+    hipLaunchKernelGGL(k_cand_offsets, dim3(pg->B), dim3(1024), 0, st, K, nsub, pg->hist, pg->cursor, pg->cbase, pg->nch);
+    hipLaunchKernelGGL(k_chunk_starts, dim3(1), dim3(64), 0, st, pg->nch, pg->B, reinterpret_cast<int*>(pg->ctr),
+                       (int)(sizeof(PgCounters) / sizeof(int)), pg->ctr->cstart, &pg->ctr->n_chunks);
+    for (int i = 0; i < n_runs; ++i) {
+        const size_t lds = runs[i].lds ? sizeof(int) * (size_t)(pg->ebase[runs[i].hi] - pg->ebase[runs[i].lo]) : 0;
+        GM_LAUNCH_T(k_cand_scatter, idx->d_q, n_q, K, pg->cursor, runs[i].lds, runs[i].lo, runs[i].hi);
+    }
+#undef GM_LAUNCH_T
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_fill_chunks, grid_for((int64_t)A.n_entries * A.smax), dim3(256), 0, st, A, pg->cbase, pg->chunks, pg->ctr);
     HIP_TRY(hipGetLastError());
