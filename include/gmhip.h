@@ -28,9 +28,10 @@
  *     fewer than k db points are padded with -1 and counts[] holds the valid length
  *   - *_dev variants take DEVICE pointers (HBM-resident inputs/outputs) and a hipStream_t passed as
  *     void*; they enqueue on that stream and return without waiting for the results.  (Large Hamming pools go
- *     through the pigeonhole-partitioned scan, which waits for the stream once inside the call -- a 32-byte
- *     read-back of how many rows need the follow-up scan -- and once more, to verify that follow-up, only when there
- *     are such rows; the first call on a handle also builds the block-sorted pool copies.)
+ *     through the pigeonhole-partitioned scan, which waits for the stream inside the call: once for the counters of the
+ *     rows that need a follow-up scan -- the host sizes that follow-up from them -- and, only when there are such
+ *     rows, once or twice more to see what the follow-up left; the waits poll a word in pinned host memory that a small
+ *     kernel writes.  The first call on a handle also builds the block-sorted pool copies.)
  *   - one host thread per handle; handles are independent; one handle = one GPU (multi-GPU is one
  *     process per GPU)
  *   - there is NO CPU fallback: without a gfx950 device every compute entry point fails with
