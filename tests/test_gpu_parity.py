@@ -695,6 +695,20 @@ def test_fuzz_against_oracle_time_boxed(oracle):
     assert n_cases >= 20
 
 
+def test_k1p_stress_time_boxed():
+    """tools/k1p_stress.py for 20 s: random pool size (40 k .. 400 k: the planner, the prefix re-scan and the id cut-off
+    are live), guide length, k, base skew, planted near-duplicates and cut-off setting -- the whole answer against the
+    plain scan (variant 8)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "k1p_stress.py"), "--seconds", "20", "--seed", "5"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "MISMATCH" not in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "cases" in out.stdout.splitlines()[-1]
+
+
 def _random_packed(n, L, seed, planted=0.0):
     rng = np.random.default_rng(seed)
     codes = rng.integers(0, 4, size=(n, L), dtype=np.uint8)

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Randomised differential run of the pigeonhole-partitioned scan at pool sizes where the planner, the prefix re-scan and the
+id cut-off are all live: random pool size / guide length / k / base skew / planted near-duplicates / cut-off setting, the
+whole answer against the plain scan (variant 8) of the same library.   python tools/k1p_stress.py --seconds 180"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from guidemaker_amd import _lib, core  # noqa: E402
+
+
+def pool(rng, n, L, skew, planted):
+    p = np.array([1 + skew, 1 - skew, 1 - skew, 1 + skew], dtype=np.float64)
+    codes = rng.choice(4, size=(n, L), p=p / p.sum()).astype(np.uint8)
+    if planted > 0:
+        m = int(n * planted)
+        dst, src = rng.integers(0, n, size=m), rng.integers(0, n, size=m)
+        codes[dst] = codes[src]
+        for _ in range(3):
+            hit = rng.random(m) < 0.67
+            codes[dst[hit], rng.integers(0, L, size=int(hit.sum()))] = rng.integers(0, 4, size=int(hit.sum()))
+    db = np.unique(core.pack_codes(codes))
+    rng.shuffle(db)
+    return db
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120.0)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    rng = np.random.default_rng(a.seed)
+    t0, case, used = time.time(), 0, {"k_hamming_scan_pg": 0}
+    while time.time() - t0 < a.seconds:
+        case += 1
+        n = int(rng.integers(40_000, 400_000))
+        L = int(rng.integers(14, 25))
+        k = int(rng.choice([1, 2, 3, 5, 7, 10, 13, 20]))
+        skew = float(rng.choice([0.0, 0.0, 0.1, 0.3]))
+        planted = float(rng.choice([0.0, 0.01, 0.05]))
+        cut = int(rng.choice([0, 0, 0, 10, 30, 60, 100]))
+        db = pool(rng, n, L, skew, planted)
+        q = np.concatenate([db[: int(rng.integers(1000, min(len(db), 120_000)))], pool(rng, 3000, L, skew, 0.0)])
+        idx = _lib.Index(db, L, _lib.METRIC_HAMMING)
+        try:
+            idx.set_param("pg_cut", cut)
+            if k == 1 and rng.random() < 0.5:
+                got = (idx.nearest(q),)
+                name = idx.last_kernel()[0]
+                idx.set_variant(8)
+                want = (idx.nearest(q),)
+            else:
+                got = idx.knn(q, k)
+                name = idx.last_kernel()[0]
+                idx.set_variant(8)
+                want = idx.knn(q, k)
+            resc = idx.last_evaluated()[1]
+        finally:
+            idx.close()
+        used[name] = used.get(name, 0) + 1
+        ok = all((x == y).all() for x, y in zip(got, want))
+        print("case %3d n_db=%d n_q=%d L=%d k=%d skew=%.1f planted=%.2f cut=%d %s %s" % (case, len(db), len(q), L, k, skew, planted, cut, name, "ok" if ok else "MISMATCH"), flush=True)
+        if not ok:
+            sys.exit(1)
+    print("cases", case, used)
+
+
+if __name__ == "__main__":
+    main()
