@@ -29,6 +29,8 @@ struct gm_index {
     int64_t keys_cap = 0;
     uint32_t* d_keys2 = nullptr;  // K2L scratch (its Hamming seeder uses d_keys at the same time)
     int64_t keys2_cap = 0;
+    uint32_t* d_lvthr = nullptr;  // Levenshtein: per candidate the seeded bound (+ the compact seeds of the second pass, + a counter)
+    int64_t lvthr_cap = 0;
     int64_t n_groups = 0;
     // workspaces (grow-only), so repeated queries do not allocate
     uint2* d_q = nullptr;
@@ -47,6 +49,7 @@ struct gm_index {
     int64_t last_incomplete = 0;  // K1P: candidates handed to the plain scan afterwards
     int variant = 0;
     int lk_seg = 0;               // experiments (gm_set_param "lk_seg"): pool segments of K1P's re-scan, 0 = choose
+    int lv_two_pass = 1;          // Levenshtein: narrow-band first pass + second pass for the short lists (gm_set_param "lv_two_pass")
     int lv_seg = 0;               // experiments (gm_set_param "lv_seg"): pool segments of the Levenshtein scan, 0 = choose
     int n_simd = 1024;            // CUs x 4
     gm_pigeon* pg = nullptr;      // K1P: block-sorted pool copies + query workspaces (built on first use)
@@ -135,6 +138,9 @@ int gm_pg_merge_prefix(gm_index* idx, int kcap, const uint32_t* keys, int n_list
                        hipStream_t st);
 int gm_pg_collect_bad(gm_index* idx, int64_t n_inc, int need, bool nearest, hipStream_t st);
 int gm_pg_read_bad(gm_index* idx, int64_t* n_bad, hipStream_t st);
+// rows i of [0, n) with counts[i] < need -> pg->inc (compact; their number arrives with gm_pg_read_bad); the list itself
+int gm_pg_collect_short(gm_index* idx, int64_t n, int need, const int32_t* counts, hipStream_t st);
+const int32_t* gm_pg_inc_list(const gm_index* idx);
 int gm_pg_blocks_of(const gm_index* idx);
 int gm_pg_block_info(const gm_index* idx, int b, int* positions, int64_t* pairs);
 int gm_pg_radius(const gm_index* idx);      // r of the layout in use: every pair within r is enumerated
@@ -144,9 +150,17 @@ int gm_pg_set_param(gm_index* idx, const char* name, int value);
 void gm_pg_free(gm_index* idx);
 
 // K2L launchers, one per guide length (gm_inst_lv.hip)
+// options of a Levenshtein scan launch: candidate planes other than idx->d_q; narrow-band first pass (K2B): bounds
+// above cap_thr are lowered to it when *cap_cnt (candidates whose seed is at most cap_thr) is >= 70 % of n_q
+struct gm_lv_opt {
+    const uint2* q = nullptr;
+    const int* cap_cnt = nullptr;
+    int cap_thr = 0;
+};
 #define GM_DECL_LV(LEN)                                                                                        \
     int gm_launch_lv_L##LEN(gm_index* idx, int algo, int kcap, int64_t n_q, int k, int n_seg, int tiles_per_seg, \
-                            const int32_t* seed_d, const int32_t* seed_c, int seed_k, uint32_t* keys, hipStream_t st);
+                            const int32_t* seed_d, const int32_t* seed_c, int seed_k, uint32_t* keys, hipStream_t st, \
+                            const gm_lv_opt* opt);
 GM_FOR_EACH_LEN(GM_DECL_LV)
 #undef GM_DECL_LV
 

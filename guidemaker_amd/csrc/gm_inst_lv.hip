@@ -10,11 +10,11 @@ namespace {
 
 template <int L, int KCAP>
 int launch_lv_cfg(gm_index* idx, int64_t n_q, int k, int n_seg, int tiles_per_seg, const int32_t* seed_d,
-                  const int32_t* seed_c, int seed_k, uint32_t* keys, hipStream_t st) {
+                  const int32_t* seed_c, int seed_k, uint32_t* keys, hipStream_t st, const gm_lv_opt& o) {
     const int64_t chunks = (n_q + gm::WAVE - 1) / gm::WAVE;
     const size_t lds = 2 * (size_t)gm::LV_TILE * 16;
     hipLaunchKernelGGL((gm::k_leven_knn_lk<L, KCAP>), dim3((unsigned)chunks, (unsigned)n_seg), dim3(gm::WAVE), lds, st,
-                       idx->d_peq, (int)idx->n_db, (int)idx->n_lv_tiles, tiles_per_seg, idx->d_q, n_q, k, seed_d,
+                       idx->d_peq, (int)idx->n_db, (int)idx->n_lv_tiles, tiles_per_seg, o.q ? o.q : idx->d_q, n_q, k, seed_d,
                        seed_c, seed_k, keys);
     HIP_TRY(hipGetLastError());
     return GM_OK;
@@ -22,16 +22,16 @@ int launch_lv_cfg(gm_index* idx, int64_t n_q, int k, int n_seg, int tiles_per_se
 
 template <int L, int KCAP>
 int launch_lvb_cfg(gm_index* idx, int64_t n_q, int k, int n_seg, int tiles_per_seg, const int32_t* seed_d,
-                   const int32_t* seed_c, int seed_k, uint32_t* keys, hipStream_t st) {
+                   const int32_t* seed_c, int seed_k, uint32_t* keys, hipStream_t st, const gm_lv_opt& o) {
     const int64_t chunks = (n_q + gm::WAVE - 1) / gm::WAVE;
     const size_t lds = 2 * (size_t)gm::lk_tile_bytes(L);
     // band-only workgroups first (the bulk once the bounds are seeded), then the workgroups that need the full matrix
     hipLaunchKernelGGL((gm::k_leven_knn_bs<L, KCAP, false>), dim3((unsigned)chunks, (unsigned)n_seg), dim3(gm::WAVE), lds, st,
-                       idx->d_onehot, (int)idx->n_db, (int)idx->n_lk_tiles, tiles_per_seg, idx->d_q, n_q, k, seed_d,
-                       seed_c, seed_k, keys);
+                       idx->d_onehot, (int)idx->n_db, (int)idx->n_lk_tiles, tiles_per_seg, o.q ? o.q : idx->d_q, n_q, k, seed_d,
+                       seed_c, seed_k, keys, o.cap_cnt, o.cap_thr);
     hipLaunchKernelGGL((gm::k_leven_knn_bs<L, KCAP, true>), dim3((unsigned)chunks, (unsigned)n_seg), dim3(gm::WAVE), lds, st,
-                       idx->d_onehot, (int)idx->n_db, (int)idx->n_lk_tiles, tiles_per_seg, idx->d_q, n_q, k, seed_d,
-                       seed_c, seed_k, keys);
+                       idx->d_onehot, (int)idx->n_db, (int)idx->n_lk_tiles, tiles_per_seg, o.q ? o.q : idx->d_q, n_q, k, seed_d,
+                       seed_c, seed_k, keys, o.cap_cnt, o.cap_thr);
     HIP_TRY(hipGetLastError());
     return GM_OK;
 }
@@ -44,19 +44,20 @@ int launch_lvb_cfg(gm_index* idx, int64_t n_q, int k, int n_seg, int tiles_per_s
 // algo 0 = K2L (Myers per pair, match masks from LDS), 1 = K2B (bit-sliced DP over 32 targets per word)
 int GM_CAT(gm_launch_lv_L, GM_LEN)(gm_index* idx, int algo, int kcap, int64_t n_q, int k, int n_seg, int tiles_per_seg,
                                    const int32_t* seed_d, const int32_t* seed_c, int seed_k, uint32_t* keys,
-                                   hipStream_t st) {
+                                   hipStream_t st, const gm_lv_opt* opt) {
+    const gm_lv_opt o = opt ? *opt : gm_lv_opt{};
     if (algo == 1) {
         switch (kcap) {
-            case 1: return launch_lvb_cfg<GM_LEN, 1>(idx, n_q, k, n_seg, tiles_per_seg, seed_d, seed_c, seed_k, keys, st);
-            case 10: return launch_lvb_cfg<GM_LEN, 10>(idx, n_q, k, n_seg, tiles_per_seg, seed_d, seed_c, seed_k, keys, st);
-            case 20: return launch_lvb_cfg<GM_LEN, 20>(idx, n_q, k, n_seg, tiles_per_seg, seed_d, seed_c, seed_k, keys, st);
+            case 1: return launch_lvb_cfg<GM_LEN, 1>(idx, n_q, k, n_seg, tiles_per_seg, seed_d, seed_c, seed_k, keys, st, o);
+            case 10: return launch_lvb_cfg<GM_LEN, 10>(idx, n_q, k, n_seg, tiles_per_seg, seed_d, seed_c, seed_k, keys, st, o);
+            case 20: return launch_lvb_cfg<GM_LEN, 20>(idx, n_q, k, n_seg, tiles_per_seg, seed_d, seed_c, seed_k, keys, st, o);
             default: return gm_fail(GM_ERR_ARG, "leven bit-sliced kernel: unsupported list capacity");
         }
     }
     switch (kcap) {
-        case 1: return launch_lv_cfg<GM_LEN, 1>(idx, n_q, k, n_seg, tiles_per_seg, seed_d, seed_c, seed_k, keys, st);
-        case 10: return launch_lv_cfg<GM_LEN, 10>(idx, n_q, k, n_seg, tiles_per_seg, seed_d, seed_c, seed_k, keys, st);
-        case 20: return launch_lv_cfg<GM_LEN, 20>(idx, n_q, k, n_seg, tiles_per_seg, seed_d, seed_c, seed_k, keys, st);
+        case 1: return launch_lv_cfg<GM_LEN, 1>(idx, n_q, k, n_seg, tiles_per_seg, seed_d, seed_c, seed_k, keys, st, o);
+        case 10: return launch_lv_cfg<GM_LEN, 10>(idx, n_q, k, n_seg, tiles_per_seg, seed_d, seed_c, seed_k, keys, st, o);
+        case 20: return launch_lv_cfg<GM_LEN, 20>(idx, n_q, k, n_seg, tiles_per_seg, seed_d, seed_c, seed_k, keys, st, o);
         default: return gm_fail(GM_ERR_ARG, "leven look-up kernel: unsupported list capacity");
     }
 }

@@ -322,7 +322,8 @@ __global__ __launch_bounds__(WAVE, (FULL ? GM_LVB_WAVES : GM_LVB_BAND_WAVES)) vo
                                                        int tiles_per_seg, const uint2* __restrict__ q,
                                                        int64_t n_q, int k, const int32_t* __restrict__ seed_dists,
                                                        const int32_t* __restrict__ seed_counts, int seed_k,
-                                                       uint32_t* __restrict__ keys) {
+                                                       uint32_t* __restrict__ keys, const int* __restrict__ cap_cnt,
+                                                       int cap_thr) {
     extern __shared__ __align__(16) uint32_t smem[];
     constexpr int TILE_W = lk_tile_bytes(L) / 4;
     constexpr int GW = lk_group_words(L);
@@ -338,6 +339,10 @@ __global__ __launch_bounds__(WAVE, (FULL ? GM_LVB_WAVES : GM_LVB_BAND_WAVES)) vo
     if (valid && seed_dists != nullptr && (seed_counts == nullptr || seed_counts[qi] >= seed_k))
         thr_seed = seed_dists[qi * seed_k + (seed_k - 1)] + 1;      // lev <= hamming
     if (thr_seed > L + 1) thr_seed = L + 1;
+    // narrow-band first pass (gmhip.hip run_leven_lookup): when most candidates are seeded at or just above cap_thr, every
+    // bound is lowered to it -- the whole launch then runs the narrower band --, and a candidate whose list does not
+    // fill under it is scanned again under its own seed
+    if (cap_cnt != nullptr && thr_seed > cap_thr && (int64_t)(*cap_cnt) * 10 >= n_q * 7) thr_seed = cap_thr;
     int thr = valid ? thr_seed : 0;
     {
         const bool in_band = __builtin_amdgcn_ballot_w64(thr > 2 * lvb_band(L) + 2) == 0ull;

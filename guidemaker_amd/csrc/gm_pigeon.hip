@@ -508,6 +508,14 @@ __global__ __launch_bounds__(256) void k_cand_cutflag(const uint2* __restrict__ 
     flag[i] = f * lam_r >= need + 2.0f * sqrtf((float)k) + 1.0f ? 1 : 0;
 }
 
+
+// rows i of [0, n) with counts[i] < need, compacted (order irrelevant) into out, counted in *n_out
+__global__ __launch_bounds__(256) void k_collect_short(const int32_t* __restrict__ counts, int64_t n, int need,
+                                                       int32_t* __restrict__ out, int* __restrict__ n_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && counts[i] < need) out[atomicAdd(n_out, 1)] = (int32_t)i;
+}
+
 template <class T>
 int ensure(T** p, int64_t* cap, int64_t need, const char* what) {
     if (need <= *cap && *p != nullptr) return GM_OK;
@@ -1554,6 +1562,17 @@ int gm_pg_read_bad(gm_index* idx, int64_t* n_bad, hipStream_t st) {
     *n_bad = pg->box->c.n_bad;
     return GM_OK;
 }
+
+int gm_pg_collect_short(gm_index* idx, int64_t n, int need, const int32_t* counts, hipStream_t st) {
+    gm_pigeon* pg = idx->pg;
+    int rc;
+    if ((rc = ensure(&pg->inc, &pg->inc_cap, n, "incomplete rows"))) return rc;
+    hipLaunchKernelGGL(k_collect_short, grid_for(n), dim3(256), 0, st, counts, n, need, pg->inc, &pg->ctr->n_bad);
+    HIP_TRY(hipGetLastError());
+    return GM_OK;
+}
+
+const int32_t* gm_pg_inc_list(const gm_index* idx) { return idx->pg ? idx->pg->inc : nullptr; }
 
 int gm_pg_scatter(gm_index* idx, int64_t n_inc, int k, bool nearest, int32_t* ids, int32_t* dists, int32_t* counts,
                   hipStream_t st) {

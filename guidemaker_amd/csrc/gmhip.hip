@@ -231,10 +231,11 @@ int run_hamming_lookup(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
 }
 
 int launch_lv_by_len(gm_index* idx, int algo, int kcap, int64_t n_q, int k, int n_seg, int tiles_per_seg,
-                     const int32_t* seed_d, const int32_t* seed_c, int seed_k, uint32_t* keys, hipStream_t st) {
+                     const int32_t* seed_d, const int32_t* seed_c, int seed_k, uint32_t* keys, hipStream_t st,
+                     const gm_lv_opt* opt = nullptr) {
     switch (idx->L) {
 #define GM_CASE(LEN) \
-    case LEN: return gm_launch_lv_L##LEN(idx, algo, kcap, n_q, k, n_seg, tiles_per_seg, seed_d, seed_c, seed_k, keys, st);
+    case LEN: return gm_launch_lv_L##LEN(idx, algo, kcap, n_q, k, n_seg, tiles_per_seg, seed_d, seed_c, seed_k, keys, st, opt);
         GM_FOR_EACH_LEN(GM_CASE)
 #undef GM_CASE
         default: return fail(GM_ERR_ARG, "leven look-up kernel: guidelen out of range");
@@ -251,6 +252,31 @@ bool use_leven_lookup(const gm_index* idx, int k) {
 
 int run_hamming_pigeon(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t* ids, int32_t* dists,
                        int32_t* counts, hipStream_t st, bool* used, bool timed);
+
+// Levenshtein narrow-band first pass: every candidate's seeded bound (Hamming k-th distance + 1; L + 1 without k
+// Hamming neighbours) is kept for the second pass, and the candidates seeded at most one above cap_thr are counted
+__global__ __launch_bounds__(256) void k_lev_seed_stats(const int32_t* __restrict__ dists, const int32_t* __restrict__ counts,
+                                                        int64_t n, int k, int L, int cap_thr, uint32_t* __restrict__ thr_out,
+                                                        int* __restrict__ cnt) {
+    __shared__ int s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const int thr = counts[i] >= k ? dists[i * k + (k - 1)] + 1 : L + 1;
+        thr_out[i] = (uint32_t)thr;
+        if (thr <= cap_thr + 1) atomicAdd(&s_cnt, 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt != 0) atomicAdd(cnt, s_cnt);
+}
+
+// seeds of the second pass: the kept bound - 1 (the kernel adds the 1 back) of the rows listed in inc
+__global__ __launch_bounds__(256) void k_lev_gather_seeds(const uint32_t* __restrict__ thr_all, const int32_t* __restrict__ inc,
+                                                          int64_t n, int32_t* __restrict__ seeds) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) seeds[j] = (int32_t)thr_all[inc[j]] - 1;
+}
 
 int run_leven_lookup(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* dists, int32_t* counts,
                      int32_t* d1, hipStream_t st) {
@@ -285,17 +311,67 @@ int run_leven_lookup(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* d
     const int n_seg = (int)((n_tiles + tiles_per_seg - 1) / tiles_per_seg);
     // own scratch: the Hamming seeder enqueued above may still be using idx->d_keys
     if ((rc = ensure_u32(&idx->d_keys2, &idx->keys2_cap, (int64_t)n_seg * n_q * kcap))) return rc;
+    // Narrow-band first pass (K2B, k-NN, pools large enough for the partitioned Hamming seeder).  The Hamming seeds put
+    // most bounds one above what the next narrower band serves (S2, L = 23: 85 % of the candidates at "lev < 9", band 4),
+    // while the k-th Levenshtein neighbour itself is closer (7 for 97 % of them).  So when most seeds are that close, ALL
+    // bounds are lowered to 2 (BAND - 1) + 2 ("lev < 8": band 3, 149 of 187 cells), a list that fills under it is exact
+    // (every target within 7 was enumerated), and the candidates whose list stays short (S2: 3 %) are scanned again
+    // under their own seeds.  The kernel takes the decision from a counter on the device: no read-back for it.
+    const int band = ((3 * idx->L + 4) / 8) / 2;      // lvb_band(L), gm_leven_bs.hip.h
+    const int cap_thr = 2 * (band - 1) + 2;
+    const bool two_pass = !nearest && algo == 1 && seeded && band - 1 >= 2 && idx->lv_two_pass && n_q >= 4096;
+    gm_lv_opt opt{};
+    uint32_t* thr_all = nullptr;
+    if (two_pass) {
+        // [n_q bounds][n_q compact seeds][1 counter]
+        if ((rc = ensure_u32(&idx->d_lvthr, &idx->lvthr_cap, 2 * n_q + 4))) return rc;
+        thr_all = idx->d_lvthr;
+        int* cnt = reinterpret_cast<int*>(idx->d_lvthr + 2 * n_q);
+        HIP_TRY(hipMemsetAsync(cnt, 0, sizeof(int), st));
+        hipLaunchKernelGGL(k_lev_seed_stats, dim3((unsigned)((n_q + 255) / 256)), dim3(256), 0, st, dists, counts, n_q, k, idx->L,
+                           cap_thr, thr_all, cnt);
+        HIP_TRY(hipGetLastError());
+        opt.cap_cnt = cnt;
+        opt.cap_thr = cap_thr;
+    }
     rc = timing_begin(idx, st);
     if (rc) return rc;
     idx->last_kernel = algo == 1 ? (nearest ? "k_leven_knn_bs(nearest)" : "k_leven_knn_bs")
                                  : (nearest ? "k_leven_knn_lk(nearest)" : "k_leven_knn_lk");
     rc = nearest ? launch_lv_by_len(idx, algo, kcap, n_q, 1, n_seg, tiles_per_seg, d1, nullptr, 1, idx->d_keys2, st)
-                 : launch_lv_by_len(idx, algo, kcap, n_q, k, n_seg, tiles_per_seg, dists, counts, k, idx->d_keys2, st);
+                 : launch_lv_by_len(idx, algo, kcap, n_q, k, n_seg, tiles_per_seg, dists, counts, k, idx->d_keys2, st, &opt);
     if (rc) return rc;
     rc = timing_end(idx, st, n_q * idx->n_db);
     if (rc) return rc;
-    return nearest ? launch_merge(kcap, idx->d_keys2, n_seg, n_q, 1, nullptr, d1, nullptr, true, st)
-                   : launch_merge(kcap, idx->d_keys2, n_seg, n_q, k, ids, dists, counts, false, st);
+    rc = nearest ? launch_merge(kcap, idx->d_keys2, n_seg, n_q, 1, nullptr, d1, nullptr, true, st)
+                 : launch_merge(kcap, idx->d_keys2, n_seg, n_q, k, ids, dists, counts, false, st);
+    if (rc || !two_pass) return rc;
+    // second pass: the candidates whose list did not fill (none when the first pass ran under the seeds themselves)
+    if ((rc = gm_pg_collect_short(idx, n_q, k, counts, st))) return rc;
+    int64_t n2 = 0;
+    if ((rc = gm_pg_read_bad(idx, &n2, st))) return rc;
+    idx->last_incomplete = n2;
+    if (n2 == 0) return GM_OK;
+    const uint2* q2 = nullptr;
+    int32_t *ids2 = nullptr, *dists2 = nullptr, *counts2 = nullptr;
+    if ((rc = gm_pg_gather(idx, n2, k, false, &q2, &ids2, &dists2, &counts2, st))) return rc;
+    int32_t* seeds2 = reinterpret_cast<int32_t*>(idx->d_lvthr + n_q);
+    hipLaunchKernelGGL(k_lev_gather_seeds, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, thr_all, gm_pg_inc_list(idx), n2,
+                       seeds2);
+    HIP_TRY(hipGetLastError());
+    const int64_t chunks2 = (n2 + gm::WAVE - 1) / gm::WAVE;
+    int64_t want2 = ((int64_t)idx->n_simd * 8 + chunks2 - 1) / chunks2;
+    if (want2 > 64) want2 = 64;
+    if (want2 < 1) want2 = 1;
+    if (want2 > n_tiles) want2 = n_tiles;
+    const int tps2 = (int)((n_tiles + want2 - 1) / want2);
+    const int n_seg2 = (int)((n_tiles + tps2 - 1) / tps2);
+    if ((rc = ensure_u32(&idx->d_keys2, &idx->keys2_cap, (int64_t)n_seg2 * n2 * kcap))) return rc;
+    gm_lv_opt opt2{};
+    opt2.q = q2;
+    if ((rc = launch_lv_by_len(idx, algo, kcap, n2, k, n_seg2, tps2, seeds2, nullptr, 1, idx->d_keys2, st, &opt2))) return rc;
+    if ((rc = launch_merge(kcap, idx->d_keys2, n_seg2, n2, k, ids2, dists2, counts2, false, st))) return rc;
+    return gm_pg_scatter(idx, n2, k, false, ids, dists, counts, st);
 }
 
 // K1P prefix re-scan (gm_pg_prefix_fraction): K1L over the first `frac` of the pool (id order) for the n compacted rows
@@ -663,6 +739,7 @@ void gm_index_free(gm_index* idx) {
     if (idx->d_peq) (void)hipFree(idx->d_peq);
     if (idx->d_keys) (void)hipFree(idx->d_keys);
     if (idx->d_keys2) (void)hipFree(idx->d_keys2);
+    if (idx->d_lvthr) (void)hipFree(idx->d_lvthr);
     if (idx->d_q) (void)hipFree(idx->d_q);
     if (idx->d_stage) (void)hipFree(idx->d_stage);
     timing_clear(idx);
@@ -692,6 +769,10 @@ int gm_set_param(gm_index* idx, const char* name, int value) {
     }
     if (std::strcmp(name, "lv_seg") == 0) {
         idx->lv_seg = value;
+        return GM_OK;
+    }
+    if (std::strcmp(name, "lv_two_pass") == 0) {
+        idx->lv_two_pass = value;
         return GM_OK;
     }
     return gm_pg_set_param(idx, name, value);

@@ -204,6 +204,8 @@ int gm_set_variant(gm_index* idx, int variant);
  *   per run of blocks with equal positions; measured slower), otherwise as many positions as the shortest block has
  *   (one launch, the default);
  *   "lv_seg": pool segments of the Levenshtein scan (0 = choose);
+ *   "lv_two_pass": 0 = the Levenshtein scan runs once under the Hamming seeds; 1 (default) = where most seeds sit just
+ *   above the next narrower band, first under that band's bound, then again for the candidates whose list stayed short;
  *   "pg_cut": K1P's id cut-off for hits at the layout's radius (0 = choose, 1..99 = that percentage of the ids, 100 = off);
  *   "pg_prefix": 0 = K1P's incomplete rows go straight to the plain re-scan (A/B, tests); 1 (default) = first a scan of
  *   the pool's first part, which holds the few neighbours at r + 1 such a row still needs (gm_pigeon.hip);

@@ -152,6 +152,12 @@ def test_leven_workload_full_size(oracle):
         _, hd, _ = hidx.knn(q, k)
         hidx.close()
         assert (dists <= hd).all()
+        # narrow-band first pass + second pass for the short lists (default) against one pass under the Hamming seeds
+        assert idx.last_evaluated()[1] > 0      # (S2: ~3 % of the candidates take the second pass)
+        idx.set_param("lv_two_pass", 0)
+        i1, d1, c1 = idx.knn(q, k)
+        assert (i1 == ids).all() and (d1 == dists).all() and (c1 == counts).all()
+        idx.set_param("lv_two_pass", 1)
         # the whole result against the per-pair Myers kernel K2L
         idx.set_variant(2)
         i2, d2, c2 = idx.knn(q, k)
