@@ -72,13 +72,13 @@ def _tree_ops(L):
     return ops
 
 
-def bitsliced_leven_ops_per_pair(L):
+def bitsliced_leven_ops_per_pair(L, narrow=False):
     """USEFUL VALU lane-ops per guide pair of K2B (gm_leven_bs.hip.h) on its banded path (every lane's bound within
     2 BAND + 2, the common case once the bounds are seeded): per 32-target word 5 ops per DP cell of the band
     |i - j| <= BAND = ((3L + 4) // 8) // 2, one count tree over the diagonal and the 5-op threshold compare.  Groups
     that take the full-matrix path execute more, groups on the narrower band fewer; the counter-derived figure
     (roofline.achieved) is the one that is measured."""
-    band = ((3 * L + 4) // 8) // 2
+    band = ((3 * L + 4) // 8) // 2 - (1 if narrow else 0)      # narrow: the first pass of the two-pass scan (bounds lowered)
     cells = L * (2 * band + 1) - band * (band + 1)
     per_word = 5.0 * cells + _tree_ops(L) + 5
     return per_word / 32.0
@@ -116,8 +116,10 @@ def roofline_block(workload, pool, kname, kern_s, n_timed, query_ms, launch_pair
         model = ("2 v_bitop3 per adder of the carry-save tree over the match words (%.2f positions per pair on average) "
                  "+ 5 comparator ops per 32 pairs + 1 v_cmp per 64" % L_eval)
     elif "knn_bs" in kname:
-        useful_opp = bitsliced_leven_ops_per_pair(L)
-        model = "5 ops per DP cell of the band per 32 pairs + diagonal count tree + comparator (banded path)"
+        # candidates re-scanned > 0 <=> the timed launch was the narrow-band first pass of the two-pass scan
+        useful_opp = bitsliced_leven_ops_per_pair(L, narrow=rescanned > 0)
+        model = ("5 ops per DP cell of the band per 32 pairs + diagonal count tree + comparator (banded path%s)"
+                 % (", narrow-band first pass" if rescanned > 0 else ""))
     else:
         useful_opp = 11.0 * L + 12.0
         model = "per-pair Myers: 11 ops per text position + tail"
