@@ -390,6 +390,7 @@ int run_hamming_prefix(gm_index* idx, bool nearest, int64_t n, int k, int kcap, 
     if (n_tiles_p > idx->n_lk_tiles) n_tiles_p = idx->n_lk_tiles;
     int64_t n_seg = ((int64_t)idx->n_simd * 8 + chunks - 1) / chunks;      // about one workgroup per wave slot
     if (n_seg > 64) n_seg = 64;
+    if (idx->lk_seg > 0) n_seg = idx->lk_seg;      // (experiments)
     if (n_seg > n_tiles_p / 2) n_seg = n_tiles_p / 2;
     if (n_seg < 1) n_seg = 1;
     int64_t tps = (n_tiles_p + n_seg - 1) / n_seg;
