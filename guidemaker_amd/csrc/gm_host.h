@@ -141,6 +141,7 @@ int gm_pg_read_bad(gm_index* idx, int64_t* n_bad, hipStream_t st);
 // rows i of [0, n) with counts[i] < need -> pg->inc (compact; their number arrives with gm_pg_read_bad); the list itself
 int gm_pg_collect_short(gm_index* idx, int64_t n, int need, const int32_t* counts, hipStream_t st);
 const int32_t* gm_pg_inc_list(const gm_index* idx);
+int gm_pg_debug_flags(const gm_index* idx);      // gm_set_param "pg_debug" (timing experiments)
 int gm_pg_blocks_of(const gm_index* idx);
 int gm_pg_block_info(const gm_index* idx, int b, int* positions, int64_t* pairs);
 int gm_pg_radius(const gm_index* idx);      // r of the layout in use: every pair within r is enumerated

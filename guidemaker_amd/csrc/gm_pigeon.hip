@@ -1573,6 +1573,7 @@ int gm_pg_collect_short(gm_index* idx, int64_t n, int need, const int32_t* count
 }
 
 const int32_t* gm_pg_inc_list(const gm_index* idx) { return idx->pg ? idx->pg->inc : nullptr; }
+int gm_pg_debug_flags(const gm_index* idx) { return idx->pg ? idx->pg->tune_debug : 0; }
 
 int gm_pg_scatter(gm_index* idx, int64_t n_inc, int k, bool nearest, int32_t* ids, int32_t* dists, int32_t* counts,
                   hipStream_t st) {

@@ -478,7 +478,7 @@ int run_hamming_pigeon(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
     }
     // A pool of repeat families floods the hit lists and K1P ends up handing most rows to the plain scan: twice the
     // work of the plain scan alone.  The answer of this query stands (exact either way); remember it for the next.
-    if (planned && n_inc > n_q / 3 && n_q >= 4096) idx->pg_flooded_k1 = keff + 1;
+    if (planned && n_inc > n_q / 3 && n_q >= 4096 && gm_pg_debug_flags(idx) == 0) idx->pg_flooded_k1 = keff + 1;
     if (n_inc > 0) {
         const uint2* q2 = nullptr;
         int32_t *ids2 = nullptr, *dists2 = nullptr, *counts2 = nullptr;

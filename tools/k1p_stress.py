@@ -32,6 +32,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--leven", type=float, default=0.15, help="share of Levenshtein cases")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     t0, case, used = time.time(), 0, {"k_hamming_scan_pg": 0}
@@ -45,6 +46,25 @@ def main():
         cut = int(rng.choice([0, 0, 0, 10, 30, 60, 100]))
         db = pool(rng, n, L, skew, planted)
         q = np.concatenate([db[: int(rng.integers(1000, min(len(db), 120_000)))], pool(rng, 3000, L, skew, 0.0)])
+        if rng.random() < a.leven:      # Levenshtein: two-pass scan (narrow band first) against the single pass
+            db = db[: int(rng.integers(33_000, min(len(db), 90_000)))]
+            q = np.concatenate([db[: int(rng.integers(4100, min(len(db), 30_000)))], pool(rng, 500, L, skew, 0.0)])
+            k = int(rng.choice([2, 3, 5, 10]))
+            idx = _lib.Index(db, L, _lib.METRIC_LEVEN)
+            try:
+                got = idx.knn(q, k)
+                name, resc = idx.last_kernel()[0], idx.last_evaluated()[1]
+                idx.set_param("lv_two_pass", 0)
+                want = idx.knn(q, k)
+            finally:
+                idx.close()
+            used[name] = used.get(name, 0) + 1
+            ok = all((x == y).all() for x, y in zip(got, want))
+            print("case %3d leven n_db=%d n_q=%d L=%d k=%d skew=%.1f planted=%.2f second pass %d rows %s" %
+                  (case, len(db), len(q), L, k, skew, planted, resc, "ok" if ok else "MISMATCH"), flush=True)
+            if not ok:
+                sys.exit(1)
+            continue
         idx = _lib.Index(db, L, _lib.METRIC_HAMMING)
         try:
             idx.set_param("pg_cut", cut)
