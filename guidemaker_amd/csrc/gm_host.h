@@ -152,7 +152,7 @@ void gm_pg_free(gm_index* idx);
 
 // K2L launchers, one per guide length (gm_inst_lv.hip)
 // options of a Levenshtein scan launch: candidate planes other than idx->d_q; narrow-band first pass (K2B): bounds
-// above cap_thr are lowered to it when *cap_cnt (candidates whose seed is at most cap_thr) is >= 70 % of n_q
+// above cap_thr are lowered to it when *cap_cnt (candidates whose seed is at most cap_thr) is >= 90 % of n_q
 struct gm_lv_opt {
     const uint2* q = nullptr;
     const int* cap_cnt = nullptr;

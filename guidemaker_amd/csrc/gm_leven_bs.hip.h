@@ -342,7 +342,7 @@ __global__ __launch_bounds__(WAVE, (FULL ? GM_LVB_WAVES : GM_LVB_BAND_WAVES)) vo
     // narrow-band first pass (gmhip.hip run_leven_lookup): when most candidates are seeded at or just above cap_thr, every
     // bound is lowered to it -- the whole launch then runs the narrower band --, and a candidate whose list does not
     // fill under it is scanned again under its own seed
-    if (cap_cnt != nullptr && thr_seed > cap_thr && (int64_t)(*cap_cnt) * 10 >= n_q * 7) thr_seed = cap_thr;
+    if (cap_cnt != nullptr && thr_seed > cap_thr && (int64_t)(*cap_cnt) * 10 >= n_q * 9) thr_seed = cap_thr;
     int thr = valid ? thr_seed : 0;
     {
         const bool in_band = __builtin_amdgcn_ballot_w64(thr > 2 * lvb_band(L) + 2) == 0ull;
