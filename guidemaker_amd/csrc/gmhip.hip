@@ -351,6 +351,7 @@ int run_leven_lookup(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* d
     int64_t n2 = 0;
     if ((rc = gm_pg_read_bad(idx, &n2, st))) return rc;
     idx->last_incomplete = n2;
+    if (n2 * 4 > n_q) idx->lv_two_pass = 0;      // the lowered bound left a quarter of the lists short on this pool: not again
     if (n2 == 0) return GM_OK;
     const uint2* q2 = nullptr;
     int32_t *ids2 = nullptr, *dists2 = nullptr, *counts2 = nullptr;
