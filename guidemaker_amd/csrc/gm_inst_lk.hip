@@ -20,8 +20,15 @@ int launch_lk_cfg(gm_index* idx, const gm_lk_args& a, hipStream_t st) {
         if (pad > lds) lds = pad;
     }
     auto kern = gm::k_hamming_knn_lk<L, KCAP, NEAREST, SEEDED>;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds));
+    // (once per instantiation, device and size: the call costs ~5 us of host time, and the re-scan launches sit on the
+    // critical path right after a read-back)
+    static size_t lds_set[64] = {};
+    const int dev = idx->device >= 0 && idx->device < 64 ? idx->device : 0;
+    if (lds > lds_set[dev]) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+        lds_set[dev] = lds;
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)chunks, (unsigned)a.n_seg), dim3(gm::WAVE), lds, st, idx->d_onehot,
                        (int)idx->n_db, a.n_tiles > 0 ? a.n_tiles : (int)idx->n_lk_tiles, a.tiles_per_seg, a.seg_base, a.q ? a.q : idx->d_q, a.n_q, a.k,
                        a.seed_keys, a.out_keys, a.ids, a.dists, a.counts);
