@@ -80,6 +80,8 @@ def lib():
     L.gm_device_count.restype = i32
     L.gm_pack.argtypes = [c.c_char_p, i64, i32, vp]
     L.gm_unpack.argtypes = [vp, i64, i32, vp]
+    L.gm_format_doubles.argtypes = [vp, i64, vp, i64]
+    L.gm_format_doubles.restype = i64
     L.gm_index_create.argtypes = [vp, i64, i32, i32, i32, c.POINTER(vp)]
     L.gm_index_create_dev.argtypes = [vp, i64, i32, i32, i32, vp, c.POINTER(vp)]
     L.gm_index_free.argtypes = [vp]
@@ -156,7 +158,7 @@ def lib():
 
 # every symbol include/gmhip.h declares (tests check the built library exports them all)
 EXPORTS = [
-    "gm_version", "gm_last_error", "gm_device_count", "gm_pack", "gm_unpack", "gm_index_create",
+    "gm_version", "gm_last_error", "gm_device_count", "gm_pack", "gm_unpack", "gm_format_doubles", "gm_index_create",
     "gm_index_create_dev", "gm_index_free", "gm_index_size", "gm_index_guidelen", "gm_index_metric",
     "gm_knn_query", "gm_knn_query_dev", "gm_nearest_dist", "gm_nearest_dist_dev", "gm_cfd_batch",
     "gm_cfd_batch_dev", "gm_last_kernel_ms", "gm_last_query_ms", "gm_last_kernel_name", "gm_last_kernel_pairs",
@@ -215,6 +217,19 @@ def unpack(packed, guidelen):
         return []
     # one vectorised bytes -> str conversion instead of a Python-level decode per row
     return np.ascontiguousarray(buf).view("S%d" % guidelen).ravel().astype(str).tolist()
+
+
+def format_doubles(values):
+    """[str(x) for x in values] for a float64 array -- Python's float repr, formatted natively (host code)."""
+    v = np.ascontiguousarray(values, dtype=np.float64)
+    n = int(v.shape[0])
+    if n == 0:
+        return []
+    buf = np.empty((25 * n + 8,), np.uint8)
+    w = lib().gm_format_doubles(_ptr(v), n, _ptr(buf), buf.shape[0])
+    if w < 0:
+        raise GmHipError("gm_format_doubles failed")
+    return buf[:w].tobytes().decode("ascii").split("\n")
 
 
 class Index:

@@ -879,7 +879,7 @@ def cfd_score(df, device: int = 0):
     ends = np.cumsum(per_row)
     starts = ends - per_row
     # str(float), as the reference formats them (CFD products are almost all distinct: nothing to share)
-    flat_l = list(map(str, scores.tolist()))
+    flat_l = _lib.format_doubles(scores)      # Python's float repr, formatted natively on the host's threads
     if len(per_row) and (per_row == per_row[0]).all():
         w = int(per_row[0])
         lists = [flat_l[a:a + w] for a in range(0, n, w)]

@@ -5,6 +5,9 @@
 #include "gm_lookup.hip.h"   // k_to_onehot only; the scan kernels are instantiated in gm_inst_lk.hip
 #include "gm_leven.hip.h"    // k_to_peq, k_leven_merge; the scan kernels are instantiated in gm_inst_lv.hip
 
+#include <charconv>
+#include <thread>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 
@@ -613,6 +616,124 @@ int gm_unpack(const uint64_t* packed, int64_t n, int guidelen, char* out) {
     for (int64_t i = 0; i < n; ++i)
         for (int p = 0; p < guidelen; ++p) out[i * guidelen + p] = B[(packed[i] >> (2 * p)) & 3u];
     return GM_OK;
+}
+
+// str(float) of Python for every value, separated by '\n' (host code: the reference's 'CFD Similar Guides' column is a
+// list of str(float) per row, core.py:1136, and Python spends 2 s on 5.9 M of them).  Python's repr: the shortest
+// decimal string that reads back as the same double -- std::to_chars' digits --, fixed notation for a decimal point
+// position in (-4, 16], else exponent notation with at least two exponent digits.  Returns the bytes written, or -1
+// when `cap` is too small (25 bytes per value always suffice).
+static int64_t format_doubles_serial(const double* v, int64_t n, char* out, int64_t cap) {
+    int64_t w = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (w + 26 > cap) return -1;
+        if (i) out[w++] = '\n';
+        const double x = v[i];
+        if (x != x) {
+            std::memcpy(out + w, "nan", 3);
+            w += 3;
+            continue;
+        }
+        if (x == HUGE_VAL || x == -HUGE_VAL) {
+            const char* t = x > 0 ? "inf" : "-inf";
+            const size_t len = std::strlen(t);
+            std::memcpy(out + w, t, len);
+            w += (int64_t)len;
+            continue;
+        }
+        char buf[40];
+        auto res = std::to_chars(buf, buf + sizeof(buf), x, std::chars_format::scientific);      // [-]d[.ddd]e[+-]XX, shortest
+        const char* p = buf;
+        if (*p == '-') out[w++] = *p++;
+        char digits[24];
+        int nd = 0;
+        while (p < res.ptr && *p != 'e') {
+            if (*p != '.') digits[nd++] = *p;
+            ++p;
+        }
+        int e10 = 0;
+        if (p < res.ptr && *p == 'e') {
+            ++p;
+            const bool neg = *p == '-';
+            if (*p == '+' || *p == '-') ++p;
+            while (p < res.ptr) e10 = e10 * 10 + (*p++ - '0');
+            if (neg) e10 = -e10;
+        }
+        const int decpt = e10 + 1;      // digits * 10^(decpt - nd): the decimal point sits after `decpt` digits
+        if (nd == 1 && digits[0] == '0') {      // +-0.0
+            std::memcpy(out + w, "0.0", 3);
+            w += 3;
+        } else if (decpt > -4 && decpt <= 16) {
+            if (decpt <= 0) {
+                out[w++] = '0';
+                out[w++] = '.';
+                for (int z = 0; z < -decpt; ++z) out[w++] = '0';
+                std::memcpy(out + w, digits, (size_t)nd);
+                w += nd;
+            } else if (decpt >= nd) {
+                std::memcpy(out + w, digits, (size_t)nd);
+                w += nd;
+                for (int z = 0; z < decpt - nd; ++z) out[w++] = '0';
+                out[w++] = '.';
+                out[w++] = '0';
+            } else {
+                std::memcpy(out + w, digits, (size_t)decpt);
+                w += decpt;
+                out[w++] = '.';
+                std::memcpy(out + w, digits + decpt, (size_t)(nd - decpt));
+                w += nd - decpt;
+            }
+        } else {
+            out[w++] = digits[0];
+            if (nd > 1) {
+                out[w++] = '.';
+                std::memcpy(out + w, digits + 1, (size_t)(nd - 1));
+                w += nd - 1;
+            }
+            out[w++] = 'e';
+            int ex = decpt - 1;
+            out[w++] = ex < 0 ? '-' : '+';
+            if (ex < 0) ex = -ex;
+            char eb[8];
+            int ne = 0;
+            do {
+                eb[ne++] = (char)('0' + ex % 10);
+                ex /= 10;
+            } while (ex);
+            if (ne < 2) eb[ne++] = '0';
+            while (ne) out[w++] = eb[--ne];
+        }
+    }
+    return w;
+}
+
+int64_t gm_format_doubles(const double* v, int64_t n, char* out, int64_t cap) {
+    if (!v || !out || n < 0) return -1;
+    if (n == 0) return 0;
+    if (cap < 26) return -1;
+    // slices on the host's threads, each into its own 25-byte-per-value region of `out`, then closed up in order
+    unsigned hw = std::thread::hardware_concurrency();
+    int64_t n_thr = hw ? (int64_t)hw : 4;
+    if (n_thr > 32) n_thr = 32;
+    if (n_thr > n / 65536 + 1) n_thr = n / 65536 + 1;
+    if (n_thr <= 1 || cap < 25 * n) return format_doubles_serial(v, n, out, cap);
+    const int64_t per = (n + n_thr - 1) / n_thr;
+    std::vector<int64_t> len((size_t)n_thr, 0);
+    std::vector<std::thread> pool;
+    for (int64_t t = 0; t < n_thr; ++t) {
+        const int64_t lo = t * per, hi = lo + per < n ? lo + per : n;
+        if (lo >= hi) break;
+        pool.emplace_back([=, &len] { len[(size_t)t] = format_doubles_serial(v + lo, hi - lo, out + 25 * lo, 25 * (hi - lo)); });
+    }
+    for (auto& th : pool) th.join();
+    int64_t w = 0;
+    for (int64_t t = 0; t < (int64_t)pool.size(); ++t) {
+        if (len[(size_t)t] < 0) return -1;
+        if (t) out[w++] = '\n';
+        std::memmove(out + w, out + 25 * (t * per), (size_t)len[(size_t)t]);
+        w += len[(size_t)t];
+    }
+    return w;
 }
 
 int gm_index_create_dev(const void* d_packed, int64_t n_db, int guidelen, int metric, int device,

@@ -68,6 +68,10 @@ int gm_device_count(void);
 /* ASCII -> packed.  seqs: n rows of guidelen chars, no terminators.  GM_ERR_SEQ on a non-ACGT base. */
 int gm_pack(const char* seqs, int64_t n, int guidelen, uint64_t* out);
 int gm_unpack(const uint64_t* packed, int64_t n, int guidelen, char* out);
+/* Python's str(float) of v[0..n), separated by '\n', into out (host code, no GPU): the 'CFD Similar Guides' column of
+ * core.cfd_score (reference core.py:1136) is a list of str(float) per row.  Returns the bytes written, -1 when cap is
+ * too small (25 n always suffices). */
+int64_t gm_format_doubles(const double* v, int64_t n, char* out, int64_t cap);
 
 /* Build the (exact, brute-force) index on GPU `device`: copies the packed db to HBM as bit planes. */
 int gm_index_create(const uint64_t* packed, int64_t n_db, int guidelen, int metric, int device,

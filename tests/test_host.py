@@ -325,3 +325,19 @@ def test_optional_gpu_config_block(tmp_path, monkeypatch):
     tp = core.TargetProcessor(targets_frame(["ACGTACGTACGTACGTACGT"]), lsr=0)
     tp.create_index(str(p))
     assert calls["device"] == 0
+
+
+def test_format_doubles_is_pythons_str_of_float():
+    """gm_format_doubles (the 'CFD Similar Guides' strings of core.cfd_score) against str(float): random values over
+    every magnitude, the notation switch points, zeros, denormals, infinities."""
+    from guidemaker_amd import _lib
+    rng = np.random.default_rng(12)
+    vals = np.concatenate([rng.random(300_000), rng.random(50_000) * 1e-5, 10.0 ** rng.uniform(-300, 300, size=100_000),
+                           -(10.0 ** rng.uniform(-20, 20, size=20_000)), np.round(rng.random(50_000), 3),
+                           np.array([0.0, -0.0, 1.0, 0.5, 1e16, 1e15, 9999999999999998.0, 123456789012345678.0, 1e-4, 1e-5,
+                                     0.0001234, 5e-324, 2.2250738585072014e-308, 1.7976931348623157e308, float("inf"),
+                                     float("-inf"), float("nan"), 0.176470588, 1e22, 1e21, 0.1 + 0.2, 1 / 3])])
+    got = _lib.format_doubles(vals)
+    want = [str(x) for x in vals.tolist()]
+    assert got == want
+    assert _lib.format_doubles(np.array([0.25])) == ["0.25"] and _lib.format_doubles(np.array([])) == []
