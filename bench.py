@@ -172,8 +172,10 @@ def roofline_block(workload, pool, kname, kern_s, n_timed, query_ms, launch_pair
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    # (defaults: 200 steps of ~1 ms -- a timed region of tens of milliseconds measures the clock ramp as much as the kernels:
+    # S1 runs 0.96 ms/step over 10 steps and 0.87 over 200 or 1000)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="s1", choices=["s1", "s2", "s3", "s4", "tiny"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
