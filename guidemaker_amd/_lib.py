@@ -82,6 +82,7 @@ def lib():
     L.gm_unpack.argtypes = [vp, i64, i32, vp]
     L.gm_format_doubles.argtypes = [vp, i64, vp, i64]
     L.gm_format_doubles.restype = i64
+    L.gm_format_neighbor_rows.argtypes = [vp, i64, i32, vp, vp, vp, i64, i32, vp, i64, vp, i64, c.POINTER(i64), c.POINTER(i64)]
     L.gm_index_create.argtypes = [vp, i64, i32, i32, i32, c.POINTER(vp)]
     L.gm_index_create_dev.argtypes = [vp, i64, i32, i32, i32, vp, c.POINTER(vp)]
     L.gm_index_free.argtypes = [vp]
@@ -158,7 +159,7 @@ def lib():
 
 # every symbol include/gmhip.h declares (tests check the built library exports them all)
 EXPORTS = [
-    "gm_version", "gm_last_error", "gm_device_count", "gm_pack", "gm_unpack", "gm_format_doubles", "gm_index_create",
+    "gm_version", "gm_last_error", "gm_device_count", "gm_pack", "gm_unpack", "gm_format_doubles", "gm_format_neighbor_rows", "gm_index_create",
     "gm_index_create_dev", "gm_index_free", "gm_index_size", "gm_index_guidelen", "gm_index_metric",
     "gm_knn_query", "gm_knn_query_dev", "gm_nearest_dist", "gm_nearest_dist_dev", "gm_cfd_batch",
     "gm_cfd_batch_dev", "gm_last_kernel_ms", "gm_last_query_ms", "gm_last_kernel_name", "gm_last_kernel_pairs",
@@ -230,6 +231,23 @@ def format_doubles(values):
     if w < 0:
         raise GmHipError("gm_format_doubles failed")
     return buf[:w].tobytes().decode("ascii").split("\n")
+
+
+def format_neighbor_rows(db_packed, guidelen, ids, dists, counts):
+    """(similar guides, similar guide distances): per result row the ';'-joined neighbour sequences and distances."""
+    db = np.ascontiguousarray(db_packed, dtype=np.uint64)
+    ids = np.ascontiguousarray(ids, dtype=np.int32)
+    dists = np.ascontiguousarray(dists, dtype=np.int32)
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    n, k = ids.shape
+    if n == 0:
+        return [], []
+    bs = np.empty((n * k * (guidelen + 1),), np.uint8)
+    bd = np.empty((n * k * 12,), np.uint8)
+    ls, ld = ctypes.c_int64(), ctypes.c_int64()
+    _check(lib().gm_format_neighbor_rows(_ptr(db), db.shape[0], guidelen, _ptr(ids), _ptr(dists), _ptr(counts), n, k, _ptr(bs),
+                                         bs.shape[0], _ptr(bd), bd.shape[0], ctypes.byref(ls), ctypes.byref(ld)))
+    return (bs[:ls.value].tobytes().decode("ascii").split("\n"), bd[:ld.value].tobytes().decode("ascii").split("\n"))
 
 
 class Index:

@@ -688,6 +688,9 @@ def format_neighbor_columns(targetprocessor_object, guide_sequences):
     rows = np.fromiter((rowmap[g] for g in guides), dtype=np.int64, count=n)
     ids, dists, counts = nb.ids[rows], nb.dists[rows], nb.counts[rows]
     k = ids.shape[1]
+    if nb._dbp is not None and nb._L is not None and 1 <= nb._L <= _lib.MAX_GUIDELEN:
+        # the index's targets are at hand in packed form: both columns natively (libgmhip, host threads)
+        return _lib.format_neighbor_rows(nb._dbp, nb._L, ids, dists, counts)
     db = nb._db
     L = len(db[0]) if len(db) else 0
     full = counts == k

@@ -736,6 +736,116 @@ int64_t gm_format_doubles(const double* v, int64_t n, char* out, int64_t cap) {
     return w;
 }
 
+// The two neighbour columns of the reference's output table (Annotation._format_guide_table, core.py:913-931), row by row
+// from the k-NN result arrays: out_seqs = ";".join(sequences of the row's counts[r] hits), out_dists = ";".join(str(d)),
+// rows separated by '\n' (host code, the host's threads).  Returns 0 and the two lengths, -1 when a buffer is too small
+// (n * k * (guidelen + 1) and n * k * 12 bytes always suffice).
+static void format_rows_serial(const uint64_t* db, int64_t n_db, int L, const int32_t* ids, const int32_t* dists,
+                               const int32_t* counts, int64_t n, int k, char* os, char* od, int64_t* ls, int64_t* ld,
+                               int* bad) {
+    // four bases per table look-up: byte of the packed word -> 4 characters
+    static const struct Lut {
+        uint32_t w[256];
+        Lut() {
+            static const char B[4] = {'A', 'C', 'G', 'T'};
+            for (int v = 0; v < 256; ++v) {
+                char c[4] = {B[v & 3], B[(v >> 2) & 3], B[(v >> 4) & 3], B[(v >> 6) & 3]};
+                std::memcpy(&w[v], c, 4);
+            }
+        }
+    } lut;
+    int64_t ws = 0, wd = 0;
+    for (int64_t r = 0; r < n; ++r) {
+        if (r) {
+            os[ws++] = '\n';
+            od[wd++] = '\n';
+        }
+        const int c = counts[r] < k ? counts[r] : k;
+        for (int j = 0; j < c; ++j) {
+            if (j) {
+                os[ws++] = ';';
+                od[wd++] = ';';
+            }
+            const int32_t id = ids[r * k + j];
+            if (id < 0 || id >= n_db) {
+                *bad = 1;
+                continue;
+            }
+            uint64_t w = db[id];
+            char seq[32];
+            for (int p = 0; p < 28; p += 4, w >>= 8) std::memcpy(seq + p, &lut.w[w & 0xff], 4);
+            std::memcpy(os + ws, seq, (size_t)L);
+            ws += L;
+            int d = dists[r * k + j];
+            if (d >= 0 && d < 10) {
+                od[wd++] = (char)('0' + d);
+            } else if (d >= 10 && d < 100) {
+                od[wd++] = (char)('0' + d / 10);
+                od[wd++] = (char)('0' + d % 10);
+            } else {
+                if (d < 0) {
+                    od[wd++] = '-';
+                    d = -d;
+                }
+                char t[12];
+                int nt = 0;
+                do {
+                    t[nt++] = (char)('0' + d % 10);
+                    d /= 10;
+                } while (d);
+                while (nt) od[wd++] = t[--nt];
+            }
+        }
+    }
+    *ls = ws;
+    *ld = wd;
+}
+
+int gm_format_neighbor_rows(const uint64_t* db_packed, int64_t n_db, int guidelen, const int32_t* ids, const int32_t* dists,
+                            const int32_t* counts, int64_t n, int k, char* out_seqs, int64_t cap_seqs, char* out_dists,
+                            int64_t cap_dists, int64_t* len_seqs, int64_t* len_dists) {
+    if (!db_packed || !ids || !dists || !counts || !out_seqs || !out_dists || !len_seqs || !len_dists || n < 0 || k < 1 ||
+        guidelen < 1 || guidelen > GM_MAX_GUIDELEN)
+        return fail(GM_ERR_ARG, "gm_format_neighbor_rows: bad argument");
+    *len_seqs = *len_dists = 0;
+    if (n == 0) return GM_OK;
+    const int64_t ss = (int64_t)k * (guidelen + 1), sd = (int64_t)k * 12;      // bytes per row at most (incl. the separator)
+    if (cap_seqs < n * ss || cap_dists < n * sd) return fail(GM_ERR_ARG, "gm_format_neighbor_rows: buffer too small");
+    int bad = 0;
+    unsigned hw = std::thread::hardware_concurrency();
+    int64_t n_thr = hw ? (int64_t)hw : 4;
+    if (n_thr > 32) n_thr = 32;
+    if (n_thr > n / 16384 + 1) n_thr = n / 16384 + 1;
+    const int64_t per = (n + n_thr - 1) / n_thr;
+    std::vector<int64_t> ls((size_t)n_thr, 0), ld((size_t)n_thr, 0);
+    std::vector<std::thread> pool;
+    int* bad_p = &bad;
+    for (int64_t t = 0; t < n_thr; ++t) {
+        const int64_t lo = t * per, hi = lo + per < n ? lo + per : n;
+        if (lo >= hi) break;
+        pool.emplace_back([=, &ls, &ld] {
+            format_rows_serial(db_packed, n_db, guidelen, ids + lo * k, dists + lo * k, counts + lo, hi - lo, k,
+                               out_seqs + lo * ss, out_dists + lo * sd, &ls[(size_t)t], &ld[(size_t)t], bad_p);
+        });
+    }
+    for (auto& th : pool) th.join();
+    if (bad) return fail(GM_ERR_ARG, "gm_format_neighbor_rows: id out of range");
+    int64_t ws = 0, wd = 0;
+    for (int64_t t = 0; t < (int64_t)pool.size(); ++t) {
+        if (t) {
+            out_seqs[ws++] = '\n';
+            out_dists[wd++] = '\n';
+        }
+        std::memmove(out_seqs + ws, out_seqs + t * per * ss, (size_t)ls[(size_t)t]);
+        std::memmove(out_dists + wd, out_dists + t * per * sd, (size_t)ld[(size_t)t]);
+        ws += ls[(size_t)t];
+        wd += ld[(size_t)t];
+    }
+    *len_seqs = ws;
+    *len_dists = wd;
+    return GM_OK;
+}
+
 int gm_index_create_dev(const void* d_packed, int64_t n_db, int guidelen, int metric, int device,
                         void* stream, gm_index** out) {
     GM_ENTER();

@@ -72,6 +72,13 @@ int gm_unpack(const uint64_t* packed, int64_t n, int guidelen, char* out);
  * core.cfd_score (reference core.py:1136) is a list of str(float) per row.  Returns the bytes written, -1 when cap is
  * too small (25 n always suffices). */
 int64_t gm_format_doubles(const double* v, int64_t n, char* out, int64_t cap);
+/* The 'Similar guides' / 'Similar guide distances' columns of the reference's output table (Annotation._format_guide_table,
+ * core.py:913-931) for n result rows (host code, no GPU): out_seqs = ";".join(the counts[r] neighbour sequences of row r),
+ * out_dists = ";".join(str(distance)), rows separated by '\n'; db_packed = the index's targets (ids index it).  The
+ * buffers need n * k * (guidelen + 1) and n * k * 12 bytes. */
+int gm_format_neighbor_rows(const uint64_t* db_packed, int64_t n_db, int guidelen, const int32_t* ids, const int32_t* dists,
+                            const int32_t* counts, int64_t n, int k, char* out_seqs, int64_t cap_seqs, char* out_dists,
+                            int64_t cap_dists, int64_t* len_seqs, int64_t* len_dists);
 
 /* Build the (exact, brute-force) index on GPU `device`: copies the packed db to HBM as bit planes. */
 int gm_index_create(const uint64_t* packed, int64_t n_db, int guidelen, int metric, int device,

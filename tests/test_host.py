@@ -341,3 +341,31 @@ def test_format_doubles_is_pythons_str_of_float():
     want = [str(x) for x in vals.tolist()]
     assert got == want
     assert _lib.format_doubles(np.array([0.25])) == ["0.25"] and _lib.format_doubles(np.array([])) == []
+
+
+def test_native_neighbor_columns_equal_the_numpy_path():
+    """gm_format_neighbor_rows (used when the index's targets are at hand in packed form) against the numpy path of
+    core.format_neighbor_columns, ragged rows (fewer than k hits, none at all) and two-digit distances included."""
+    from guidemaker_amd import _lib
+    rng = np.random.default_rng(4)
+    for L, k, n_db, n in ((20, 10, 5000, 3000), (27, 3, 40, 500), (10, 20, 300, 70_000)):
+        db_packed = rng.integers(0, 1 << (2 * L), size=n_db, dtype=np.uint64)
+        db = np.asarray(_lib.unpack(db_packed, L), dtype=object)
+        q = ["".join(rng.choice(list("ACGT"), size=L)) + str(i) for i in range(n)]      # distinct keys
+        ids = rng.integers(0, n_db, size=(n, k)).astype(np.int32)
+        dists = rng.integers(0, 28, size=(n, k)).astype(np.int32)
+        counts = rng.integers(0, k + 1, size=n).astype(np.int32)
+        counts[: n // 2] = k
+        for r in range(n):
+            ids[r, counts[r]:] = -1
+            dists[r, counts[r]:] = -1
+
+        class TP:
+            pass
+        tp = TP()
+        tp.neighbors = core.NeighborMap(q, np.arange(n), ids, dists, counts, db, q_packed=np.zeros(n, np.uint64),
+                                        db_packed=db_packed, guidelen=L)
+        got = core.format_neighbor_columns(tp, q)
+        tp.neighbors = core.NeighborMap(q, np.arange(n), ids, dists, counts, db)
+        want = core.format_neighbor_columns(tp, q)
+        assert got[0] == want[0] and got[1] == want[1]
