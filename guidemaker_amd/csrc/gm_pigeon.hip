@@ -586,6 +586,7 @@ struct gm_pigeon {
     PgMailbox* box = nullptr;         // pinned, host-coherent mailbox of the per-query read-backs (k_publish)
     PgMailbox* box_dev = nullptr;     // ... its device address
     unsigned box_seq = 0;
+    bool box_off = false;             // the mailbox word once failed to arrive while the stream ran: plain copies from then on
     int64_t grid = 0;
     uint32_t* lists = nullptr;    // hit lists (gm_pg_blocks::loff / lcap)
     int64_t lists_cap = 0;
@@ -1379,7 +1380,7 @@ static int pg_read_counters(gm_pigeon* pg, hipStream_t st) {
         const char* e = std::getenv("GM_PG_MAILBOX");
         return !(e && e[0] == '0');
     }();
-    if (!polled) {
+    if (!polled || pg->box_off) {
         HIP_TRY(hipMemcpyAsync(&pg->box->c, pg->ctr, sizeof(PgCounters), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemsetAsync(&pg->ctr->n_bad, 0, sizeof(int), st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -1396,6 +1397,7 @@ static int pg_read_counters(gm_pigeon* pg, hipStream_t st) {
         if ((spins & 0x3ff) == 0x3ff &&
             std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 1.0) {
             HIP_TRY(hipStreamSynchronize(st));
+            pg->box_off = true;      // (not one second per read-back from here on)
             if (pg->box->seq != seq) {
                 HIP_TRY(hipMemcpy(&pg->box->c, pg->ctr, sizeof(PgCounters), hipMemcpyDeviceToHost));
                 HIP_TRY(hipMemset(&pg->ctr->n_bad, 0, sizeof(int)));
