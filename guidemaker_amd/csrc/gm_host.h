@@ -112,7 +112,10 @@ GM_FOR_EACH_LEN(GM_DECL_PG)
 // gm_pg_scan: the K1P launch; gm_pg_merge: hit lists -> top k + the list of rows that are not exact;
 // gm_pg_incomplete: how many such rows (synchronises the stream); gm_pg_gather / gm_pg_scatter: move those rows
 // to / from a compact query.
-int gm_pg_plan(int64_t n_db, int64_t n_q, int L, int k, double p_match, gm_pg_layout* out);
+int gm_pg_plan(int64_t n_db, int64_t n_q, int L, int k, double p_match, gm_pg_layout* out, const double* p_short = nullptr);
+int gm_pg_sample_rows(gm_index* idx, int64_t n, int64_t stride, hipStream_t st);
+bool gm_pg_sampling(const gm_index* idx);
+void gm_pg_expect_short(gm_index* idx, double share);      // (of the candidates, at the planned layout's radius)
 bool gm_pg_layout_make(int L, int B, int X, int lenx, int n2, gm_pg_layout* out);
 int gm_pg_layout_radius(const gm_pg_layout& lay);
 bool gm_pg_layout_forced(const gm_index* idx, gm_pg_layout* out);

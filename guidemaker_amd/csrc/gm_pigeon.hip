@@ -403,6 +403,11 @@ __global__ __launch_bounds__(256) void k_count_incomplete(const int32_t* __restr
     if (counts != nullptr ? counts[i] < need : d1[i] < 0) atomicAdd(n_bad, 1);
 }
 
+__global__ __launch_bounds__(256) void k_stride_rows(int32_t* __restrict__ inc, int64_t n, int64_t stride) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) inc[j] = (int32_t)(j * stride);
+}
+
 __global__ __launch_bounds__(256) void k_gather_rows(const uint2* __restrict__ q, const int32_t* __restrict__ inc, int64_t n,
                                                      uint2* __restrict__ q2) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -551,9 +556,11 @@ struct gm_pigeon {
     int tune_gap = 0;                  // table gaps: 0 = choose, 1 = common gap (one launch), 2 = per-block gaps
     int tune_run = 128;                // chunk-table entries per XCD run (gm_set_param "pg_run")
     int tune_msplit = 0;               // lanes per candidate in the merge, 0 = choose (gm_set_param "pg_msplit")
+    int tune_sample = 1;               // 0 = the layout planner uses the Poisson model instead of a scanned sample (gm_set_param "pg_sample")
     int tune_prefix = 1;               // 0 = the incomplete rows go straight to the plain re-scan (gm_set_param "pg_prefix")
     int tune_cut = 0;                  // id cut-off: 0 = choose, 1 .. 99 = that percentage of the ids, 100 = off ("pg_cut")
-    bool cut_dropped = false;          // the cut-off left more than 1 % of the candidates short on this pool: not used again
+    bool cut_dropped = false;          // the cut-off left more than 1 % of the candidates short (beyond expect_short) on this pool: not used again
+    double expect_short = 0.0;         // share of the candidates the planner's sample expects short WITHOUT the cut-off (0: no sample)
     double base_freq[4] = {0.25, 0.25, 0.25, 0.25};      // base composition of the pool (gm_pg_pool_stats)
     uint8_t* cflag = nullptr;          // per candidate: takes the id cut-off
     int64_t cflag_cap = 0;
@@ -726,8 +733,12 @@ int gm_pg_layout_radius(const gm_pg_layout& lay) {
 // 1.5 group evaluations on top -- descriptor load, a DMA unit waited for cold; measured on S3 / S4, profiles/r02 --;
 // a bucket's candidates are padded to whole 64-lane chunks; under a skewed composition a
 // neighbour bucket holds rho = ((1 - p) / 3) / p times the targets of the own bucket per substitution).
+// p_short (optional, [L + 1]): measured share of the candidates whose k-th neighbour lies beyond r (gm_pg_sample_rows +
+// a plain scan of the sample, gmhip.hip) -- replaces the Poisson term, which knows the pool's composition but not the
+// spread between candidates (on a GC-rich real genome an AT-rich candidate has a fraction of the average's neighbours)
+// nor repeats.
 // Returns 1 and fills *out when a layout beats the plain scan clearly (cost < 0.45), else 0.
-int gm_pg_plan(int64_t n_db, int64_t n_q, int L, int k, double p_match, gm_pg_layout* out) {
+int gm_pg_plan(int64_t n_db, int64_t n_q, int L, int k, double p_match, gm_pg_layout* out, const double* p_short) {
     if (L < 12 || L > GM_MAX_GUIDELEN || n_db < 32768 || k < 1 || k > 20) return 0;
     if (!(p_match >= 0.25 && p_match < 0.9)) p_match = 0.25;
     if (n_q < 1) n_q = n_db;
@@ -747,6 +758,7 @@ int gm_pg_plan(int64_t n_db, int64_t n_q, int L, int k, double p_match, gm_pg_la
                     term *= mean / (j + 1);
                 }
                 if (mean > 700.0) p_inc = 0.0;
+                if (p_short != nullptr) p_inc = p_short[r < L ? r : L];
                 if (p_inc >= best) continue;
                 for (int len2 = n2 ? 4 : 0; len2 <= (n2 ? GM_PG_MAXLEN : 0); ++len2)
                     for (int len1 = (n1 && n0) ? 2 : 0; len1 <= ((n1 && n0) ? GM_PG_MAXLEN : 0); ++len1)
@@ -874,6 +886,11 @@ int gm_pg_set_param(gm_index* idx, const char* name, int value) {
     }
     if (std::strcmp(name, "pg_prefix") == 0) {
         idx->pg->tune_prefix = value;
+        return GM_OK;
+    }
+    if (std::strcmp(name, "pg_sample") == 0) {      // (takes effect when the layout is next planned)
+        idx->pg->tune_sample = value;
+        idx->plan_nq = -1;
         return GM_OK;
     }
     if (std::strcmp(name, "pg_msplit") == 0) {
@@ -1418,7 +1435,9 @@ int gm_pg_incomplete(gm_index* idx, int64_t* n_inc, int64_t* pairs_evaluated, hi
     if ((rc = pg_read_counters(pg, st))) return rc;
     const PgCounters h = pg->box->c;
     *n_inc = h.n_inc;
-    if (pg->cut_id != 0xffffffffu && pg->tune_cut == 0 && pg->cap_nq > 0 && (int64_t)h.n_inc * 100 > pg->cap_nq) pg->cut_dropped = true;
+    if (pg->cut_id != 0xffffffffu && pg->tune_cut == 0 && pg->cap_nq > 0 &&
+        (double)h.n_inc > (0.01 + pg->expect_short) * (double)pg->cap_nq)
+        pg->cut_dropped = true;
     *pairs_evaluated = 0;
     for (int b = 0; b < GM_PG_MAXB; ++b) {
         pg->last_bpairs[b] = (int64_t)h.bpairs[b];
@@ -1572,6 +1591,21 @@ int gm_pg_collect_short(gm_index* idx, int64_t n, int need, const int32_t* count
     hipLaunchKernelGGL(k_collect_short, grid_for(n), dim3(256), 0, st, counts, n, need, pg->inc, &pg->ctr->n_bad);
     HIP_TRY(hipGetLastError());
     return GM_OK;
+}
+
+// every stride-th candidate row -> pg->inc (the planner's sample; gm_pg_gather then builds the compact query)
+int gm_pg_sample_rows(gm_index* idx, int64_t n, int64_t stride, hipStream_t st) {
+    if (!idx->pg) idx->pg = new gm_pigeon();
+    gm_pigeon* pg = idx->pg;
+    int rc;
+    if ((rc = ensure(&pg->inc, &pg->inc_cap, n, "incomplete rows"))) return rc;
+    hipLaunchKernelGGL(k_stride_rows, grid_for(n), dim3(256), 0, st, pg->inc, n, stride);
+    HIP_TRY(hipGetLastError());
+    return GM_OK;
+}
+bool gm_pg_sampling(const gm_index* idx) { return !idx->pg || idx->pg->tune_sample != 0; }
+void gm_pg_expect_short(gm_index* idx, double share) {
+    if (idx->pg) idx->pg->expect_short = share;
 }
 
 const int32_t* gm_pg_inc_list(const gm_index* idx) { return idx->pg ? idx->pg->inc : nullptr; }

@@ -451,7 +451,43 @@ int run_hamming_pigeon(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
         // (gm_set_param "pg_layout": experiments)
     } else {
         if (idx->plan_nq != n_q || idx->plan_k != keff) {      // (the pool and its composition belong to the handle)
-            idx->plan_found = gm_pg_plan(idx->n_db, n_q, idx->L, keff, p_match, &idx->plan_lay);
+            // how far the k-th neighbour lies, measured: a plain scan of every (n_q / 2048)-th candidate against the
+            // whole pool (~0.1 ms, once per plan) -- the independent-base model knows the pool's composition, not the
+            // spread between candidates or the repeats of a real genome
+            std::vector<double> p_short;
+            constexpr int64_t SAMPLE = 2048;
+            if (n_q >= 16 * SAMPLE && gm_pg_sampling(idx)) {
+                const uint2* qs = nullptr;
+                int32_t *ids_s = nullptr, *dists_s = nullptr, *counts_s = nullptr;
+                if ((rc = gm_pg_sample_rows(idx, SAMPLE, n_q / SAMPLE, st))) return rc;
+                if ((rc = gm_pg_gather(idx, SAMPLE, keff, nearest, &qs, &ids_s, &dists_s, &counts_s, st))) return rc;
+                if ((rc = run_hamming_lookup(idx, nearest, SAMPLE, keff, ids_s, dists_s, counts_s, false, st, qs))) return rc;
+                std::vector<int32_t> hd((size_t)SAMPLE * keff), hc((size_t)SAMPLE, keff);
+                HIP_TRY(hipMemcpyAsync(hd.data(), dists_s, sizeof(int32_t) * hd.size(), hipMemcpyDeviceToHost, st));
+                if (counts_s) HIP_TRY(hipMemcpyAsync(hc.data(), counts_s, sizeof(int32_t) * hc.size(), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                std::vector<int64_t> beyond((size_t)idx->L + 2, 0);      // rows whose k-th neighbour lies beyond r
+                for (int64_t j = 0; j < SAMPLE; ++j) {
+                    int kth = hc[(size_t)j] >= keff ? hd[(size_t)j * keff + keff - 1] : idx->L + 1;
+                    if (kth < 0 || kth > idx->L + 1) kth = idx->L + 1;
+                    for (int r = 0; r < kth && r <= idx->L; ++r) ++beyond[(size_t)r];
+                }
+                p_short.resize((size_t)idx->L + 1);
+                for (int r = 0; r <= idx->L; ++r) p_short[(size_t)r] = ((double)beyond[(size_t)r] + 0.5) / (double)(SAMPLE + 1);
+                if (std::getenv("GM_DEBUG")) {
+                    fprintf(stderr, "[gm] planner sample (%lld rows): share with the k-th neighbour beyond r =", (long long)SAMPLE);
+                    for (int r = 2; r <= 8 && r <= idx->L; ++r) fprintf(stderr, " %d:%.4f", r, p_short[(size_t)r]);
+                    fprintf(stderr, "\n");
+                }
+            }
+            idx->plan_found = gm_pg_plan(idx->n_db, n_q, idx->L, keff, p_match, &idx->plan_lay,
+                                         p_short.empty() ? nullptr : p_short.data());
+            double expect = 0.0;
+            if (idx->plan_found && !p_short.empty()) {
+                const int r = gm_pg_layout_radius(idx->plan_lay);
+                expect = p_short[(size_t)(r < idx->L ? r : idx->L)];
+            }
+            gm_pg_expect_short(idx, expect);
             idx->plan_nq = n_q;
             idx->plan_k = keff;
         }
@@ -513,12 +549,19 @@ int run_hamming_pigeon(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
         // only if a list still does not fill
         const int guess = gm_pg_radius(idx) + 2;
         if ((rc = run_hamming_lookup(idx, nearest, n_inc, keff, ids2, dists2, counts2, false, st, q2, guess))) return rc;
-        int64_t n_bad = 0;
-        if ((rc = gm_pg_count_incomplete(idx, n_inc, keff, counts2, nearest ? dists2 : nullptr, &n_bad, st))) return rc;
-        if (n_bad > 0 &&
-            (rc = run_hamming_lookup(idx, nearest, n_inc, keff, ids2, dists2, counts2, false, st, q2)))
-            return rc;
         if ((rc = gm_pg_scatter(idx, n_inc, keff, nearest, ids, dists, counts, st))) return rc;
+        // the rows whose list did not fill under the guess (and only those) go through the unseeded scan
+        int64_t n_bad = 0;
+        if ((rc = gm_pg_collect_bad(idx, n_inc, keff, nearest, st))) return rc;
+        if ((rc = gm_pg_read_bad(idx, &n_bad, st))) return rc;
+        if (std::getenv("GM_DEBUG"))
+            fprintf(stderr, "[gm] plain re-scan: %lld rows under the bound %d, %lld left for the unseeded scan\n", (long long)n_inc,
+                    guess, (long long)n_bad);
+        if (n_bad > 0) {
+            if ((rc = gm_pg_gather(idx, n_bad, keff, nearest, &q2, &ids2, &dists2, &counts2, st))) return rc;
+            if ((rc = run_hamming_lookup(idx, nearest, n_bad, keff, ids2, dists2, counts2, false, st, q2))) return rc;
+            if ((rc = gm_pg_scatter(idx, n_bad, keff, nearest, ids, dists, counts, st))) return rc;
+        }
     }
     *used = true;
     return GM_OK;

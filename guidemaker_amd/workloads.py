@@ -1,5 +1,6 @@
-"""Synthetic workloads of SURVEY.md section 8(d): i.i.d. genomes with a given GC content, scanned with
-the package's own PAM scanner (no real E. coli / B. subtilis / yeast genome exists offline)."""
+"""Workloads of SURVEY.md section 8(d): i.i.d. genomes with a given GC content, scanned with the package's own PAM
+scanner (no real E. coli / B. subtilis / yeast genome exists offline), and the one real genome of BASELINE size that
+the reference ships as data (P. aeruginosa PAO1, as a 2-bit fixture under tests/golden/)."""
 import gzip
 import os
 
@@ -28,6 +29,11 @@ WORKLOADS = {
     "s4": dict(records=[100_000_000], gc=0.5, seed=4, pam="NNGRRT", orientation="3prime", guidelen=20,
                metric="hamming", k=20, editdist=2,
                label="S4: synthetic 100 Mb uniform, NNGRRT 3prime, L=20, hamming, k=20"),
+    # SURVEY.md section 8 "offline real data": P. aeruginosa PAO1 (NC_002516, 6 264 404 bp, GC 66.6 %), the genome in the
+    # reference's data directory; the sequence travels as tests/golden/pao1_genome.2bit.gz (tests/golden/make_pao1.py)
+    "pao1": dict(fixture="pao1_genome.2bit.gz", records=[6_264_404], gc=0.666, seed=0, pam="NGG", orientation="3prime",
+                 guidelen=20, metric="hamming", k=10, editdist=2,
+                 label="PAO1: REAL genome P. aeruginosa PAO1 NC_002516 (6 264 404 bp, gc 0.666), NGG 3prime, L=20, hamming, k=10"),
     # small variant for tests / smoke
     "tiny": dict(records=[200_000], gc=0.45, seed=9, pam="NGG", orientation="3prime", guidelen=20,
                  metric="hamming", k=10, editdist=2, label="tiny: synthetic 200 kb, NGG 3prime, L=20"),
@@ -86,6 +92,21 @@ def read_genome(path):
     return recs
 
 
+def read_2bit(path, length):
+    """Sequence of a tests/golden/*.2bit.gz fixture: 2 bits per base (A0 C1 G2 T3), base i in bits [2(i%4), 2(i%4)+1]
+    of byte i//4, `length` bases."""
+    with gzip.open(path, "rb") as fh:
+        b = np.frombuffer(fh.read(), np.uint8)
+    if b.shape[0] * 4 < length:
+        raise ValueError("%s holds %d bases, %d expected" % (path, b.shape[0] * 4, length))
+    codes = np.stack([(b >> s) & 3 for s in (0, 2, 4, 6)], axis=1).reshape(-1)[:length]
+    return np.frombuffer(b"ACGT", np.uint8)[codes].tobytes().decode("ascii")
+
+
+def fixture_path(fname):
+    return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", fname)
+
+
 def real_genome_path(name):
     """Path of a real genome for workload `name`, if the box has one: environment variable GM_GENOME_<NAME>
     (e.g. GM_GENOME_S1=/data/ecoli_k12_mg1655.gbk.gz).  SURVEY.md 8(d): real E. coli / B. subtilis / yeast files are
@@ -102,7 +123,14 @@ def make_pool(name, seed_offset=0):
     parts = []
     label = w["label"]
     real = real_genome_path(name) if seed_offset == 0 else None
-    if real:
+    if "fixture" in w:
+        path = fixture_path(w["fixture"])
+        if not os.path.exists(path):
+            raise FileNotFoundError("workload %s needs the fixture %s" % (name, path))
+        seq = read_2bit(path, w["records"][0])
+        parts.append(core.pack_codes(core.scan_targets(seq, w["pam"], w["orientation"], w["guidelen"])["codes"]))
+        real = path
+    elif real:
         total = 0
         for _, seq in read_genome(real):
             total += len(seq)

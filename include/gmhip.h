@@ -220,6 +220,9 @@ int gm_set_variant(gm_index* idx, int variant);
  *   "pg_cut": K1P's id cut-off for hits at the layout's radius (0 = choose, 1..99 = that percentage of the ids, 100 = off);
  *   "pg_prefix": 0 = K1P's incomplete rows go straight to the plain re-scan (A/B, tests); 1 (default) = first a scan of
  *   the pool's first part, which holds the few neighbours at r + 1 such a row still needs (gm_pigeon.hip);
+ *   "pg_sample": 1 (default) = K1P's layout planner measures how far the k-th neighbour lies on a scanned sample of the
+ *   candidates (every (n_q / 2048)-th row against the whole pool, once per plan, for n_q >= 32768); 0 = it uses the
+ *   independent-base model of the pool's composition alone (A/B, tests).  The result is exact either way;
  *   "pg_msplit": lanes per candidate in K1P's merge (0 = choose, 1, 2, 4);
  *   "pg_debug": timing experiments only (bit 0: the scan skips its list stores; bit 1: the scan accepts no hit at
  *   all -- results are then WRONG). */

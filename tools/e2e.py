@@ -30,9 +30,12 @@ def main():
     w = workloads.WORKLOADS[a.workload]
     rng = np.random.Generator(np.random.PCG64(w["seed"]))
     recs = []
-    for i, n in enumerate(w["records"]):
-        codes = workloads.synth_genome(n, w["gc"], rng)
-        recs.append(Rec(np.frombuffer(b"ACGT", np.uint8)[codes].tobytes().decode(), "rec%d" % i))
+    if "fixture" in w:      # a real genome (tests/golden/*.2bit.gz)
+        recs.append(Rec(workloads.read_2bit(workloads.fixture_path(w["fixture"]), w["records"][0]), a.workload))
+    else:
+        for i, n in enumerate(w["records"]):
+            codes = workloads.synth_genome(n, w["gc"], rng)
+            recs.append(Rec(np.frombuffer(b"ACGT", np.uint8)[codes].tobytes().decode(), "rec%d" % i))
     t = {}
     # warm the GPU context first (HIP initialisation is paid once per process, not per genome)
     core.PamTarget(w["pam"], w["orientation"], w["metric"]).find_targets([Rec(recs[0].seq[:100000], "warm")], w["guidelen"])
