@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""A/B of one K1P knob on a workload, device-resident: ms/step, scan kernel ms, evaluated pairs, re-scanned rows, and
+whether the result equals the default's.
+   python tools/layout_ab.py pao1 61515140 727161            # forced layouts (gm_set_param "pg_layout")
+   DBG_PARAM=pg_cut python tools/layout_ab.py pao1 100 20 35  # id cut-off percentages"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
