@@ -68,6 +68,8 @@ def main():
         idx = _lib.Index(db, L, _lib.METRIC_HAMMING)
         try:
             idx.set_param("pg_cut", cut)
+            if rng.random() < 0.2:      # (default: the planner scans a sample of the candidates when there are >= 32768)
+                idx.set_param("pg_sample", 0)
             if k == 1 and rng.random() < 0.5:
                 got = (idx.nearest(q),)
                 name = idx.last_kernel()[0]
