@@ -176,7 +176,7 @@ def parse():
     # S1 runs 0.96 ms/step over 10 steps and 0.87 over 200 or 1000)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="s1", choices=["s1", "s2", "s3", "s4", "pao1", "tiny"])
+    ap.add_argument("--workload", default="s1", choices=["s1", "s2", "s3", "s4", "pao1", "pao1_leven", "tiny"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -34,6 +34,10 @@ WORKLOADS = {
     "pao1": dict(fixture="pao1_genome.2bit.gz", records=[6_264_404], gc=0.666, seed=0, pam="NGG", orientation="3prime",
                  guidelen=20, metric="hamming", k=10, editdist=2,
                  label="PAO1: REAL genome P. aeruginosa PAO1 NC_002516 (6 264 404 bp, gc 0.666), NGG 3prime, L=20, hamming, k=10"),
+    # ... and the same genome under BASELINE configs[2]'s parameters (Cas12a, Levenshtein)
+    "pao1_leven": dict(fixture="pao1_genome.2bit.gz", records=[6_264_404], gc=0.666, seed=0, pam="TTTV", orientation="5prime",
+                       guidelen=23, metric="leven", k=5, editdist=3,
+                       label="PAO1-leven: REAL genome P. aeruginosa PAO1 NC_002516 (6 264 404 bp, gc 0.666), TTTV 5prime, L=23, leven, k=5"),
     # small variant for tests / smoke
     "tiny": dict(records=[200_000], gc=0.45, seed=9, pam="NGG", orientation="3prime", guidelen=20,
                  metric="hamming", k=10, editdist=2, label="tiny: synthetic 200 kb, NGG 3prime, L=20"),

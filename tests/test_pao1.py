@@ -133,3 +133,36 @@ def test_pao1_flow_gpu(oracle):
     some = next(iter(tp.neighbors))
     e = tp.neighbors[some]
     assert e["target"] == some and e["neighbors"]["seqs"][0] == some and e["neighbors"]["dist"][0] == 0
+
+
+@pytest.mark.gpu
+def test_pao1_levenshtein_gpu(oracle):
+    """The same genome under BASELINE configs[2]'s parameters (TTTV 5prime, L = 23, Levenshtein, k = 5): the bit-sliced
+    scan with its narrow-band first pass against the single pass, against the per-pair Myers kernel, and against the
+    oracle's O(nm) DP on a row sample -- real targets cluster (repeats, codon bias), the synthetic pools do not."""
+    pool = workloads.make_pool("pao1_leven")
+    L, k = pool["guidelen"], pool["k"]
+    q, db = pool["packed_all"], pool["packed_db"]
+    assert q.shape[0] == 43123 and db.shape[0] == 42455
+    idx = _lib.Index(db, L, _lib.METRIC_LEVEN)
+    try:
+        ids, dists, counts = idx.knn(q, k)
+        assert idx.last_kernel()[0].startswith("k_leven_knn_bs")
+        assert (counts == k).all() and (dists[:, 0] == 0).all() and (np.diff(dists, axis=1) >= 0).all()
+        idx.set_param("lv_two_pass", 0)
+        i1, d1, c1 = idx.knn(q, k)
+        idx.set_param("lv_two_pass", 1)
+        assert (i1 == ids).all() and (d1 == dists).all() and (c1 == counts).all()
+        idx.set_variant(2)                                                        # per-pair Myers kernel
+        i2, d2, c2 = idx.knn(q, k)
+        idx.set_variant(0)
+        assert (i2 == ids).all() and (d2 == dists).all() and (c2 == counts).all()
+    finally:
+        idx.close()
+    rows = np.sort(np.random.default_rng(23).choice(q.shape[0], size=256, replace=False))
+    asc = np.frombuffer(b"ACGT", np.uint8)
+    shifts = (2 * np.arange(L, dtype=np.uint64))[None, :]
+    db_b = np.ascontiguousarray(asc[((db[:, None] >> shifts) & np.uint64(3)).astype(np.uint8)])
+    q_b = np.ascontiguousarray(asc[((q[rows][:, None] >> shifts) & np.uint64(3)).astype(np.uint8)])
+    oi, od, oc = oracle.knn(db_b, q_b, L, "leven", k)
+    assert (oc == counts[rows]).all() and (od == dists[rows]).all() and (oi == ids[rows]).all()
