@@ -24,9 +24,12 @@ def main():
     w = workloads.WORKLOADS[a.workload]
     rng = np.random.Generator(np.random.PCG64(w["seed"]))
     recs = []
-    for i, n in enumerate(w["records"]):
-        codes = workloads.synth_genome(n, w["gc"], rng)
-        recs.append(Rec(np.frombuffer(b"ACGT", np.uint8)[codes].tobytes().decode(), "rec%d" % i))
+    if "fixture" in w:      # a real genome (tests/golden/*.2bit.gz)
+        recs.append(Rec(workloads.read_2bit(workloads.fixture_path(w["fixture"]), w["records"][0]), a.workload))
+    else:
+        for i, n in enumerate(w["records"]):
+            codes = workloads.synth_genome(n, w["gc"], rng)
+            recs.append(Rec(np.frombuffer(b"ACGT", np.uint8)[codes].tobytes().decode(), "rec%d" % i))
     pt = core.PamTarget(w["pam"], w["orientation"], w["metric"])
     tp = core.TargetProcessor(pt.find_targets(recs, w["guidelen"]), lsr=10, editdist=w["editdist"], knum=w["k"])
     tp.check_restriction_enzymes(["NRAGCA"])
