@@ -547,13 +547,18 @@ class TargetProcessor:
                                      db_packed=self._db_packed, guidelen=self._guidelen)
 
     def export_bed(self) -> object:
-        """Targets that are not seed-duplicated, as a BED-like frame."""
-        df = deepcopy(self.targets.loc[self.targets['isseedduplicated'] == False])
-        df = df[["seqid", "start", "stop", "target", "strand"]]
-        df['strand'] = df['strand'].apply(lambda x: '+' if x == True else '-')
-        df.columns = ["chrom", "chromstart", "chromend", "name", "strand"]
-        df.sort_values(by=['chrom', 'chromstart'], inplace=True)
-        return df
+        """BED-like frame (chrom, chromstart, chromend, name, strand) of the targets whose seed is unique, ordered by
+        record and start -- what the reference's export_bed returns (core.py:525-543)."""
+        t = self.targets
+        rows = ~t["isseedduplicated"].to_numpy(dtype=bool)
+        bed = pd.DataFrame({
+            "chrom": t["seqid"].array[rows],      # (stays categorical: the sort below follows the category order)
+            "chromstart": t["start"].to_numpy()[rows],
+            "chromend": t["stop"].to_numpy()[rows],
+            "name": t["target"].to_numpy()[rows],
+            "strand": pd.Series(np.where(t["strand"].to_numpy(dtype=bool)[rows], "+", "-"), dtype=object).to_numpy(),
+        }, index=t.index[rows])
+        return bed.sort_values(by=["chrom", "chromstart"])
 
     @staticmethod
     def _draw_control_codes(count: int, length: int, gc: float) -> np.ndarray:
@@ -576,24 +581,24 @@ class TargetProcessor:
     def get_control_seqs(self, seq_record_iter: object, configpath, length: int = 20, n: int = 10,
                          num_threads: int = 2) -> pd.DataFrame:
         """Random sequences with the genome's GC content that are farthest from every target."""
-        with open(configpath) as cf:
-            config = yaml.safe_load(cf)
-        MINIMUM_HMDIST = config['CONTROL']['MINIMUM_HMDIST']
-        MAX_CONTROL_SEARCH_MULTIPLE = max(config['CONTROL']['CONTROL_SEARCH_MULTIPLE'])
-        CONTROL_SEARCH_MULTIPLE = config['CONTROL']['CONTROL_SEARCH_MULTIPLE']
+        with open(configpath) as fh:
+            control_cfg = yaml.safe_load(fh)["CONTROL"]
+        wanted_dist = control_cfg["MINIMUM_HMDIST"]
+        multiples = list(control_cfg["CONTROL_SEARCH_MULTIPLE"])
+        largest_multiple = max(multiples)
 
-        totlen = 0
-        gccnt = 0
+        # genome-wide GC fraction, length-weighted over the records; per record Bio.SeqUtils.gc_fraction's default:
+        # (G+C+S) / (G+C+S+A+T+W+U), other letters ignored (reference core.py:570-578)
+        genome_len, gc_weighted = 0, 0.0
         for record in seq_record_iter:
             s = str(record.seq)
-            # Bio.SeqUtils.gc_fraction(seq) default: (G+C+S) / (G+C+S+A+T+W+U), other letters ignored
-            gc_total = sum(s.count(c) for c in "CGScgs")
-            counted = gc_total + sum(s.count(c) for c in "ATWUatwu")
-            gccnt += (gc_total / counted if counted else 0) * len(s)
-            totlen += len(s)
-        gc = gccnt / (totlen)
+            strong = sum(map(s.count, "CGScgs"))
+            weak = sum(map(s.count, "ATWUatwu"))
+            gc_weighted += (strong / (strong + weak) if strong + weak else 0) * len(s)
+            genome_len += len(s)
+        gc = gc_weighted / genome_len
         self.gc_percent = gc * 100
-        self.genomesize = totlen / (1024 * 1024)
+        self.genomesize = genome_len / (1024 * 1024)
 
         if self.nmslib_index is None:
             raise ValueError("get_control_seqs: no index -- call create_index() first")
@@ -607,48 +612,43 @@ class TargetProcessor:
         n_searched = 0
         t0 = time.perf_counter()
         hamming = self._is_hamming()
-        try:
-            # loop condition (and its walk off the end of the list) as in the reference, core.py:586
-            while minimum_hmdist < MINIMUM_HMDIST or search_mult == MAX_CONTROL_SEARCH_MULTIPLE:
-                if sm_count >= len(CONTROL_SEARCH_MULTIPLE):
-                    # the reference's CONTROL_SEARCH_MULTIPLE[sm_count] raises a bare "list index out of range" here
-                    # (core.py:587, re-raised at :619-620); same exception type, with the cause spelled out
-                    raise IndexError(
-                        "list index out of range: no %d control sequences at distance >= CONTROL.MINIMUM_HMDIST=%s "
-                        "from every target after CONTROL.CONTROL_SEARCH_MULTIPLE=%s x n draws (best minimum %d over "
-                        "%d targets; the search is exact, so on large genomes lower MINIMUM_HMDIST in the config)"
-                        % (n, MINIMUM_HMDIST, CONTROL_SEARCH_MULTIPLE, minimum_hmdist, len(self._db_targets)))
-                search_mult = CONTROL_SEARCH_MULTIPLE[sm_count]
-                # candidates stay numeric (codes -> packed words) until the n winners are known: at the
-                # largest multiple this is 10^4 * n sequences
-                codes = self._draw_control_codes(n * search_mult, length, gc)
-                d1 = self.nmslib_index.nearest(pack_codes(codes))
-                # sorted(..., reverse=True, key=dist) is stable: ties stay in draw order
-                order = np.argsort(-d1.astype(np.int64), kind="stable")[0:n]
-                sort_seq = codes_to_strings(codes[order])
-                if hamming:
-                    sort_dist = [float(d1[i]) for i in order.tolist()]   # reference: raw / 2 -> float
-                else:
-                    sort_dist = [int(d1[i]) for i in order.tolist()]
-                minimum_hmdist = int(min(sort_dist))
-                sm_count += 1
-                n_searched += n * search_mult
-        except IndexError as e:
-            raise e
+        # loop condition (and its walk off the end of the list) as in the reference, core.py:586
+        while minimum_hmdist < wanted_dist or search_mult == largest_multiple:
+            if sm_count >= len(multiples):
+                # the reference's CONTROL_SEARCH_MULTIPLE[sm_count] raises a bare "list index out of range" here
+                # (core.py:587, re-raised at :619-620); same exception type, with the cause spelled out
+                raise IndexError(
+                    "list index out of range: no %d control sequences at distance >= CONTROL.MINIMUM_HMDIST=%s "
+                    "from every target after CONTROL.CONTROL_SEARCH_MULTIPLE=%s x n draws (best minimum %d over "
+                    "%d targets; the search is exact, so on large genomes lower MINIMUM_HMDIST in the config)"
+                    % (n, wanted_dist, multiples, minimum_hmdist, len(self._db_targets)))
+            search_mult = multiples[sm_count]
+            # candidates stay numeric (codes -> packed words) until the n winners are known: at the
+            # largest multiple this is 10^4 * n sequences
+            codes = self._draw_control_codes(n * search_mult, length, gc)
+            d1 = self.nmslib_index.nearest(pack_codes(codes))
+            # sorted(..., reverse=True, key=dist) is stable: ties stay in draw order
+            order = np.argsort(-d1.astype(np.int64), kind="stable")[0:n]
+            sort_seq = codes_to_strings(codes[order])
+            if hamming:
+                sort_dist = [float(d1[i]) for i in order.tolist()]   # reference: raw / 2 -> float
+            else:
+                sort_dist = [int(d1[i]) for i in order.tolist()]
+            minimum_hmdist = int(min(sort_dist))
+            sm_count += 1
+            n_searched += n * search_mult
         dt = time.perf_counter() - t0
         logger.info("get_control_seqs: %d random %d-mers x N_db=%d targets in %.3f s (%.3e guide pairs/s), minimum "
                     "distance %s", n_searched, length, len(self._db_targets), dt,
                     n_searched * len(self._db_targets) / max(dt, 1e-9), min(sort_dist))
 
-        total_ncontrolsearched = search_mult * n
-        self.ncontrolsearched = total_ncontrolsearched
-        randomdf = pd.DataFrame(data={"Sequences": sort_seq, "Hamming distance": sort_dist})
-
-        def create_name(seq):
-            return "Cont-" + hashlib.md5(seq.encode()).hexdigest()
-        randomdf['name'] = randomdf["Sequences"].apply(create_name)
-        randomdf = randomdf[["name", "Sequences", "Hamming distance"]]
-        return (min(sort_dist), statistics.median(sort_dist), randomdf)
+        self.ncontrolsearched = search_mult * n      # (the LAST multiple's draw, as the reference reports it)
+        table = pd.DataFrame({
+            "name": ["Cont-" + hashlib.md5(seq.encode()).hexdigest() for seq in sort_seq],
+            "Sequences": sort_seq,
+            "Hamming distance": sort_dist,
+        })
+        return (min(sort_dist), statistics.median(sort_dist), table)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -95,7 +95,17 @@ def test_carsonella_targets_and_filters(tag, orient):
     assert tp.targets["hasrestrictionsite"].tolist() == cols["hasrestrictionsite"]
     summ = load_json("carsonella_summary.json")["summary"][tag]
     assert len(tp._query_targets()) == summ["n_query"]
-    assert tp.export_bed().shape == (summ["n_bed"], 5)
+    bed = tp.export_bed()
+    assert bed.shape == (summ["n_bed"], 5)
+    assert list(bed.columns) == ["chrom", "chromstart", "chromend", "name", "strand"]
+    # reference core.py:538-542 on the golden columns: seed-unique rows, '+' / '-', ordered by (record, start) -- stable
+    keep = [i for i, d in enumerate(cols["isseedduplicated"]) if not d]
+    keep.sort(key=lambda i: cols["start"][i])
+    assert bed["name"].tolist() == [cols["target"][i] for i in keep]
+    assert bed["chromstart"].tolist() == [cols["start"][i] for i in keep]
+    assert bed["chromend"].tolist() == [cols["stop"][i] for i in keep]
+    assert bed["strand"].tolist() == ["+" if cols["strand"][i] else "-" for i in keep]
+    assert bed.index.tolist() == keep and bed["strand"].dtype == object
     assert len(tp) == summ["n_targets"] and "potential PAM targets" in str(tp)
 
 
