@@ -456,7 +456,7 @@ int run_hamming_pigeon(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
             // spread between candidates or the repeats of a real genome
             std::vector<double> p_short;
             constexpr int64_t SAMPLE = 2048;
-            if (n_q >= 16 * SAMPLE && gm_pg_sampling(idx)) {
+            if (n_q >= 16 * SAMPLE && idx->n_db >= 32768 && idx->L >= 12 && gm_pg_sampling(idx)) {      // (gm_pg_plan's own preconditions)
                 const uint2* qs = nullptr;
                 int32_t *ids_s = nullptr, *dists_s = nullptr, *counts_s = nullptr;
                 if ((rc = gm_pg_sample_rows(idx, SAMPLE, n_q / SAMPLE, st))) return rc;

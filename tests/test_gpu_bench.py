@@ -21,7 +21,7 @@ def _last_json(text):
 
 def test_bench_single_gpu_line():
     out = subprocess.run([sys.executable, "bench.py", "--workload", "tiny", "--steps", "3", "--warmup", "1",
-                          "--cpu-seconds", "1"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+                          "--cpu-seconds", "1"], cwd=ROOT, capture_output=True, text=True, timeout=400)
     assert out.returncode == 0, out.stderr[-2000:]
     d = _last_json(out.stdout)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -44,7 +44,7 @@ def test_bench_two_rank_rehearsal(scaling):
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2",
                           "--workload", "tiny", "--steps", "2", "--warmup", "1", "--scaling", scaling],
-                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=400)
     assert out.returncode == 0, out.stderr[-3000:]      # EVERY rank must pass its checks
     d = _last_json(out.stdout)
     assert d["n_gpus"] == 2 and d["rccl_world"] == 2 and d["scaling"] == scaling and d["collective_backend"] == "gloo"

@@ -704,7 +704,7 @@ def test_k1p_stress_time_boxed():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "k1p_stress.py"), "--seconds", "20", "--seed", "5"],
-                         capture_output=True, text=True, timeout=600)
+                         capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "MISMATCH" not in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
     assert "cases" in out.stdout.splitlines()[-1]
 
@@ -893,7 +893,7 @@ def test_multi_device_entry_matches_single_device():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, "-c", _MULTI_CHILD, root], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, "-c", _MULTI_CHILD, root], capture_output=True, text=True, timeout=240)
     assert out.returncode == 0 and "multi ok" in out.stdout, out.stdout + out.stderr
 
 
@@ -922,7 +922,7 @@ def test_library_first_then_torch_in_one_process():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, "-c", _ORDER_CHILD, root], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, "-c", _ORDER_CHILD, root], capture_output=True, text=True, timeout=240)
     assert out.returncode == 0 and "order ok" in out.stdout, out.stdout + out.stderr
 
 
