@@ -33,19 +33,21 @@ def main():
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--leven", type=float, default=0.15, help="share of Levenshtein cases")
+    ap.add_argument("--max-n", type=int, default=400_000, help="largest pool (>= 1.5 M brings the radius-2 layouts in)")
+    ap.add_argument("--max-q", type=int, default=120_000, help="largest number of pool members among the candidates")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     t0, case, used = time.time(), 0, {"k_hamming_scan_pg": 0}
     while time.time() - t0 < a.seconds:
         case += 1
-        n = int(rng.integers(40_000, 400_000))
+        n = int(rng.integers(40_000, a.max_n))
         L = int(rng.integers(14, 25))
         k = int(rng.choice([1, 2, 3, 5, 7, 10, 13, 20]))
         skew = float(rng.choice([0.0, 0.0, 0.1, 0.3]))
         planted = float(rng.choice([0.0, 0.01, 0.05]))
         cut = int(rng.choice([0, 0, 0, 10, 30, 60, 100]))
         db = pool(rng, n, L, skew, planted)
-        q = np.concatenate([db[: int(rng.integers(1000, min(len(db), 120_000)))], pool(rng, 3000, L, skew, 0.0)])
+        q = np.concatenate([db[: int(rng.integers(1000, min(len(db), a.max_q)))], pool(rng, 3000, L, skew, 0.0)])
         if rng.random() < a.leven:      # Levenshtein: two-pass scan (narrow band first) against the single pass
             db = db[: int(rng.integers(33_000, min(len(db), 90_000)))]
             q = np.concatenate([db[: int(rng.integers(4100, min(len(db), 30_000)))], pool(rng, 500, L, skew, 0.0)])
