@@ -724,6 +724,31 @@ def _random_packed(n, L, seed, planted=0.0):
     return db
 
 
+@pytest.mark.parametrize("n,L,k,layout", [(300_000, 20, 10, 727261), (400_000, 27, 10, 72727161), (250_000, 24, 20, 82824140)])
+def test_layouts_with_two_radius2_blocks(oracle, n, L, k, layout):
+    """The planner may give TWO blocks the two-substitution neighbourhood (long guides on pools of millions: L = 27,
+    4.2 M targets 43 -> 32 ms per query).  Forced here on pools the oracle can check: blocks (7,7,6) radii (2,2,1),
+    (7,7,7,6) radii (2,2,1,1), (8,8,4,4) radii (2,2,1,0) -- against the plain scan on every row and the oracle on a sample."""
+    db = _random_packed(n, L, seed=900 + L + k, planted=0.01)
+    q = np.concatenate([db[: n // 3], _random_packed(3000, L, seed=78)])
+    idx = _lib.Index(db, L, _lib.METRIC_HAMMING)
+    try:
+        idx.set_param("pg_layout", layout)
+        ids, dists, counts = idx.knn(q, k)
+        assert idx.last_kernel()[0] == "k_hamming_scan_pg"
+        d1 = idx.nearest(q)
+        assert (d1 == dists[:, 0]).all()
+        idx.set_variant(8)
+        i8, d8, c8 = idx.knn(q, k)
+        assert (i8 == ids).all() and (d8 == dists).all() and (c8 == counts).all()
+        rows = np.sort(np.random.default_rng(4).choice(q.shape[0], size=400, replace=False))
+        oi, od, oc = oracle.knn(_packed_to_bytes(db, L), _packed_to_bytes(q[rows], L), L, "hamming", k)
+        od = np.where(od >= 0, od // 2, -1)
+        assert (oc == counts[rows]).all() and (od == dists[rows]).all() and (oi == ids[rows]).all()
+    finally:
+        idx.close()
+
+
 @pytest.mark.parametrize("n,L,k,planted,layout", [(200_000, 20, 3, 0.0, 61515140), (200_000, 20, 3, 0.02, 61515140),
                                                    (400_000, 20, 6, 0.01, 61515140), (300_000, 20, 10, 0.0, 61515140),
                                                    (260_000, 23, 5, 0.01, 0), (150_000, 17, 3, 0.0, 0)])
