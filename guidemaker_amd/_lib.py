@@ -115,6 +115,11 @@ def lib():
     L.gm_pigeon_block_info.restype = i32
     L.gm_pigeon_plan.argtypes = [i64, i32, i32, c.c_double]
     L.gm_pigeon_plan.restype = i32
+    L.gm_pigeon_plan_dist.argtypes = [i64, i64, i32, i32, c.c_double, c.POINTER(c.c_double), i32, c.POINTER(i32),
+                                      c.POINTER(i32), c.POINTER(c.c_double), c.POINTER(i32)]
+    L.gm_pigeon_plan_dist.restype = i32
+    L.gm_pigeon_cascade_info.argtypes = [vp, i32, c.POINTER(i64), c.POINTER(i32), c.POINTER(i64), c.POINTER(i64)]
+    L.gm_pigeon_cascade_info.restype = i32
     L.gm_set_variant.argtypes = [vp, i32]
     L.gm_set_param.argtypes = [vp, c.c_char_p, i32]
     L.gm_set_param.restype = i32
@@ -165,7 +170,7 @@ EXPORTS = [
     "gm_cfd_batch_dev", "gm_last_kernel_ms", "gm_last_query_ms", "gm_last_kernel_name", "gm_last_kernel_pairs",
     "gm_set_variant", "gm_timing_reserve", "gm_timing_read", "gm_pam_count", "gm_pam_emit", "gm_pam_free",
     "gm_pack_keys_dev", "gm_unpack_keys_dev", "gm_site_flags", "gm_seed_duplicated",
-    "gm_last_kernel_evaluated", "gm_last_incomplete", "gm_pigeon_blocks", "gm_pigeon_plan", "gm_pigeon_block_info", "gm_set_param",
+    "gm_last_kernel_evaluated", "gm_last_incomplete", "gm_pigeon_blocks", "gm_pigeon_plan", "gm_pigeon_plan_dist", "gm_pigeon_cascade_info", "gm_pigeon_block_info", "gm_set_param",
     "gm_multi_create", "gm_multi_knn_query", "gm_multi_devices", "gm_multi_has_comm", "gm_multi_index", "gm_multi_free",
 ]
 
@@ -357,6 +362,16 @@ class Index:
             out.append((int(pos.value), int(pairs.value)))
         return out
 
+    def cascade_info(self):
+        """K1P levels of the last query: list of dict(n_q, radius, pairs, left) -- level 0 first; [] = plain scan."""
+        out = []
+        n = int(lib().gm_pigeon_cascade_info(self._h, -1, None, None, None, None))
+        for lv in range(n):
+            nq, rad, pairs, left = ctypes.c_int64(0), ctypes.c_int32(0), ctypes.c_int64(0), ctypes.c_int64(0)
+            lib().gm_pigeon_cascade_info(self._h, lv, ctypes.byref(nq), ctypes.byref(rad), ctypes.byref(pairs), ctypes.byref(left))
+            out.append(dict(n_q=int(nq.value), radius=int(rad.value), pairs=int(pairs.value), left=int(left.value)))
+        return out
+
     def pigeon_blocks(self):
         """Blocks of the pigeonhole layout built for this index (0: the plain scan is in use)."""
         return int(lib().gm_pigeon_blocks(self._h))
@@ -441,6 +456,22 @@ def pam_scan(seq, pam, five_prime, guidelen, device=0):
         if h.value:
             lib().gm_pam_free(h)
     return packed, tstart, mstart, int(nf.value)
+
+
+def pigeon_plan_dist(n_db, n_q, guidelen, k, p_short, p_match=0.25, levels=3):
+    """The planner with a measured distribution p_short[r] (share of the candidates whose k-th neighbour lies beyond
+    r): -> dict(blocks=[(len, radius), ...], cost, cascade).  Host arithmetic, no GPU needed."""
+    import numpy as _np
+    ps = _np.ascontiguousarray(p_short, dtype=_np.float64)
+    if ps.shape[0] < guidelen + 1:
+        raise ValueError("p_short needs guidelen + 1 entries")
+    blen = (ctypes.c_int32 * 8)()
+    trad = (ctypes.c_int32 * 8)()
+    cost, casc = ctypes.c_double(0.0), ctypes.c_int32(0)
+    B = int(lib().gm_pigeon_plan_dist(int(n_db), int(n_q), int(guidelen), int(k), float(p_match),
+                                      ps.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), int(levels), blen, trad,
+                                      ctypes.byref(cost), ctypes.byref(casc)))
+    return dict(blocks=[(int(blen[b]), int(trad[b])) for b in range(B)], cost=float(cost.value), cascade=int(casc.value))
 
 
 def pigeon_plan(n_db, guidelen, k, p_match=0.25):

@@ -13,6 +13,21 @@
 
 struct gm_pigeon;   // K1P state (gm_pigeon.hip)
 
+// K1P cascade (gmhip.hip run_hamming_pigeon): the rows a K1P pass leaves short -- their k-th neighbour lies beyond the
+// pass's radius -- are searched again, as a compact candidate set, by a further K1P pass with a larger radius and a
+// layout of its own (fewer, larger buckets: the set is a fraction of the candidates), and only what the last pass
+// leaves goes to the plain scan.  Every level owns its pool copies, workspaces and plan.
+constexpr int GM_PG_LEVELS = 3;
+struct gm_pg_level_state {
+    gm_pigeon* pg = nullptr;
+    int64_t plan_nq = -1;
+    int plan_k = -1, plan_found = 0, plan_cascade = 0;
+    int pg_flooded_k1 = 0;
+    double plan_cost = 1.0;
+    gm_pg_layout plan_lay{};
+    std::vector<double> plan_p_short;
+};
+
 struct gm_index {
     int device = 0;
     int L = 0;
@@ -52,10 +67,22 @@ struct gm_index {
     int lv_two_pass = 1;          // Levenshtein: narrow-band first pass + second pass for the short lists (gm_set_param "lv_two_pass")
     int lv_seg = 0;               // experiments (gm_set_param "lv_seg"): pool segments of the Levenshtein scan, 0 = choose
     int n_simd = 1024;            // CUs x 4
-    gm_pigeon* pg = nullptr;      // K1P: block-sorted pool copies + query workspaces (built on first use)
+    gm_pigeon* pg = nullptr;      // K1P: block-sorted pool copies + query workspaces (built on first use) of the
+                                  // cascade level that is running (level 0 between queries)
     // the layout planner's last answer (the enumeration costs ~30 us of host time per query otherwise)
     int64_t plan_nq = -1;
     int plan_k = -1, plan_found = 0;
+    int plan_cascade = 0;         // the plan sends the rows it leaves short to a deeper K1P level
+    double plan_cost = 1.0;       // the planner's cost of the plan (pool scans per candidate, re-scans included)
+    std::vector<double> plan_p_short;      // measured share of the candidates whose k-th neighbour lies beyond r (empty: no sample)
+    gm_pg_level_state pg_deeper[GM_PG_LEVELS - 1];      // the state of levels 1 .. (swapped in while such a level runs)
+    int pg_level = 0;             // cascade level whose state is in pg / plan_* right now
+    int pg_cascade = 1;           // gm_set_param "pg_cascade": 0 = never, 1 = when the planner says so, 2 = whenever rows are left
+    int pg_layout_deeper = 0;     // gm_set_param "pg_layout2": forced layout of the deeper levels (tests; digits as "pg_layout")
+    // per level of the last query: candidates, radius, pairs evaluated, rows left short (gm_pigeon_cascade_info)
+    int64_t casc_nq[GM_PG_LEVELS]{}, casc_pairs[GM_PG_LEVELS]{}, casc_left[GM_PG_LEVELS]{};
+    int casc_radius[GM_PG_LEVELS]{};
+    int casc_levels = 0;
     // k (+ 1) for which the planner's layout left more than a third of the candidates incomplete on this pool (repeat
     // families flood the hit lists): later queries with that k go straight to the plain scan
     int pg_flooded_k1 = 0;
@@ -112,7 +139,10 @@ GM_FOR_EACH_LEN(GM_DECL_PG)
 // gm_pg_scan: the K1P launch; gm_pg_merge: hit lists -> top k + the list of rows that are not exact;
 // gm_pg_incomplete: how many such rows (synchronises the stream); gm_pg_gather / gm_pg_scatter: move those rows
 // to / from a compact query.
-int gm_pg_plan(int64_t n_db, int64_t n_q, int L, int k, double p_match, gm_pg_layout* out, const double* p_short = nullptr);
+int gm_pg_plan(int64_t n_db, int64_t n_q, int L, int k, double p_match, gm_pg_layout* out, const double* p_short = nullptr,
+               int deeper_levels = 0, double* cost_out = nullptr, int* cascade_out = nullptr);
+void gm_pg_inherit(gm_index* idx, const gm_pigeon* parent);      // a deeper level takes over the pool's composition + the knobs
+const gm_pigeon* gm_pg_state(const gm_index* idx);
 int gm_pg_sample_rows(gm_index* idx, int64_t n, int64_t stride, hipStream_t st);
 bool gm_pg_sampling(const gm_index* idx);
 void gm_pg_expect_short(gm_index* idx, double share);      // (of the candidates, at the planned layout's radius)

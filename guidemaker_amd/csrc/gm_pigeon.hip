@@ -399,8 +399,9 @@ __global__ __launch_bounds__(256) void k_fill_chunks(PgLayoutArg A, const int* _
 __global__ __launch_bounds__(256) void k_count_incomplete(const int32_t* __restrict__ counts, const int32_t* __restrict__ d1,
                                                           int64_t n, int need, int* __restrict__ n_bad) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (counts != nullptr ? counts[i] < need : d1[i] < 0) atomicAdd(n_bad, 1);
+    const bool bad = i < n && (counts != nullptr ? counts[i] < need : d1[i] < 0);
+    const uint64_t bal = __builtin_amdgcn_ballot_w64(bad);      // one atomic per wave that has any
+    if (bal != 0ull && (threadIdx.x & 63u) == 0u) atomicAdd(n_bad, __builtin_popcountll(bal));
 }
 
 __global__ __launch_bounds__(256) void k_stride_rows(int32_t* __restrict__ inc, int64_t n, int64_t stride) {
@@ -457,9 +458,8 @@ __global__ __launch_bounds__(256) void k_collect_bad(const int32_t* __restrict__
                                                      const int32_t* __restrict__ counts2, const int32_t* __restrict__ d1,
                                                      int32_t* __restrict__ out, int* __restrict__ n_out) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    if (counts2 != nullptr ? counts2[j] < need : d1[j] < 0)
-        out[atomicAdd(n_out, 1)] = (int32_t)((uint32_t)inc[j] & ~gm::PG_INC_OVERFLOW);
+    const bool take = j < n && (counts2 != nullptr ? counts2[j] < need : d1[j] < 0);
+    gm::gm_block_append(take, take ? (int32_t)((uint32_t)inc[j] & ~gm::PG_INC_OVERFLOW) : 0, out, n_out);
 }
 
 
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(256) void k_cand_cutflag(const uint2* __restrict__ 
 __global__ __launch_bounds__(256) void k_collect_short(const int32_t* __restrict__ counts, int64_t n, int need,
                                                        int32_t* __restrict__ out, int* __restrict__ n_out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && counts[i] < need) out[atomicAdd(n_out, 1)] = (int32_t)i;
+    gm::gm_block_append(i < n && counts[i] < need, (int32_t)i, out, n_out);
 }
 
 template <class T>
@@ -737,14 +737,59 @@ int gm_pg_layout_radius(const gm_pg_layout& lay) {
 // a plain scan of the sample, gmhip.hip) -- replaces the Poisson term, which knows the pool's composition but not the
 // spread between candidates (on a GC-rich real genome an AT-rich candidate has a fraction of the average's neighbours)
 // nor repeats.
-// Returns 1 and fills *out when a layout beats the plain scan clearly (cost < 0.45), else 0.
-int gm_pg_plan(int64_t n_db, int64_t n_q, int L, int k, double p_match, gm_pg_layout* out, const double* p_short) {
+// Cascade (deeper_levels > 0, p_short given): the rows a layout leaves short need not take the plain re-scan (cost 1.0 =
+// the whole pool per row).  When they are many they form a candidate set of their own, n_q x p_short[r] rows whose k-th
+// neighbour lies beyond r with the conditional shares p_short[r'] / p_short[r], and a deeper K1P level with a larger
+// radius (and, the set being small, fewer and larger buckets) serves them at its own planned cost + the fixed price of
+// one more level (grouping, merge, read-back: ~150 us, expressed in pool scans per row).  On a real genome the k-th
+// neighbour's distance spreads over 3 .. 7 (P. aeruginosa PAO1, k = 10: 5 for half the guides, beyond 5 for 12.6 %),
+// and the first level then runs the radius the MAJORITY needs instead of the radius nearly all need.
+// Returns 1 and fills *out when a layout beats the plain scan clearly (cost < 0.45), else 0; *cost_out = its cost,
+// *cascade_out = 1 when the cost assumes that a deeper level takes the short rows.
+constexpr double PG_PAIR_RATE = 2.6e13;          // evaluated pairs per second of the look-up scans (S1 .. S4, profiles/r02)
+constexpr double PG_LEVEL_OVERHEAD_US = 150.0;   // fixed price of one more K1P level
+constexpr double PG_CASCADE_MIN_ROWS = 4096.0;   // fewer short rows than this: the plain / prefix re-scan
+int gm_pg_plan(int64_t n_db, int64_t n_q, int L, int k, double p_match, gm_pg_layout* out, const double* p_short,
+               int deeper_levels, double* cost_out, int* cascade_out) {
+    if (cost_out) *cost_out = 1.0;
+    if (cascade_out) *cascade_out = 0;
     if (L < 12 || L > GM_MAX_GUIDELEN || n_db < 32768 || k < 1 || k > 20) return 0;
     if (!(p_match >= 0.25 && p_match < 0.9)) p_match = 0.25;
     if (n_q < 1) n_q = n_db;
     const double rho = ((1.0 - p_match) / 3.0) / p_match;
     double best = 0.45;      // K1P has to be clearly cheaper than scanning everything
     int found = 0;
+    // price of a row left short at radius r (memoised: it depends on r only)
+    double tail_of[GM_MAX_GUIDELEN + 2];
+    int tail_casc[GM_MAX_GUIDELEN + 2];
+    for (int r = 0; r <= GM_MAX_GUIDELEN + 1; ++r) {
+        tail_of[r] = -1.0;
+        tail_casc[r] = 0;
+    }
+    auto tail = [&](int r, double p_inc) {
+        if (r > L) r = L;
+        if (tail_of[r] >= 0.0) return tail_of[r];
+        double t = 1.0;
+        const double n_sub = (double)n_q * p_inc;
+        if (deeper_levels > 0 && p_short != nullptr && p_inc > 0.0 && n_sub >= PG_CASCADE_MIN_ROWS) {
+            double ps2[GM_MAX_GUIDELEN + 2];
+            for (int rr = 0; rr <= L; ++rr) {
+                const double c = rr <= r ? 1.0 : p_short[rr] / p_inc;
+                ps2[rr] = c < 1.0 ? c : 1.0;
+            }
+            gm_pg_layout sub{};
+            double c2 = 1.0;
+            if (gm_pg_plan(n_db, (int64_t)n_sub, L, k, p_match, &sub, ps2, deeper_levels - 1, &c2, nullptr)) {
+                const double fixed = PG_LEVEL_OVERHEAD_US * 1e-6 * PG_PAIR_RATE / ((double)n_db * n_sub);
+                if (c2 + fixed < t) {
+                    t = c2 + fixed;
+                    tail_casc[r] = 1;
+                }
+            }
+        }
+        tail_of[r] = t;
+        return t;
+    };
     for (int n2 = 0; n2 <= 2; ++n2)      // (two radius-2 blocks pay off for long guides on pools of millions: L = 27, 4.2 M: 43 -> 32 ms)
         for (int n1 = 0; n1 <= 5; ++n1)      // (four radius-1 blocks: 262 k targets, L = 20, k = 10: 0.64 -> 0.46 ms per query)
             for (int n0 = 0; n2 + n1 + n0 <= GM_PG_MAXB; ++n0) {
@@ -759,7 +804,9 @@ int gm_pg_plan(int64_t n_db, int64_t n_q, int L, int k, double p_match, gm_pg_la
                 }
                 if (mean > 700.0) p_inc = 0.0;
                 if (p_short != nullptr) p_inc = p_short[r < L ? r : L];
-                if (p_inc >= best) continue;
+                if (p_inc > 1.0) p_inc = 1.0;
+                const double p_tail = p_inc * tail(r, p_inc);
+                if (p_tail >= best) continue;
                 for (int len2 = n2 ? 4 : 0; len2 <= (n2 ? GM_PG_MAXLEN : 0); ++len2)
                     for (int len1 = (n1 && n0) ? 2 : 0; len1 <= ((n1 && n0) ? GM_PG_MAXLEN : 0); ++len1)
                     for (int e1 = 0; e1 < ((n1 && n0) ? n1 : 1); ++e1) {      // e1 of the radius-1 blocks one base longer
@@ -811,14 +858,16 @@ int gm_pg_plan(int64_t n_db, int64_t n_q, int L, int k, double p_match, gm_pg_la
                         int lists = 0;
                         for (int b = 0; b < B; ++b) lists += (gm_pg_buckets_of(lay.blen[b], lay.trad[b]) + 7) / 8;
                         if (lists > GM_PG_MAXLISTS) continue;
-                        const double cost = work + (p_inc < 1.0 ? p_inc : 1.0);
+                        const double cost = work + p_tail;
                         if (cost < best) {
                             best = cost;
                             *out = lay;
                             found = 1;
+                            if (cascade_out) *cascade_out = tail_casc[r < L ? r : L];
                         }
                     }
             }
+    if (cost_out) *cost_out = best;
     return found;
 }
 
@@ -851,6 +900,22 @@ int gm_pg_pool_stats(gm_index* idx, hipStream_t st, double* p_match) {
     return GM_OK;
 }
 
+// a deeper cascade level: the pool is the same (composition), the knobs follow level 0; its layout and copies are its own
+void gm_pg_inherit(gm_index* idx, const gm_pigeon* parent) {
+    if (!idx->pg) idx->pg = new gm_pigeon();
+    gm_pigeon* pg = idx->pg;
+    if (!parent) return;
+    pg->p_match = parent->p_match;
+    for (int b = 0; b < 4; ++b) pg->base_freq[b] = parent->base_freq[b];
+    pg->tune_sub = parent->tune_sub;
+    pg->tune_run = parent->tune_run;
+    pg->tune_msplit = parent->tune_msplit;
+    pg->tune_prefix = parent->tune_prefix;
+    pg->tune_debug = parent->tune_debug;
+    pg->tune_layout = idx->pg_layout_deeper;
+}
+const gm_pigeon* gm_pg_state(const gm_index* idx) { return idx->pg; }
+
 int gm_pg_blocks_of(const gm_index* idx) { return idx->pg ? idx->pg->B : 0; }
 int gm_pg_radius(const gm_index* idx) {
     if (!idx->pg) return 0;
@@ -860,6 +925,17 @@ int gm_pg_radius(const gm_index* idx) {
 }
 
 int gm_pg_set_param(gm_index* idx, const char* name, int value) {
+    if (std::strcmp(name, "pg_cascade") == 0) {
+        if (value < 0 || value > 2) return gm_fail(GM_ERR_ARG, "pg_cascade: 0 (off), 1 (planner), 2 (whenever rows are left short)");
+        idx->pg_cascade = value;
+        idx->plan_nq = -1;
+        return GM_OK;
+    }
+    if (std::strcmp(name, "pg_layout2") == 0) {      // forced layout of the deeper cascade levels (tests)
+        idx->pg_layout_deeper = value;
+        for (auto& lv : idx->pg_deeper) lv.plan_nq = -1;
+        return GM_OK;
+    }
     if (!idx->pg) idx->pg = new gm_pigeon();
     if (std::strcmp(name, "pg_sub") == 0) {
         if (value < 1 || value > 19) return gm_fail(GM_ERR_ARG, "pg_sub: 1..19");

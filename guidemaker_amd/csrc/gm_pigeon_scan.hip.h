@@ -347,6 +347,31 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
     if (lane < ch.cn) lists[(int64_t)((uint32_t)Q.qrow[lane] & 0x7fffffffu) * row_words + ch.lst] = (uint32_t)Q.cnt[lane];
 }
 
+// Appends `value` of the threads with take == true to out[] (order irrelevant): the workgroup's threads are ranked by
+// wave ballots + an LDS scan of the wave totals, ONE atomicAdd per workgroup on *counter hands out the range.  Every
+// thread of the workgroup calls it (it contains barriers); blockDim.x = a multiple of 64, at most 1024.
+__device__ __forceinline__ void gm_block_append(bool take, int32_t value, int32_t* __restrict__ out, int* __restrict__ counter) {
+    __shared__ int s_wave[16];
+    __shared__ int s_base;
+    const uint64_t bal = __builtin_amdgcn_ballot_w64(take);
+    const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+    const int before = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+    if (lane == 0) s_wave[wave] = __builtin_popcountll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int n_waves = (int)((blockDim.x + 63u) >> 6);
+        int tot = 0;
+        for (int w = 0; w < n_waves; ++w) {
+            const int c = s_wave[w];
+            s_wave[w] = tot;
+            tot += c;
+        }
+        s_base = tot != 0 ? atomicAdd(counter, tot) : 0;
+    }
+    __syncthreads();
+    if (take) out[s_base + s_wave[wave] + before] = value;
+}
+
 // K1P merge: SPLIT adjacent lanes per candidate (4 for lists of <= 10 keys, where the kernel waits for memory; fewer
 // for 20 keys, where the sorted-insert ripples of a divergent wave are the cost), each folding every SPLIT-th hit list into its
 // own register list (duplicates taken once), then lane 0 of the group takes the other lists over by shuffles and
@@ -393,21 +418,36 @@ __global__ void k_merge_hits(gm_pg_blocks P, const uint32_t* __restrict__ lists,
             if (sub < off && v != 0u && v < list.v[KCAP - 1]) list.insert(v - 1u);
         }
     }
-    if (sub != 0 || !valid) return;
+    // The incomplete rows are appended to `inc` with ONE device-wide atomic per workgroup (gm_block_append) and counted
+    // through LDS: with a thread per row on the same address, a cascade's first level -- which leaves a third of the rows
+    // short on purpose -- spent 1.8 ms of S3's 2.4 ms merge in 270 000 serialised atomics (profiles/r03/NOTES.md).
+    __shared__ int s_hist[24], s_over;
+    if (threadIdx.x < 24) s_hist[threadIdx.x] = 0;
+    if (threadIdx.x == 24) s_over = 0;
+    __syncthreads();
+    const bool owner = sub == 0 && valid;
     const bool full = list.v[KCAP - 1] != RegList<KCAP>::EMPTY;
     // (a short row that took the id cut-off does not know all its neighbours at r either)
-    if (!overflow && !full && cflag != nullptr && cflag[qi] != 0) overflow = 1;
-    if (overflow) {      // hits were lost: nothing about this row is known
+    if (owner && !overflow && !full && cflag != nullptr && cflag[qi] != 0) overflow = 1;
+    int32_t entry = 0;
+    bool take = false;
+    if (owner && overflow) {      // hits were lost: nothing about this row is known
         list.init(k, nullptr, 0);
-        inc[atomicAdd(inc_count, 1)] = (int32_t)((uint32_t)qi | PG_INC_OVERFLOW);
-        atomicAdd(over_count, 1);
-    } else if (!full) {      // every target within r is in the list (there are fewer than k): kept for the re-scan
-        inc[atomicAdd(inc_count, 1)] = (int32_t)qi;
+        entry = (int32_t)((uint32_t)qi | PG_INC_OVERFLOW);
+        take = true;
+        atomicAdd(&s_over, 1);
+    } else if (owner && !full) {      // every target within r is in the list (there are fewer than k): kept for the re-scan
+        entry = (int32_t)qi;
+        take = true;
         int c = 0;
 #pragma unroll
         for (int s = 0; s < KCAP; ++s) c += (list.v[s] != 0u && list.v[s] != RegList<KCAP>::EMPTY) ? 1 : 0;
-        atomicAdd(&chist[c < 23 ? c : 23], 1);      // (the host sizes the prefix re-scan from this)
+        atomicAdd(&s_hist[c < 23 ? c : 23], 1);      // (the host sizes the prefix re-scan from this)
     }
+    gm_block_append(take, entry, inc, inc_count);      // (contains the barrier that orders the LDS counters)
+    if (threadIdx.x < 24 && s_hist[threadIdx.x] != 0) atomicAdd(&chist[threadIdx.x], s_hist[threadIdx.x]);
+    if (threadIdx.x == 24 && s_over != 0) atomicAdd(over_count, s_over);
+    if (!owner) return;
     list.store(k, qi, ids, dists, counts, nearest != 0);
 }
 

@@ -417,11 +417,44 @@ int run_hamming_prefix(gm_index* idx, bool nearest, int64_t n, int k, int kcap, 
     return gm_pg_merge_prefix(idx, kcap, idx->d_keys, (int)n_seg + 1, n, a.k, nearest, st);
 }
 
-// K1P (gm_pigeon.hip): exact Hamming k-NN from B block-sorted pool copies, then the plain scan for the few
-// candidates whose merged list did not fill.  Returns through *used whether K1P ran (the layout planner
-// may decide that the plain scan is the better choice for this pool / k).
-int run_hamming_pigeon(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t* ids, int32_t* dists,
-                       int32_t* counts, hipStream_t st, bool* used, bool timed = true) {
+// K1P (gm_pigeon.hip): exact Hamming k-NN from B block-sorted pool copies, then a deeper K1P level (larger radius,
+// layout of its own) or the plain scan for the candidates whose merged list did not fill.  Returns through *used
+// whether K1P ran (the layout planner may decide that the plain scan is the better choice for this pool / k).
+namespace {
+// the K1P state of cascade level `level` >= 1 swapped into the handle while that level runs on the compact candidate
+// set q (every gm_pg_* call works on idx->pg / idx->d_q)
+struct PgLevelScope {
+    gm_index* idx;
+    gm_pg_level_state* lv;
+    uint2* saved_q;
+    int saved_level;
+    void swap_state() {
+        std::swap(idx->pg, lv->pg);
+        std::swap(idx->plan_nq, lv->plan_nq);
+        std::swap(idx->plan_k, lv->plan_k);
+        std::swap(idx->plan_found, lv->plan_found);
+        std::swap(idx->plan_cascade, lv->plan_cascade);
+        std::swap(idx->plan_cost, lv->plan_cost);
+        std::swap(idx->pg_flooded_k1, lv->pg_flooded_k1);
+        std::swap(idx->plan_lay, lv->plan_lay);
+        std::swap(idx->plan_p_short, lv->plan_p_short);
+    }
+    PgLevelScope(gm_index* i, int level, const uint2* q) : idx(i), lv(&i->pg_deeper[level - 1]), saved_q(i->d_q), saved_level(i->pg_level) {
+        swap_state();
+        idx->d_q = const_cast<uint2*>(q);
+        idx->pg_level = level;
+    }
+    ~PgLevelScope() {
+        swap_state();
+        idx->d_q = saved_q;
+        idx->pg_level = saved_level;
+    }
+};
+}  // namespace
+
+static int run_pigeon_level(gm_index* idx, int level, bool nearest, int64_t n_q, int k, int32_t* ids, int32_t* dists,
+                            int32_t* counts, hipStream_t st, bool* used, bool timed, const double* p_short_in,
+                            int parent_radius) {
     *used = false;
     const int keff = nearest ? 1 : k;
     if (keff > 20 || idx->n_db < keff || n_q < 1) return GM_OK;
@@ -431,10 +464,10 @@ int run_hamming_pigeon(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
     // block 0 with the two-substitution neighbourhood, the others plain; 900 + B: block 0 two-substitution, block 1
     // one-substitution (tests, A/B); the result is exact for any layout
     const int vcode = idx->variant / 100;
-    const bool forced = vcode >= 1 && vcode <= 9 && idx->variant % 100 >= 2 && idx->variant % 100 <= GM_PG_MAXB;
+    const bool forced = level == 0 && vcode >= 1 && vcode <= 9 && idx->variant % 100 >= 2 && idx->variant % 100 <= GM_PG_MAXB;
     int rc;
     double p_match = 0.25;
-    if (idx->n_db >= 32768 || forced) {
+    if (idx->n_db >= 32768 || forced || level > 0) {
         if ((rc = gm_pg_pool_stats(idx, st, &p_match))) return rc;
     }
     gm_pg_layout lay{};
@@ -448,15 +481,25 @@ int run_hamming_pigeon(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
         if (idx->L / B < 2 && expand == 0) return GM_OK;
         if (!gm_pg_layout_make(idx->L, B, expand, len0, vcode >= 8 ? 1 : 0, &lay)) return GM_OK;
     } else if (gm_pg_layout_forced(idx, &lay)) {
-        // (gm_set_param "pg_layout": experiments)
+        // (gm_set_param "pg_layout" / "pg_layout2": experiments, tests)
+        if (level > 0) {
+            idx->plan_p_short.clear();
+            if (p_short_in) idx->plan_p_short.assign(p_short_in, p_short_in + idx->L + 1);
+        }
     } else {
-        if (idx->plan_nq != n_q || idx->plan_k != keff) {      // (the pool and its composition belong to the handle)
+        // (the pool and its composition belong to the handle; a deeper level's candidate count varies a little from query
+        // to query: its plan stands while the count stays within an eighth of the planned one)
+        const bool stale = level == 0 ? idx->plan_nq != n_q
+                                      : (idx->plan_nq < 0 || std::llabs((long long)(n_q - idx->plan_nq)) * 8 > (long long)idx->plan_nq);
+        if (stale || idx->plan_k != keff) {
             // how far the k-th neighbour lies, measured: a plain scan of every (n_q / 2048)-th candidate against the
             // whole pool (~0.1 ms, once per plan) -- the independent-base model knows the pool's composition, not the
             // spread between candidates or the repeats of a real genome
             std::vector<double> p_short;
             constexpr int64_t SAMPLE = 2048;
-            if (n_q >= 16 * SAMPLE && idx->n_db >= 32768 && idx->L >= 12 && gm_pg_sampling(idx)) {      // (gm_pg_plan's own preconditions)
+            if (level > 0) {
+                if (p_short_in) p_short.assign(p_short_in, p_short_in + idx->L + 1);      // the parent's shares, conditional
+            } else if (n_q >= 16 * SAMPLE && idx->n_db >= 32768 && idx->L >= 12 && gm_pg_sampling(idx)) {      // (gm_pg_plan's own preconditions)
                 const uint2* qs = nullptr;
                 int32_t *ids_s = nullptr, *dists_s = nullptr, *counts_s = nullptr;
                 if ((rc = gm_pg_sample_rows(idx, SAMPLE, n_q / SAMPLE, st))) return rc;
@@ -474,28 +517,45 @@ int run_hamming_pigeon(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
                 }
                 p_short.resize((size_t)idx->L + 1);
                 for (int r = 0; r <= idx->L; ++r) p_short[(size_t)r] = ((double)beyond[(size_t)r] + 0.5) / (double)(SAMPLE + 1);
-                if (std::getenv("GM_DEBUG")) {
-                    fprintf(stderr, "[gm] planner sample (%lld rows): share with the k-th neighbour beyond r =", (long long)SAMPLE);
-                    for (int r = 2; r <= 8 && r <= idx->L; ++r) fprintf(stderr, " %d:%.4f", r, p_short[(size_t)r]);
-                    fprintf(stderr, "\n");
-                }
             }
+            if (std::getenv("GM_DEBUG") && !p_short.empty()) {
+                fprintf(stderr, "[gm] level %d planner (%lld rows): share with the k-th neighbour beyond r =", level, (long long)n_q);
+                for (int r = 2; r <= 9 && r <= idx->L; ++r) fprintf(stderr, " %d:%.4f", r, p_short[(size_t)r]);
+                fprintf(stderr, "\n");
+            }
+            const int deeper = idx->pg_cascade != 0 ? GM_PG_LEVELS - 1 - level : 0;
+            double cost = 1.0;
+            idx->plan_cascade = 0;
             idx->plan_found = gm_pg_plan(idx->n_db, n_q, idx->L, keff, p_match, &idx->plan_lay,
-                                         p_short.empty() ? nullptr : p_short.data());
+                                         p_short.empty() ? nullptr : p_short.data(), deeper, &cost, &idx->plan_cascade);
             double expect = 0.0;
             if (idx->plan_found && !p_short.empty()) {
                 const int r = gm_pg_layout_radius(idx->plan_lay);
                 expect = p_short[(size_t)(r < idx->L ? r : idx->L)];
             }
+            if (std::getenv("GM_DEBUG")) {
+                fprintf(stderr, "[gm] level %d plan for %lld candidates: %s", level, (long long)n_q, idx->plan_found ? "blocks" : "none");
+                for (int b = 0; idx->plan_found && b < idx->plan_lay.B; ++b) fprintf(stderr, " %d/%d", idx->plan_lay.blen[b], idx->plan_lay.trad[b]);
+                fprintf(stderr, " cost %.4f, expects %.4f short%s\n", cost, expect, idx->plan_cascade ? " -> deeper level" : "");
+            }
             gm_pg_expect_short(idx, expect);
+            idx->plan_cost = cost;
+            idx->plan_p_short = p_short;
             idx->plan_nq = n_q;
             idx->plan_k = keff;
         }
         if (!idx->plan_found) return GM_OK;
         if (idx->pg_flooded_k1 == keff + 1) return GM_OK;
+        if (level > 0 && idx->pg_cascade == 1) {
+            // a level of its own has a fixed price (grouping, merge, read-back: ~150 us): for a few thousand rows the
+            // prefix / plain re-scan of the parent is the cheaper way (S1: 5 414 rows, 0.10 ms against 0.19)
+            const double fixed = 150e-6 * 2.6e13 / ((double)idx->n_db * (double)n_q);
+            if (idx->plan_cost + fixed >= 0.5) return GM_OK;
+        }
         lay = idx->plan_lay;
         planned = true;
     }
+    if (level > 0 && gm_pg_layout_radius(lay) <= parent_radius) return GM_OK;      // (a deeper level must reach further)
     if ((rc = gm_pg_prepare(idx, &lay, st))) {
         if (forced && rc == GM_ERR_ARG) return GM_OK;      // forced layout not usable for this length
         return rc;
@@ -516,20 +576,64 @@ int run_hamming_pigeon(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
         idx->last_evaluated = pairs;
         idx->last_incomplete = n_inc;
     }
+    const int radius = gm_pg_radius(idx);
+    if (level < GM_PG_LEVELS) {
+        idx->casc_nq[level] = n_q;
+        idx->casc_radius[level] = radius;
+        idx->casc_pairs[level] = pairs;
+        idx->casc_left[level] = n_inc;
+        idx->casc_levels = level + 1;
+    }
+    if (std::getenv("GM_DEBUG"))
+        fprintf(stderr, "[gm] level %d: %lld candidates, radius %d, %.3g pairs evaluated, %lld rows left short\n", level,
+                (long long)n_q, radius, (double)pairs, (long long)n_inc);
+    double expect = 0.0;      // share of the rows the plan itself expects short at this radius
+    if (planned && !idx->plan_p_short.empty()) expect = idx->plan_p_short[(size_t)(radius < idx->L ? radius : idx->L)];
     // A pool of repeat families floods the hit lists and K1P ends up handing most rows to the plain scan: twice the
     // work of the plain scan alone.  The answer of this query stands (exact either way); remember it for the next.
-    if (planned && n_inc > n_q / 3 && n_q >= 4096 && gm_pg_debug_flags(idx) == 0) idx->pg_flooded_k1 = keff + 1;
+    if (planned && (double)n_inc > (expect + 1.0 / 3.0) * (double)n_q && n_q >= 4096 && gm_pg_debug_flags(idx) == 0)
+        idx->pg_flooded_k1 = keff + 1;
     if (n_inc > 0) {
         const uint2* q2 = nullptr;
         int32_t *ids2 = nullptr, *dists2 = nullptr, *counts2 = nullptr;
         if ((rc = gm_pg_gather(idx, n_inc, keff, nearest, &q2, &ids2, &dists2, &counts2, st))) return rc;
+        // Cascade: many rows left short (their k-th neighbour lies beyond this level's radius: the planner chose the
+        // radius the majority needs) -> a deeper K1P level over the compact rows, planned for THEIR number and the
+        // conditional distribution of their k-th neighbour; what that level leaves takes its own re-scan paths.
+        if (level + 1 < GM_PG_LEVELS && idx->pg_cascade != 0 && idx->pg_flooded_k1 != keff + 1 &&
+            (idx->pg_cascade == 2 ? n_inc >= 64 : (n_inc >= 4096 && !idx->plan_p_short.empty()))) {
+            std::vector<double> ps2;
+            if (!idx->plan_p_short.empty()) {
+                const int L = idx->L;
+                const double base = idx->plan_p_short[(size_t)(radius < L ? radius : L)];
+                ps2.resize((size_t)L + 1);
+                for (int rr = 0; rr <= L; ++rr) {
+                    const double c = rr <= radius || base <= 0.0 ? 1.0 : idx->plan_p_short[(size_t)rr] / base;
+                    ps2[(size_t)rr] = c < 1.0 ? c : 1.0;
+                }
+            }
+            bool used2 = false;
+            {
+                const gm_pigeon* parent = gm_pg_state(idx);
+                PgLevelScope scope(idx, level + 1, q2);
+                gm_pg_inherit(idx, parent);
+                rc = run_pigeon_level(idx, level + 1, nearest, n_inc, k, ids2, dists2, counts2, st, &used2, false,
+                                      ps2.empty() ? nullptr : ps2.data(), radius);
+            }
+            if (rc) return rc;
+            if (used2) {
+                if ((rc = gm_pg_scatter(idx, n_inc, keff, nearest, ids, dists, counts, st))) return rc;
+                *used = true;
+                return GM_OK;
+            }
+        }
         // A row that is short without an overflow knows all its neighbours within r; the k - c it lacks are the targets
         // at r + 1 with the smallest ids, and the first part of the pool (id order) almost surely holds them: scan only
         // that prefix, fold in the partial lists, and hand the plain re-scan just the rows that are still short (and
         // those whose lists overflowed).
         const double frac = gm_pg_prefix_fraction(idx, keff);
         if (frac <= 0.6) {
-            if ((rc = run_hamming_prefix(idx, nearest, n_inc, keff, kcap, q2, gm_pg_radius(idx) + 2, frac, ids, dists, counts, st)))
+            if ((rc = run_hamming_prefix(idx, nearest, n_inc, keff, kcap, q2, radius + 2, frac, ids, dists, counts, st)))
                 return rc;
             if ((rc = gm_pg_scatter(idx, n_inc, keff, nearest, ids, dists, counts, st))) return rc;
             if ((rc = gm_pg_collect_bad(idx, n_inc, keff, nearest, st))) return rc;
@@ -547,7 +651,7 @@ int run_hamming_pigeon(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
         // these rows have fewer than k neighbours within r (or a flooded slot list): their k-th neighbour is
         // almost surely at r + 1, so scan under the bound d < r + 2 first and fall back to the unseeded scan
         // only if a list still does not fill
-        const int guess = gm_pg_radius(idx) + 2;
+        const int guess = radius + 2;
         if ((rc = run_hamming_lookup(idx, nearest, n_inc, keff, ids2, dists2, counts2, false, st, q2, guess))) return rc;
         if ((rc = gm_pg_scatter(idx, n_inc, keff, nearest, ids, dists, counts, st))) return rc;
         // the rows whose list did not fill under the guess (and only those) go through the unseeded scan
@@ -565,6 +669,12 @@ int run_hamming_pigeon(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
     }
     *used = true;
     return GM_OK;
+}
+
+int run_hamming_pigeon(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t* ids, int32_t* dists,
+                       int32_t* counts, hipStream_t st, bool* used, bool timed = true) {
+    idx->casc_levels = 0;
+    return run_pigeon_level(idx, 0, nearest, n_q, k, ids, dists, counts, st, used, timed, nullptr, -1);
 }
 
 // variant 0 = default (K1L look-up kernel), 1 = popcount kernel K1, 5 and 2x/3x = K1v knobs
@@ -1011,6 +1121,11 @@ void gm_index_free(gm_index* idx) {
     if (idx->d_db) (void)hipFree(idx->d_db);
     if (idx->d_vert) (void)hipFree(idx->d_vert);
     gm_pg_free(idx);
+    for (auto& lv : idx->pg_deeper) {      // the deeper cascade levels' K1P state
+        idx->pg = lv.pg;
+        lv.pg = nullptr;
+        gm_pg_free(idx);
+    }
     if (idx->d_onehot) (void)hipFree(idx->d_onehot);
     if (idx->d_peq) (void)hipFree(idx->d_peq);
     if (idx->d_keys) (void)hipFree(idx->d_keys);
@@ -1090,6 +1205,7 @@ static int knn_query_dev_impl(gm_index* idx, const void* d_q, int64_t n_q, int k
     if (rc) return rc;
     rc = planes_launch(static_cast<const uint64_t*>(d_q), idx->d_q, n_q, n_q, st);
     if (rc) return rc;
+    idx->casc_levels = 0;
     if (use_leven_lookup(idx, k)) return run_leven_lookup(idx, n_q, k, ids, dists, counts, nullptr, st);
     if (use_lookup(idx)) {
         if (idx->variant == 0 || idx->variant > 100) {      // (variant 8 = plain two-phase scan, the A/B baseline of K1P)
@@ -1172,6 +1288,7 @@ static int nearest_dist_dev_impl(gm_index* idx, const void* d_q, int64_t n_q, vo
     if (rc) return rc;
     rc = planes_launch(static_cast<const uint64_t*>(d_q), idx->d_q, n_q, n_q, st);
     if (rc) return rc;
+    idx->casc_levels = 0;
     if (use_leven_lookup(idx, 1)) return run_leven_lookup(idx, n_q, 1, nullptr, nullptr, nullptr, d1, st);
     if (use_lookup(idx)) {
         if (idx->variant == 0 || idx->variant > 100) {
@@ -1372,6 +1489,32 @@ int gm_pigeon_plan(int64_t n_db, int guidelen, int k, double p_match) {
     }
     const int even = (guidelen + lay.B - 1) / lay.B;
     return lay.B + 100 * n1 + (n1 && len1 != even ? 1000 * len1 : 0) + 10000 * n2 + 100000 * len2;
+}
+
+int gm_pigeon_plan_dist(int64_t n_db, int64_t n_q, int guidelen, int k, double p_match, const double* p_short,
+                        int levels, int* blen, int* trad, double* cost, int* cascade) {
+    gm_pg_layout lay{};
+    double c = 1.0;
+    int casc = 0;
+    if (levels < 1) levels = 1;
+    if (levels > GM_PG_LEVELS) levels = GM_PG_LEVELS;
+    const int found = gm_pg_plan(n_db, n_q, guidelen, k, p_match, &lay, p_short, levels - 1, &c, &casc);
+    if (cost) *cost = c;
+    if (cascade) *cascade = found ? casc : 0;
+    for (int b = 0; b < GM_PG_MAXB; ++b) {
+        if (blen) blen[b] = found && b < lay.B ? lay.blen[b] : 0;
+        if (trad) trad[b] = found && b < lay.B ? lay.trad[b] : 0;
+    }
+    return found ? lay.B : 0;
+}
+
+int gm_pigeon_cascade_info(gm_index* idx, int level, int64_t* n_q, int* radius, int64_t* pairs, int64_t* left) {
+    if (!idx || level < 0 || level >= idx->casc_levels || level >= GM_PG_LEVELS) return idx ? idx->casc_levels : 0;
+    if (n_q) *n_q = idx->casc_nq[level];
+    if (radius) *radius = idx->casc_radius[level];
+    if (pairs) *pairs = idx->casc_pairs[level];
+    if (left) *left = idx->casc_left[level];
+    return idx->casc_levels;
 }
 
 }  // extern "C"

@@ -187,6 +187,18 @@ int gm_pigeon_block_info(gm_index* idx, int b, int* positions, int64_t* pairs);
  * when it differs from the even split ceil(guidelen / B); n2 = blocks with the two-substitution neighbourhood, len2 =
  * their length.  The layout serves radius 3 n2 + 2 n1 + (B - n1 - n2) - 1.  0 when the plain scan is the better choice. */
 int gm_pigeon_plan(int64_t n_db, int guidelen, int k, double p_match);
+/* The planner with a measured distribution (host arithmetic only): p_short[r], r = 0 .. guidelen, = share of the n_q
+ * candidates whose k-th neighbour lies beyond r (what the library samples before it plans a query of >= 32 768
+ * candidates); levels = K1P levels allowed (1 = a single pass, up to 3: the rows a pass leaves short go to a further
+ * pass with a larger radius and a layout planned for their number, "cascade").  Fills blen[8] / trad[8] (block lengths
+ * and search radii of the FIRST level's layout), *cost (modelled pool scans per candidate, everything included) and
+ * *cascade (1: the cost assumes a deeper level takes the short rows).  Returns the number of blocks, 0 = plain scan. */
+int gm_pigeon_plan_dist(int64_t n_db, int64_t n_q, int guidelen, int k, double p_match, const double* p_short,
+                        int levels, int* blen, int* trad, double* cost, int* cascade);
+/* The K1P cascade of the last query on this handle: number of levels that ran (0: the plain scan), and for level l
+ * (0 = the first pass) its candidates, the radius its layout serves, the pairs it evaluated and the rows it left
+ * short (handed to the next level or to the re-scan).  Returns the number of levels, or 0. */
+int gm_pigeon_cascade_info(gm_index* idx, int level, int64_t* n_q, int* radius, int64_t* pairs, int64_t* left);
 
 /* Per-launch timing history: gm_timing_reserve(idx, n) arms n HIP-event pairs (and resets the
  * history); every later scan-kernel launch on this handle records into the next pair (wrapping);

@@ -785,6 +785,50 @@ def test_prefix_rescan_matches_plain_rescan_and_oracle(oracle, n, L, k, planted,
         idx.close()
 
 
+@pytest.mark.parametrize("n,L,k,planted,lay1,lay2", [
+    (300_000, 20, 10, 0.01, 717160, 51515151),      # (7,7,6) radii (1,1,0) = r 4, then (5,5,5,5) all radius 1 = r 7
+    (300_000, 20, 10, 0.0, 717061, 61515140),       # (7,7,6) radii (1,0,1), then bench.py's S1 layout (r 6)
+    (400_000, 20, 5, 0.02, 50505050, 717160),       # four plain blocks (r 3), then r 4
+    (250_000, 23, 10, 0.01, 818170, 61616150),      # L = 23: (8,8,7) radii (1,1,0) = r 4, then (6,6,6,5) radii (1,1,1,0) = r 6
+    (200_000, 20, 20, 0.01, 717160, 61515140),      # 20 neighbours
+])
+def test_cascade_of_k1p_levels_is_exact(oracle, n, L, k, planted, lay1, lay2):
+    """The rows a K1P pass leaves short go, as a compact candidate set, through a deeper K1P level with a larger radius
+    and a layout of its own (gm_set_param "pg_cascade" = 2 forces that whenever >= 64 rows are left; "pg_layout2" = the
+    deeper levels' layout), and only what the last level leaves takes the plain re-scan.  Against the same query without
+    the cascade, the plain scan and the oracle on the rows with the farthest k-th neighbours + a random sample."""
+    db = _random_packed(n, L, seed=1300 + L + k, planted=planted)
+    rng = np.random.default_rng(19)
+    q = np.concatenate([db[: n // 2], _random_packed(4000, L, seed=79)])
+    idx = _lib.Index(db, L, _lib.METRIC_HAMMING)
+    try:
+        idx.set_param("pg_layout", lay1)
+        idx.set_param("pg_cascade", 2)
+        idx.set_param("pg_layout2", lay2)
+        ids, dists, counts = idx.knn(q, k)
+        assert idx.last_kernel()[0] == "k_hamming_scan_pg"
+        info = idx.cascade_info()
+        assert len(info) >= 2 and info[0]["n_q"] == q.shape[0] and info[1]["n_q"] == info[0]["left"] >= 64, info
+        assert info[1]["radius"] > info[0]["radius"], info
+        d1 = idx.nearest(q)
+        assert (d1 == dists[:, 0]).all()
+        idx.set_param("pg_cascade", 0)
+        i0, d0, c0 = idx.knn(q, k)
+        assert len(idx.cascade_info()) == 1
+        assert (i0 == ids).all() and (d0 == dists).all() and (c0 == counts).all()
+        idx.set_variant(8)
+        i8, d8, c8 = idx.knn(q, k)
+        assert idx.cascade_info() == []
+        assert (i8 == ids).all() and (d8 == dists).all() and (c8 == counts).all()
+        far = np.flatnonzero(dists[:, k - 1] >= np.sort(dists[:, k - 1])[-1500])[:1200]
+        rows = np.unique(np.concatenate([far, rng.choice(q.shape[0], size=300, replace=False)]))
+        oi, od, oc = oracle.knn(_packed_to_bytes(db, L), _packed_to_bytes(q[rows], L), L, "hamming", k)
+        od = np.where(od >= 0, od // 2, -1)
+        assert (oc == counts[rows]).all() and (od == dists[rows]).all() and (oi == ids[rows]).all()
+    finally:
+        idx.close()
+
+
 @pytest.mark.parametrize("n,k,cut", [(500_000, 20, 0), (500_000, 20, 25), (500_000, 20, 4), (300_000, 5, 30), (300_000, 2, 10)])
 def test_id_cutoff_is_exact(oracle, n, k, cut):
     """Hits at the layout's radius only from targets with ids below a cut-off ("pg_cut": 0 = the library's choice, else

@@ -28,6 +28,31 @@ def pool(rng, n, L, skew, planted):
     return db
 
 
+def rand_layout(rng, L, r_lo, r_hi):
+    """A random K1P layout for guides of L bases whose radius lies in [r_lo, r_hi], as gm_set_param "pg_layout" digits
+    (len, radius per block; at most four blocks: the parameter is a 32-bit int) -- or 0 when none turned up."""
+    for _ in range(200):
+        B = int(rng.integers(3, 5)) if L <= 24 else 4
+        cuts = np.sort(rng.choice(np.arange(1, L), size=B - 1, replace=False))
+        lens = np.diff(np.concatenate([[0], cuts, [L]]))
+        if lens.min() < 3 or lens.max() > 8:
+            continue
+        rad = rng.choice([0, 1, 1, 2], size=B)
+        rad[lens < 4] = np.minimum(rad[lens < 4], 1)
+        order = np.argsort(-rad, kind="stable")      # (larger radii first, as the planner's layouts)
+        lens, rad = lens[order], rad[order]
+        r = int(rad.sum() + B - 1)
+        if not (r_lo <= r <= r_hi) or (rad == 2).sum() > 2:
+            continue
+        if sum((1 + 3 * l * (t >= 1) + 9 * (l * (l - 1) // 2) * (t >= 2) + 7) // 8 for l, t in zip(lens, rad)) > 64:
+            continue
+        code = 0
+        for l, t in zip(lens, rad):
+            code = code * 100 + int(l) * 10 + int(t)
+        return code
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
@@ -35,6 +60,7 @@ def main():
     ap.add_argument("--leven", type=float, default=0.15, help="share of Levenshtein cases")
     ap.add_argument("--max-n", type=int, default=400_000, help="largest pool (>= 1.5 M brings the radius-2 layouts in)")
     ap.add_argument("--max-q", type=int, default=120_000, help="largest number of pool members among the candidates")
+    ap.add_argument("--cascade", type=float, default=0.35, help="share of Hamming cases with a forced cascade of K1P levels")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     t0, case, used = time.time(), 0, {"k_hamming_scan_pg": 0}
@@ -72,6 +98,14 @@ def main():
             idx.set_param("pg_cut", cut)
             if rng.random() < 0.2:      # (default: the planner scans a sample of the candidates when there are >= 32768)
                 idx.set_param("pg_sample", 0)
+            casc = ""
+            if rng.random() < a.cascade:      # a first level that leaves many rows short + forced deeper levels
+                lay1, lay2 = rand_layout(rng, L, 2, 4), rand_layout(rng, L, 4, 8)
+                if lay1 and lay2:
+                    idx.set_param("pg_layout", lay1)
+                    idx.set_param("pg_layout2", lay2)
+                    idx.set_param("pg_cascade", 2)
+                    casc = " cascade %d -> %d" % (lay1, lay2)
             if k == 1 and rng.random() < 0.5:
                 got = (idx.nearest(q),)
                 name = idx.last_kernel()[0]
@@ -80,6 +114,10 @@ def main():
             else:
                 got = idx.knn(q, k)
                 name = idx.last_kernel()[0]
+                levels = idx.cascade_info()
+                if casc:
+                    casc += " levels " + "/".join("%d@r%d" % (lv["n_q"], lv["radius"]) for lv in levels)
+                    used["cascade levels >= 2"] = used.get("cascade levels >= 2", 0) + (len(levels) >= 2)
                 idx.set_variant(8)
                 want = idx.knn(q, k)
             resc = idx.last_evaluated()[1]
@@ -87,7 +125,7 @@ def main():
             idx.close()
         used[name] = used.get(name, 0) + 1
         ok = all((x == y).all() for x, y in zip(got, want))
-        print("case %3d n_db=%d n_q=%d L=%d k=%d skew=%.1f planted=%.2f cut=%d %s %s" % (case, len(db), len(q), L, k, skew, planted, cut, name, "ok" if ok else "MISMATCH"), flush=True)
+        print("case %3d n_db=%d n_q=%d L=%d k=%d skew=%.1f planted=%.2f cut=%d %s%s %s" % (case, len(db), len(q), L, k, skew, planted, cut, name, casc, "ok" if ok else "MISMATCH"), flush=True)
         if not ok:
             sys.exit(1)
     print("cases", case, used)

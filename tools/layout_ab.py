@@ -33,7 +33,8 @@ for lay in [0] + [int(x) for x in sys.argv[2:]]:
         same = ""
         if ref is None: ref = (ids.clone(), dists.clone())
         else: same = "same" if bool((ids == ref[0]).all()) and bool((dists == ref[1]).all()) else "DIFFERENT"
-        print("layout %8d: %7.2f ms/step, scan %.2f ms, evaluated %.3g, rescanned %d %s" % (lay, dt, idx.last_kernel()[1], ev, resc, same), flush=True)
+        lv = " | ".join("L%d %d rows r=%d %.3g pairs -> %d left" % (i, c["n_q"], c["radius"], c["pairs"], c["left"]) for i, c in enumerate(idx.cascade_info()))
+        print("layout %8d: %7.2f ms/step, scan %.2f ms, evaluated %.3g, rescanned %d %s  [%s]" % (lay, dt, idx.last_kernel()[1], ev, resc, same, lv), flush=True)
     except Exception as e:
         print("layout", lay, "failed:", e, flush=True)
     idx.close()
