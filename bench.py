@@ -102,7 +102,20 @@ def roofline_block(workload, pool, kname, kern_s, n_timed, query_ms, launch_pair
             reg = json.load(fh).get(workload, {})
     if reg and not reg.get("kernel", "").startswith(kname.split("(")[0]):
         reg = {}      # counters of another kernel: do not mix
-    ctr = reg.get("counters", {})
+    # The registered counters describe ONE launch shape: the layout the planner picked on the profiled box (the pairs it
+    # evaluated, the positions per block).  A live launch of another shape (another layout, cut-off or cascade split)
+    # must not be priced with them: then the line says "stale" and carries the modelled figure only.
+    stale = None
+    if reg:
+        live_blocks = [int(pos) for pos, _ in (block_info or [])]
+        reg_pairs, reg_blocks = reg.get("pairs_evaluated"), reg.get("block_positions")
+        if reg_pairs is None:
+            stale = "the registered PMC pass does not record the launch shape"
+        elif abs(float(reg_pairs) - evaluated_pairs) > 0.005 * max(evaluated_pairs, 1.0):
+            stale = "registered for %.6g evaluated pairs per launch, this launch evaluated %.6g" % (reg_pairs, evaluated_pairs)
+        elif reg_blocks is not None and list(reg_blocks) != live_blocks:
+            stale = "registered for block positions %s, this launch ran %s" % (reg_blocks, live_blocks)
+    ctr = reg.get("counters", {}) if not stale else {}
     peak = VALU_LANE_OPS_PER_S / 1e12
     if metric == "hamming":
         if block_info and sum(p for _, p in block_info) > 0:
@@ -147,8 +160,9 @@ def roofline_block(workload, pool, kname, kern_s, n_timed, query_ms, launch_pair
     else:
         roof["achieved"] = useful
         roof["frac"] = useful / peak
-        roof["counters"] = None
-        roof["note_counters"] = "no PMC pass registered for this workload/kernel: achieved = the modelled useful ops"
+        roof["counters"] = "stale" if stale else None
+        roof["note_counters"] = ("registered PMC pass not used (%s): achieved = the modelled useful ops" % stale) if stale else \
+            "no PMC pass registered for this workload/kernel: achieved = the modelled useful ops"
     if "achieved" in roof and useful > roof["achieved"]:
         # (K2B: part of the waves run the narrower band, i.e. fewer cells than the model's band: the kernel cannot do
         # more useful work than it issues)
@@ -156,7 +170,7 @@ def roofline_block(workload, pool, kname, kern_s, n_timed, query_ms, launch_pair
         model += "; capped at the issued rate"
     roof["useful"] = {"achieved": useful, "frac": useful / peak, "ops_per_pair": useful_opp, "model": model}
     compulsory = 8.0 * (n_q + n_db) + 8.0 * k * n_q
-    traffic = reg.get("hbm_side_bytes_per_launch")
+    traffic = reg.get("hbm_side_bytes_per_launch") if not stale else None
     roof["traffic"] = traffic
     roof["compulsory_bytes"] = compulsory
     if traffic:
@@ -180,6 +194,11 @@ def parse():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extra", default="auto",
+                    help="further workloads measured in the same process after the headline (N = 1 only), under "
+                         "extra.workloads: comma list of s2,s3,s4,pao1,cfd; 'auto' = all of them when the headline is s1, "
+                         "'none' = skip")
+    ap.add_argument("--extra-steps", type=int, default=50)
     return ap.parse_args()
 
 
@@ -256,6 +275,108 @@ def wall_clock_knn(pool, metric_code, device):
     return dt
 
 
+def measure_workload(name, steps, warmup, dev, stream):
+    """One further workload in the same process (N = 1): the device-resident k-NN of all its candidates against its
+    pool, `steps` timed steps after `warmup` (wall clock around synchronised steps, like the headline), the HIP-event
+    time of the dominant kernel, and its roofline block with the same counter guard as the headline."""
+    from guidemaker_amd import _lib, workloads
+    pool = workloads.make_pool(name)
+    L, k = pool["guidelen"], pool["k"]
+    metric_code = _lib.METRIC_HAMMING if pool["metric"] == "hamming" else _lib.METRIC_LEVEN
+    d_db = torch.from_numpy(pool["packed_db"].view(np.int64)).to(dev)
+    d_q = torch.from_numpy(np.ascontiguousarray(pool["packed_all"]).view(np.int64)).to(dev)
+    n_q, n_db = d_q.shape[0], d_db.shape[0]
+    ids = torch.empty((n_q, k), dtype=torch.int32, device=dev)
+    dists = torch.empty_like(ids)
+    counts = torch.empty((n_q,), dtype=torch.int32, device=dev)
+    idx = _lib.Index.from_device(d_db.data_ptr(), n_db, L, metric_code, dev.index or 0, stream)
+    try:
+        def step():
+            idx.knn_dev(d_q.data_ptr(), n_q, k, ids.data_ptr(), dists.data_ptr(), counts.data_ptr(), stream)
+        for _ in range(warmup):
+            step()
+        idx.timing_reserve(max(1, steps))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        kernel_ms = idx.timing_read()
+        kname = idx.last_kernel()[0]
+        c = counts.cpu().numpy()
+        d_all = dists.cpu().numpy()
+        assert (c == min(k, n_db)).all() and (np.diff(d_all, axis=1) >= 0).all() and (d_all[:, 0] == 0).all(), \
+            "bench sanity check failed (%s)" % name
+        kern_s = float(np.mean(kernel_ms)) * 1e-3
+        evaluated, rescanned = idx.last_evaluated()
+        roof = roofline_block(name, pool, kname, kern_s, len(kernel_ms), idx.last_query_ms(), float(idx.last_kernel()[2]),
+                              float(evaluated), rescanned, idx.pigeon_blocks() if "scan_pg" in kname else 0, n_q, n_db,
+                              idx.pigeon_block_info() if "scan_pg" in kname else None)
+        pairs = float(n_q) * n_db
+        return {"workload": pool["label"], "data": "real genome" if pool.get("real_genome") else "synthetic",
+                "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+                "value": pairs * steps / elapsed, "value_evaluated": float(evaluated) * steps / elapsed,
+                "n_candidates": int(n_q), "n_targets": int(n_db), "guidelen": L, "k": k, "distance": pool["metric"],
+                "kernel": kname, "kernel_ms_avg": kern_s * 1e3, "issued_frac": roof.get("frac") if roof.get("counters") not in (None, "stale") else None,
+                "useful_frac": roof["useful"]["frac"], "traffic": roof.get("traffic"),
+                "pairs_evaluated": float(evaluated), "candidates_rescanned": int(rescanned),
+                "k1p_levels": idx.cascade_info(), "roofline": roof}
+    finally:
+        idx.close()
+
+
+def measure_cfd(dev, stream, pairs=50_000_000, L=20, mismatches=4, rounds=20):
+    """k_cfd on device-resident pairs (what core.cfd_score batches): an HBM-streaming kernel, 24 algorithmic bytes per
+    pair (two packed operands in, one float64 out).  Torch events on the launch stream; checked on a sample against
+    the host mirror of calc_cfd."""
+    import ctypes
+    from guidemaker_amd import _lib, core
+    g = torch.randint(0, 1 << (2 * L), (pairs,), dtype=torch.int64, device=dev)
+    o = g.clone()
+    for _ in range(mismatches):
+        o ^= torch.randint(1, 4, (pairs,), dtype=torch.int64, device=dev) << (2 * torch.randint(0, L, (pairs,), device=dev))
+    mm = torch.from_numpy(core._load_cfd_table().reshape(-1)).to(dev)
+    out = torch.empty((pairs,), dtype=torch.float64, device=dev)
+    lib = _lib.lib()
+
+    def launch():
+        rc = lib.gm_cfd_batch_dev(ctypes.c_void_p(g.data_ptr()), ctypes.c_void_p(o.data_ptr()), pairs, L,
+                                  ctypes.c_void_p(mm.data_ptr()), ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(stream))
+        assert rc == 0, lib.gm_last_error()
+
+    for _ in range(3):
+        launch()
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        launch()
+        e1.record()
+        e1.synchronize()
+        times.append(e0.elapsed_time(e1))
+    ms = float(np.mean(times))
+    sel = np.random.default_rng(0).choice(pairs, 64, replace=False)
+    gs = _lib.unpack(g[sel].cpu().numpy().astype(np.uint64), L)
+    os_ = _lib.unpack(o[sel].cpu().numpy().astype(np.uint64), L)
+    want = np.array([core.calc_cfd(x, y) for x, y in zip(gs, os_)])
+    assert np.abs(out[sel].cpu().numpy() - want).max() <= 1e-6, "cfd sanity check failed"
+    gbs = pairs * 24 / (ms * 1e-3) / 1e9
+    res = {"workload": "CFD scores of %d device-resident guide pairs, L=%d, %d substituted positions" % (pairs, L, mismatches),
+           "kernel": "k_cfd", "pairs": pairs, "ms_per_step": ms, "kernel_ms_avg": ms, "value": pairs / (ms * 1e-3),
+           "unit": "guide pairs scored/s", "dtype": "f64",
+           "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_pair": 24, "traffic": None}}
+    if os.path.exists(COUNTERS_JSON):
+        with open(COUNTERS_JSON) as fh:
+            ent = json.load(fh).get("cfd", {})
+        if ent.get("hbm_side_bytes_per_launch") and ent.get("pairs", pairs) == pairs:
+            res["roofline"]["traffic"] = ent["hbm_side_bytes_per_launch"]
+            res["roofline"]["traffic_over_algorithmic"] = ent["hbm_side_bytes_per_launch"] / (pairs * 24.0)
+    return res
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -289,21 +410,23 @@ def main():
     metric_code = _lib.METRIC_HAMMING if pool["metric"] == "hamming" else _lib.METRIC_LEVEN
     db_np = pool["packed_db"]
     n_db = db_np.shape[0]
-    if args.scaling == "weak":
-        n_q = pool["packed_all"].shape[0]
-        if rank == 0:
-            q_np = pool["packed_all"]
-        else:
+    def rank_candidates(r):
+        """Candidates of rank r (every rank can form every rank's set: the self-check below scans them all)."""
+        if args.scaling == "weak":
+            if r == 0:
+                return pool["packed_all"]
             # the same kind of work on every rank: this rank's candidates are the genome's targets again, in an order
             # of their own (pool members, as in get_neighbors -- candidates from a foreign genome have no self hit and
             # leave twice as many rows to the re-scan, which would show up as a scaling loss that is not one)
-            q_np = pool["packed_all"][np.random.default_rng(1000 + rank).permutation(n_q)]
-    else:
+            return pool["packed_all"][np.random.default_rng(1000 + r).permutation(pool["packed_all"].shape[0])]
         shard = -(-pool["packed_all"].shape[0] // world)
-        n_q = shard
-        q_np = pool["packed_all"][rank * shard:(rank + 1) * shard]
-        if q_np.shape[0] < shard:       # pad the last shard so the all-gather is regular
-            q_np = np.concatenate([q_np, np.tile(q_np[-1:], shard - q_np.shape[0])])
+        q = pool["packed_all"][r * shard:(r + 1) * shard]
+        if q.shape[0] < shard:       # pad the last shard so the all-gather is regular
+            q = np.concatenate([q, np.tile(q[-1:] if q.shape[0] else pool["packed_all"][-1:], shard - q.shape[0])])
+        return q
+
+    q_np = rank_candidates(rank)
+    n_q = q_np.shape[0]
 
     d_db = torch.from_numpy(db_np.view(np.int64)).to(dev)
     d_q = torch.from_numpy(np.ascontiguousarray(q_np).view(np.int64)).to(dev)
@@ -366,6 +489,39 @@ def main():
     for _ in range(args.warmup):
         step()
     finish()
+    gather_ms = None
+    if world > 1:
+        # Outside the timed region, once: (1) the gathered table of one step equals this rank's OWN scan of every rank's
+        # candidates (the replicated pool makes every rank able to check every shard), (2) what one all-gather of a step's
+        # neighbour lists costs on its own (synchronous; in the timed loop it overlaps the next step's scan).
+        if args.warmup == 0:
+            step()
+            finish()
+        g_ids, g_dists, g_counts = gathered
+        chk_ids = torch.empty((n_q, k), dtype=torch.int32, device=dev)
+        chk_dists = torch.empty_like(chk_ids)
+        chk_counts = torch.empty((n_q,), dtype=torch.int32, device=dev)
+        for r in range(world):
+            d_qr = d_q if r == rank else torch.from_numpy(np.ascontiguousarray(rank_candidates(r)).view(np.int64)).to(dev)
+            idx.knn_dev(d_qr.data_ptr(), n_q, k, chk_ids.data_ptr(), chk_dists.data_ptr(), chk_counts.data_ptr(), stream)
+            lo = r * n_q
+            assert (g_ids[lo:lo + n_q].to(dev) == chk_ids).all() and (g_dists[lo:lo + n_q].to(dev) == chk_dists).all() \
+                and (g_counts[lo:lo + n_q].to(dev) == chk_counts).all(), \
+                "rank %d: the gathered rows of rank %d differ from this rank's own scan of them" % (rank, r)
+        del chk_ids, chk_dists, chk_counts
+        idx.knn_dev(d_q.data_ptr(), n_q, k, ids_b[0].data_ptr(), dists_b[0].data_ptr(), counts_b[0].data_ptr(), stream)
+        torch.cuda.synchronize()
+        times = []
+        for _ in range(3):
+            dist.barrier()
+            t_g = time.perf_counter()
+            if backend == "nccl":
+                distributed.all_gather_neighbors(ids_b[0], dists_b[0], counts_b[0], world * n_q)
+                torch.cuda.synchronize()
+            else:
+                distributed.all_gather_neighbors(ids_b[0].cpu(), dists_b[0].cpu(), counts_b[0].cpu(), world * n_q)
+            times.append((time.perf_counter() - t_g) * 1e3)
+        gather_ms = float(min(times))
     idx.timing_reserve(max(1, args.steps))
     torch.cuda.synchronize()
     if world > 1:
@@ -380,11 +536,19 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    kernel_ms = idx.timing_read()
+    per_rank = None
     if world > 1:
+        # every rank's own figures (a poor scaling curve must be attributable): wall clock per step, dominant-kernel
+        # time, the synchronous all-gather measured above, rows its K1P pass handed on
+        mine = {"rank": rank, "ms_per_step": elapsed / args.steps * 1e3, "kernel_ms_avg": float(np.mean(kernel_ms)),
+                "gather_ms_sync": gather_ms, "query_device_ms": idx.last_query_ms(),
+                "candidates_rescanned": int(idx.last_evaluated()[1])}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kernel_ms = idx.timing_read()
     kname = idx.last_kernel()[0]
     query_ms = idx.last_query_ms()
 
@@ -439,8 +603,28 @@ def main():
                                       "%s" % (world, " (overlapping the next step's scan)" if nbuf == 2 and use_async else "")},
             "roofline": roof,
         }
+        out["k1p_levels"] = idx.cascade_info()
+        if per_rank is not None:
+            out["per_rank"] = per_rank
+            out["gather_bytes_per_rank"] = int(n_q) * k * 4
         if world == 1:
             out["genome_wide_knn_wall_s"] = wall_clock_knn(pool, metric_code, local_rank)
+        want = args.extra
+        if want == "auto":
+            want = "s2,s3,s4,pao1,cfd" if args.workload == "s1" else "none"
+        if world == 1 and want != "none":
+            # the other BASELINE configurations (and the one real genome) in the same process, so that the driver's run
+            # times them too; the contract fields above stay the S1 headline's
+            extra = {}
+            for name in [w for w in want.split(",") if w]:
+                try:
+                    if name == "cfd":
+                        extra[name] = measure_cfd(dev, stream)
+                    else:
+                        extra[name] = measure_workload(name, args.extra_steps, max(5, args.warmup), dev, stream)
+                except Exception as e:      # a further workload must never break the headline line
+                    extra[name] = {"error": repr(e)}
+            out["extra"] = {"workloads": extra}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pool, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -27,10 +27,13 @@ struct gm_pg_blocks {
     int n_lists;
     int run;                             // consecutive chunk-table entries executed on the same XCD
     int debug;                           // timing experiments only (gm_set_param "pg_debug"): bit 0 = skip the list stores
-    int row_words;                       // words of one candidate's row of the hit buffer: [hit count of every list,
-                                         // padded to 4 words][keys of list 0][keys of list 1] ...
+    int row_words;                       // words of one candidate's row of the hit buffer: [keys of list 0][keys of list 1] ...
     int lcap[GM_PG_MAXLISTS];            // key capacity of list l (a multiple of 4)
     int loff[GM_PG_MAXLISTS];            // the keys of list l of candidate q start at word q * row_words + loff[l]
+    uint32_t* hdr;                       // [n_q][hdr_words]: the keys appended to list l of candidate q (more than lcap[l]: the
+                                         // list overflowed), written once by the list's workgroup -- a dense array of its own:
+                                         // the merge reads the headers of consecutive candidates from consecutive lines
+    int hdr_words;                       // n_lists rounded up to a multiple of 4
 };
 
 // A layout: B blocks of blen[b] bases (sum = guide length) with a search radius trad[b] per block: 0 = only the

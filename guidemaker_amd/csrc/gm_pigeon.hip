@@ -597,6 +597,8 @@ struct gm_pigeon {
     int64_t grid = 0;
     uint32_t* lists = nullptr;    // hit lists (gm_pg_blocks::loff / lcap)
     int64_t lists_cap = 0;
+    uint32_t* hdr = nullptr;      // one header word per (candidate, list) (gm_pg_blocks::hdr)
+    int64_t hdr_cap = 0;
     int64_t cap_nq = -1;          // candidate count / layout the list capacities were sized for
     int cap_sub_for = -1;
     uint64_t cap_layout_for = 0;
@@ -989,7 +991,7 @@ void gm_pg_free(gm_index* idx) {
     for (int b = 0; b < GM_PG_MAXB; ++b)
         if (pg->cperm[b]) (void)hipFree(pg->cperm[b]);
     void* bufs[] = {pg->k0, pg->k1, pg->r0, pg->r1, pg->sort_tmp, pg->nch, pg->cbase, pg->hist, pg->cursor, pg->chunks, pg->ctr,
-                    pg->lists, pg->raw_off, pg->inc, pg->inc_b, pg->cflag, pg->q2, pg->ids2, pg->dists2, pg->counts2};
+                    pg->lists, pg->hdr, pg->raw_off, pg->inc, pg->inc_b, pg->cflag, pg->q2, pg->ids2, pg->dists2, pg->counts2};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     if (pg->box) (void)hipHostFree(pg->box);
@@ -1322,9 +1324,9 @@ static void pg_list_capacity(const gm_index* idx, gm_pigeon* pg, int64_t n_q) {
             pg->mem_limit = (double)free_b / 4.0;
     }
     double scale = 1.0;
-    const int header = (P.n_lists + 3) / 4 * 4;      // the counts of all lists, then the keys
+    P.hdr_words = (P.n_lists + 3) / 4 * 4;      // (the lists' header words live in their own dense array)
     for (;;) {
-        int64_t words = header;
+        int64_t words = 0;
         for (int l = 0; l < P.n_lists; ++l) {
             double c = std::ceil(scale * (mean[l] + 4.0 * std::sqrt(mean[l]) + 2.0));
             if (c > 4096.0) c = 4096.0;
@@ -1399,6 +1401,8 @@ int gm_pg_scan(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
         pg->cap_sub_for = pg->tune_sub;
     }
     if ((rc = ensure(&pg->lists, &pg->lists_cap, gm_pg_list_words(pg) * n_q, "K1P hit lists"))) return rc;
+    if ((rc = ensure(&pg->hdr, &pg->hdr_cap, (int64_t)pg->blocks.hdr_words * n_q, "K1P list headers"))) return rc;
+    pg->blocks.hdr = pg->hdr;
     gm_pg_blocks& blocks = pg->blocks;
     for (int b = 0; b < pg->B; ++b) {
         blocks.blen[b] = pg->blen[b];

@@ -146,8 +146,9 @@ struct PgQueue {
     uint2* qpl;         // [WAVE]     candidate planes
     int* qrow;          // [WAVE]     candidate rows
     int* cnt;           // [WAVE]     hits appended so far
-    int* c1;            // [WAVE]     hits with d < thr0 - 1   (k == 1: best distance so far)
-    int* c2;            // [WAVE]     hits with d < thr0 - 2
+    uint32_t* c12;      // [WAVE]     distinct targets known with d < thr0 - 1 (low half) / d < thr0 - 2 (high half);
+                        //            k == 1: the best distance so far (whole word)
+    uint32_t* c34;      // [WAVE]     ... with d < thr0 - 3 / d < thr0 - 4
     int head, tail;     // wave-uniform ring positions (monotonic)
 };
 
@@ -171,6 +172,8 @@ __device__ __forceinline__ void pg_flush(PgQueue& Q, int n, int lane, const uint
     const int64_t row = (int64_t)(rw & 0x7fffffffu);
     const uint32_t cut_c = (rw >> 31) != 0u ? cut_id : 0xffffffffu;
     uint64_t hm = ((uint64_t)m.y << 32) | (uint64_t)m.x;
+    uint32_t inc12 = 0u, inc34 = 0u;      // this entry's owned hits below the four bound levels (16-bit fields)
+    int best = 64;
     while (hm != 0ull) {
         const int j = __builtin_ctzll(hm);
         hm &= hm - 1ull;
@@ -180,23 +183,38 @@ __device__ __forceinline__ void pg_flush(PgQueue& Q, int n, int lane, const uint
         if (d == thr0 - 1 && t.z >= cut_c) continue;      // id cut-off: at distance r only ids below it count
         bool owned = true;      // no earlier block finds this pair
         for (int b = 0; b < n_before; ++b) owned = owned && __popc(mism & bmask[b]) > brad[b];
-        if (k == 1) {
-            atomicMin(&Q.c1[cl], d);
-        } else {
-            if (d < thr0 - 1) atomicAdd(&Q.c1[cl], 1);
-            if (d < thr0 - 2) atomicAdd(&Q.c2[cl], 1);
-        }
+        best = d < best ? d : best;
+        // (every hit counts towards the bounds, reported by this list or not: it is a real target at that distance)
+        inc12 += (d < thr0 - 1 ? 1u : 0u) + (d < thr0 - 2 ? 0x10000u : 0u);
+        inc34 += (d < thr0 - 3 ? 1u : 0u) + (d < thr0 - 4 ? 0x10000u : 0u);
         if (!owned) continue;
         const int slot = atomicAdd(&Q.cnt[cl], 1);
         if (slot < lcap && !(debug & 1)) lists[row * row_words + slot] = ((uint32_t)d << ID_BITS) | t.z;
     }
+    if (k == 1) {
+        if (best < 64) atomicMin(&Q.c12[cl], (uint32_t)best);
+    } else if ((inc12 | inc34) != 0u) {
+        // one packed LDS add per entry and counter pair; a field that has reached 32 (k <= 20) takes no more, and an
+        // entry adds at most 255 per field: 31 + 64 x 255 stays inside 16 bits
+        const uint32_t o12 = Q.c12[cl], o34 = Q.c34[cl];
+        uint32_t a0 = inc12 & 0xffffu, a1 = inc12 >> 16, a2 = inc34 & 0xffffu, a3 = inc34 >> 16;
+        a0 = (o12 & 0xffffu) >= 32u ? 0u : (a0 > 255u ? 255u : a0);
+        a1 = (o12 >> 16) >= 32u ? 0u : (a1 > 255u ? 255u : a1);
+        a2 = (o34 & 0xffffu) >= 32u ? 0u : (a2 > 255u ? 255u : a2);
+        a3 = (o34 >> 16) >= 32u ? 0u : (a3 > 255u ? 255u : a3);
+        if ((a0 | a1) != 0u) atomicAdd(&Q.c12[cl], a0 | (a1 << 16));
+        if ((a2 | a3) != 0u) atomicAdd(&Q.c34[cl], a2 | (a3 << 16));
+    }
     __syncthreads();      // single-wave workgroup: orders the LDS atomics before the reads of the counters below
 }
 
-// bound of this lane's candidate from the counters the flushes keep
+// bound of this lane's candidate from the counters the flushes keep (the counts are nested: d < thr0 - 4 implies
+// d < thr0 - 3 ...): with k distinct targets known closer than t nothing at distance >= t can enter the top k
 __device__ __forceinline__ int pg_bound(const PgQueue& Q, int lane, int k, int thr0) {
-    if (k == 1) return Q.c1[lane] + 1;      // ties at the best distance stay in: the smallest id among them wins in the merge
-    return thr0 - (Q.c1[lane] >= k ? 1 : 0) - (Q.c2[lane] >= k ? 1 : 0);
+    if (k == 1) return (int)Q.c12[lane] + 1;      // ties at the best distance stay in: the smallest id among them wins in the merge
+    const uint32_t a = Q.c12[lane], b = Q.c34[lane];
+    const uint32_t kk = (uint32_t)k;
+    return thr0 - ((a & 0xffffu) >= kk ? 1 : 0) - ((a >> 16) >= kk ? 1 : 0) - ((b & 0xffffu) >= kk ? 1 : 0) - ((b >> 16) >= kk ? 1 : 0);
 }
 
 // evaluate one 64-target group from LDS (word offset WOFF) and queue the lanes that have hits
@@ -247,8 +265,8 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
     Q.qpl = Q.mask + PG_QCAP;
     Q.qrow = reinterpret_cast<int*>(Q.qpl + WAVE);
     Q.cnt = Q.qrow + WAVE;
-    Q.c1 = Q.cnt + WAVE;
-    Q.c2 = Q.c1 + WAVE;
+    Q.c12 = reinterpret_cast<uint32_t*>(Q.cnt + WAVE);
+    Q.c34 = Q.c12 + WAVE;
     Q.head = Q.tail = 0;
     const int lane = threadIdx.x;
     const bool valid = lane < ch.cn;
@@ -259,8 +277,8 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
     Q.qpl[lane] = qv;
     Q.qrow[lane] = (int)((uint32_t)qi | (lane_cut ? 0x80000000u : 0u));
     Q.cnt[lane] = 0;
-    Q.c1[lane] = k == 1 ? thr0 : 0;
-    Q.c2[lane] = 0;
+    Q.c12[lane] = k == 1 ? (uint32_t)thr0 : 0u;
+    Q.c34[lane] = 0u;
 
     // L = positions evaluated: the copy's table leaves out P.skiplen[b] positions of its own block (all pairs of
     // the bucket agree there, or differ on exactly one of them: `add`), so table position p is sequence position p
@@ -344,7 +362,7 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
     }
     // every (list, candidate) pair has exactly one writer (the row number comes back from LDS: a 64-bit index kept in
     // registers across the scan loop is two VGPRs the loop does not have)
-    if (lane < ch.cn) lists[(int64_t)((uint32_t)Q.qrow[lane] & 0x7fffffffu) * row_words + ch.lst] = (uint32_t)Q.cnt[lane];
+    if (lane < ch.cn) P.hdr[(int64_t)((uint32_t)Q.qrow[lane] & 0x7fffffffu) * P.hdr_words + ch.lst] = (uint32_t)Q.cnt[lane];
 }
 
 // Appends `value` of the threads with take == true to out[] (order irrelevant): the workgroup's threads are ranked by
@@ -390,10 +408,11 @@ __global__ void k_merge_hits(gm_pg_blocks P, const uint32_t* __restrict__ lists,
     RegList<KCAP> list;
     list.init(k, nullptr, 0);
     int overflow = 0;
-    const uint32_t* __restrict__ row = lists + qi * P.row_words;      // [counts][keys of list 0][keys of list 1] ...
+    const uint32_t* __restrict__ row = lists + qi * P.row_words;      // [keys of list 0][keys of list 1] ...
+    const uint32_t* __restrict__ hrow = P.hdr + qi * P.hdr_words;      // keys appended to every list of the row
     for (int l = sub; l < P.n_lists; l += SPLIT) {
         const int lcap = P.lcap[l];                    // multiple of 4
-        int c = (int)row[l];
+        int c = (int)hrow[l];
         if (c > lcap) {
             overflow = 1;
             c = lcap;

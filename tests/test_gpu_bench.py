@@ -21,7 +21,8 @@ def _last_json(text):
 
 def test_bench_single_gpu_line():
     out = subprocess.run([sys.executable, "bench.py", "--workload", "tiny", "--steps", "3", "--warmup", "1",
-                          "--cpu-seconds", "1"], cwd=ROOT, capture_output=True, text=True, timeout=400)
+                          "--cpu-seconds", "1", "--extra", "s2,pao1,cfd", "--extra-steps", "3"], cwd=ROOT,
+                         capture_output=True, text=True, timeout=400)
     assert out.returncode == 0, out.stderr[-2000:]
     d = _last_json(out.stdout)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -33,6 +34,19 @@ def test_bench_single_gpu_line():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "hnsw" in cb
     assert 0.0 <= cb["hnsw"]["top2_distance_recall_vs_exact"] <= 1.0
+    # the further workloads of the same process (the driver's default run carries s2, s3, s4, pao1 and cfd)
+    ex = d["extra"]["workloads"]
+    assert set(ex) == {"s2", "pao1", "cfd"}, ex.keys()
+    for name in ("s2", "pao1"):
+        w = ex[name]
+        assert "error" not in w, w
+        for key in ("ms_per_step", "kernel", "kernel_ms_avg", "issued_frac", "useful_frac", "traffic", "pairs_evaluated",
+                    "candidates_rescanned", "k1p_levels", "roofline", "value", "value_evaluated"):
+            assert key in w, (name, key)
+        assert w["steps"] == 3 and w["ms_per_step"] > 0 and 0.0 < w["useful_frac"] <= 1.0
+        assert w["roofline"]["counters"] in (None, "stale") or isinstance(w["roofline"]["counters"], dict)
+    assert ex["pao1"]["data"] == "real genome" and ex["pao1"]["kernel"] == "k_hamming_scan_pg"
+    assert ex["cfd"]["roofline"]["bound"] == "hbm" and 0.0 < ex["cfd"]["roofline"]["frac"] <= 1.0
 
 
 @pytest.mark.parametrize("scaling", ["weak", "strong"])
@@ -48,4 +62,11 @@ def test_bench_two_rank_rehearsal(scaling):
     assert out.returncode == 0, out.stderr[-3000:]      # EVERY rank must pass its checks
     d = _last_json(out.stdout)
     assert d["n_gpus"] == 2 and d["rccl_world"] == 2 and d["scaling"] == scaling and d["collective_backend"] == "gloo"
-    assert d["value"] > 0 and "cpu_baseline" not in d
+    assert d["value"] > 0 and "cpu_baseline" not in d and "extra" not in d
+    # every rank's own figures travel with the line (a scaling curve has to be attributable), and every rank has checked
+    # the gathered table against its own scan of every shard before the timed region
+    pr = d["per_rank"]
+    assert [p["rank"] for p in pr] == [0, 1]
+    for p in pr:
+        assert p["kernel_ms_avg"] > 0 and p["gather_ms_sync"] > 0 and p["ms_per_step"] > 0
+    assert d["gather_bytes_per_rank"] == d["config"]["n_candidates_per_gpu"] * d["config"]["k"] * 4

@@ -86,6 +86,10 @@ def main():
     ap.add_argument("--register", help="workload key: record the dominant kernel's counters in --counters-json, where "
                                        "bench.py looks them up for its roofline block")
     ap.add_argument("--kernel", help="substring of the dominant kernel's short name (for --register)")
+    ap.add_argument("--bench-line", help="file whose last JSON line is the bench.py line of the profiled command "
+                                         "(tools/profile.sh: gpurun_out/TAG/stats.log): the launch shape it reports "
+                                         "(pairs evaluated, positions per block) is registered with the counters, and "
+                                         "bench.py uses the counters only for a live launch of the same shape")
     a = ap.parse_args()
     table = collect(a.root, a.dispatch_min_ns)
     table = {k: v for k, v in table.items() if v["mean_ns_in_pmc_passes"] >= a.min_ns}
@@ -122,7 +126,22 @@ def main():
                                 "(tools/profile.sh + tools/pmc_summary.py --register).  FETCH_SIZE / WRITE_SIZE in KiB; "
                                 "hbm_side_bytes_per_launch = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction, "
                                 "MI355X_MICROARCH.md HBM section; includes Infinity-Cache hits).")
-            data[a.register] = {"kernel": " + ".join(hits), "source": a.out,
+            shape = {}
+            if a.bench_line and os.path.exists(a.bench_line):
+                with open(a.bench_line) as fh:
+                    lines = [ln for ln in fh.read().splitlines() if ln.startswith("{")]
+                if lines:
+                    line = json.loads(lines[-1])
+                    roof = line.get("roofline", {})
+                    if a.register in line.get("extra", {}).get("workloads", {}):
+                        roof = line["extra"]["workloads"][a.register].get("roofline", {})
+                    if "pairs_evaluated" in roof:
+                        shape["pairs_evaluated"] = roof["pairs_evaluated"]
+                        shape["block_positions"] = [int(b["positions"]) for b in roof.get("blocks", [])]
+                        shape["k1p_levels"] = line.get("k1p_levels")
+                    if a.register == "cfd":
+                        shape["pairs"] = line.get("pairs")
+            data[a.register] = {"kernel": " + ".join(hits), "source": a.out, **shape,
                                 "resources": {k: table[k]["resources"] for k in hits},
                                 "mean_ns_in_pmc_passes": sum(table[k]["mean_ns_in_pmc_passes"] for k in hits),
                                 "hbm_side_bytes_per_launch": total, "counters": dict(counters)}
