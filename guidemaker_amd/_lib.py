@@ -118,6 +118,9 @@ def lib():
     L.gm_pigeon_plan_dist.argtypes = [i64, i64, i32, i32, c.c_double, c.POINTER(c.c_double), i32, c.POINTER(i32),
                                       c.POINTER(i32), c.POINTER(c.c_double), c.POINTER(i32)]
     L.gm_pigeon_plan_dist.restype = i32
+    L.gm_pigeon_plan_sample.argtypes = [i64, i64, i32, i32, c.c_double, c.POINTER(c.c_uint32), i32, i32, c.POINTER(i32),
+                                        c.POINTER(i32), c.POINTER(c.c_double), c.POINTER(i32)]
+    L.gm_pigeon_plan_sample.restype = i32
     L.gm_pigeon_cascade_info.argtypes = [vp, i32, c.POINTER(i64), c.POINTER(i32), c.POINTER(i64), c.POINTER(i64)]
     L.gm_pigeon_cascade_info.restype = i32
     L.gm_set_variant.argtypes = [vp, i32]
@@ -170,7 +173,7 @@ EXPORTS = [
     "gm_cfd_batch_dev", "gm_last_kernel_ms", "gm_last_query_ms", "gm_last_kernel_name", "gm_last_kernel_pairs",
     "gm_set_variant", "gm_timing_reserve", "gm_timing_read", "gm_pam_count", "gm_pam_emit", "gm_pam_free",
     "gm_pack_keys_dev", "gm_unpack_keys_dev", "gm_site_flags", "gm_seed_duplicated",
-    "gm_last_kernel_evaluated", "gm_last_incomplete", "gm_pigeon_blocks", "gm_pigeon_plan", "gm_pigeon_plan_dist", "gm_pigeon_cascade_info", "gm_pigeon_block_info", "gm_set_param",
+    "gm_last_kernel_evaluated", "gm_last_incomplete", "gm_pigeon_blocks", "gm_pigeon_plan", "gm_pigeon_plan_dist", "gm_pigeon_plan_sample", "gm_pigeon_cascade_info", "gm_pigeon_block_info", "gm_set_param",
     "gm_multi_create", "gm_multi_knn_query", "gm_multi_devices", "gm_multi_has_comm", "gm_multi_index", "gm_multi_free",
 ]
 
@@ -471,6 +474,22 @@ def pigeon_plan_dist(n_db, n_q, guidelen, k, p_short, p_match=0.25, levels=3):
     B = int(lib().gm_pigeon_plan_dist(int(n_db), int(n_q), int(guidelen), int(k), float(p_match),
                                       ps.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), int(levels), blen, trad,
                                       ctypes.byref(cost), ctypes.byref(casc)))
+    return dict(blocks=[(int(blen[b]), int(trad[b])) for b in range(B)], cost=float(cost.value), cascade=int(casc.value))
+
+
+def pigeon_plan_sample(n_db, n_q, guidelen, k, cum, p_match=0.25, levels=3):
+    """The planner on a sample of the library's own kind: cum[i, d] = pool targets within Hamming distance d = 0 .. 8 of
+    sampled candidate i.  -> dict(blocks=[(len, radius), ...], cost, cascade).  Host arithmetic, no GPU needed."""
+    import numpy as _np
+    cm = _np.ascontiguousarray(cum, dtype=_np.uint32)
+    if cm.ndim != 2 or cm.shape[1] != 9:
+        raise ValueError("cum must be [rows, 9]")
+    blen = (ctypes.c_int32 * 8)()
+    trad = (ctypes.c_int32 * 8)()
+    cost, casc = ctypes.c_double(0.0), ctypes.c_int32(0)
+    B = int(lib().gm_pigeon_plan_sample(int(n_db), int(n_q), int(guidelen), int(k), float(p_match),
+                                        cm.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), int(cm.shape[0]), int(levels),
+                                        blen, trad, ctypes.byref(cost), ctypes.byref(casc)))
     return dict(blocks=[(int(blen[b]), int(trad[b])) for b in range(B)], cost=float(cost.value), cascade=int(casc.value))
 
 

@@ -249,7 +249,9 @@ class PamTarget:
         if packed_parts:
             # side-car for TargetProcessor: the 2-bit packed form of the 'target' column (the boundary format of
             # include/gmhip.h), so that the filters, create_index and get_neighbors do not re-encode the strings
-            df_targets.attrs["gm_packed"] = np.concatenate(packed_parts)
+            # (the array itself lives in this module's side-car cache; the frame carries a string token -- arrays in
+            # `attrs` break pd.concat / pd.merge, which compare attrs dicts with ==, and are deep-copied per operation)
+            df_targets.attrs["gm_packed_token"] = _packed_side_car_put(np.concatenate(packed_parts))
             df_targets.attrs["gm_guidelen"] = int(target_len)
         return df_targets
 
@@ -369,8 +371,8 @@ class TargetProcessor:
 
     def _packed_targets(self):
         """(packed uint64 [len(targets)], guide length) of the frame's 'target' column, encoded ONCE per frame: taken
-        from the side-car find_targets attaches (frame.attrs['gm_packed'], checked against the strings on a few
-        rows), else packed here; cached until the column object or its length changes.  None when the targets have no
+        from the side-car find_targets keeps for the frame (token in frame.attrs, packed_side_car(); checked against the
+        strings on up to 256 probe rows), else packed here; cached until the column object or its length changes.  None when the targets have no
         common length <= 27 or contain non-ACGT letters."""
         t = self.targets['target']
         n = len(t)
@@ -380,10 +382,11 @@ class TargetProcessor:
         out = None
         if n:
             L = len(t.iat[0])
-            side = self.targets.attrs.get("gm_packed")
+            side = packed_side_car(self.targets)
             if (side is not None and self.targets.attrs.get("gm_guidelen") == L and len(side) == n
                     and 1 <= L <= _lib.MAX_GUIDELEN):
-                probe = sorted({0, n // 3, n // 2, n - 1})
+                # probe rows: the ends and up to 256 evenly spaced rows (a full check would cost as much as packing)
+                probe = sorted(set(np.linspace(0, n - 1, num=min(n, 256), dtype=np.int64).tolist()) | {0, n // 3, n // 2, n - 1})
                 try:
                     if (_lib.pack([t.iat[i] for i in probe], L) == side[probe]).all():
                         out = (np.ascontiguousarray(side, dtype=np.uint64), L)
@@ -738,11 +741,48 @@ def neighbor_table(targetprocessor_object) -> pd.DataFrame:
     pk = getattr(nb, "packed_pairs", None)
     if pk is not None:
         # side-car for cfd_score: the packed guides and their packed similar guides (n x k), so that the strings just
-        # built are not parsed and re-encoded (checked against the strings on a few rows before use)
+        # built are not parsed and re-encoded.  The arrays stay in a private cache of this module; the frame carries a
+        # small string token only (pandas compares and deep-copies `attrs` on concat / merge / every frame operation:
+        # arrays in there break `pd.concat` and cost a copy per operation), and cfd_score uses the side-car only when a
+        # hash over EVERY row of both columns still matches.
         side = pk(keys)
         if side is not None:
-            frame.attrs["gm_cfd_packed"] = side
+            frame.attrs["gm_cfd_token"] = _side_car_put(side, keys, sim)
     return frame
+
+
+def _packed_side_car_put(packed) -> str:
+    token = "gm-packed-%d-%x" % (len(_PACKED_SIDE_CARS), id(packed))
+    while len(_PACKED_SIDE_CARS) >= _SIDE_CAR_LIMIT:
+        _PACKED_SIDE_CARS.pop(next(iter(_PACKED_SIDE_CARS)))
+    _PACKED_SIDE_CARS[token] = packed
+    return token
+
+
+def packed_side_car(frame):
+    """The 2-bit packed 'target' column find_targets kept for this frame (uint64 [len(frame)]), or None: the frame was
+    not made by find_targets, or its side-car has been dropped from the cache (the last few frames are kept)."""
+    token = frame.attrs.get("gm_packed_token") if hasattr(frame, "attrs") else None
+    return _PACKED_SIDE_CARS.get(token) if isinstance(token, str) else None
+
+
+_PACKED_SIDE_CARS = {}   # token -> packed 'target' column of a find_targets frame
+_SIDE_CARS = {}          # token -> (packed guides, packed similar guides, L, hash of the guide column, of the similar-guides column)
+_SIDE_CAR_LIMIT = 4      # frames whose side-car is kept (oldest dropped first)
+
+
+def _column_hash(col) -> int:
+    """Hash over every row of a string column (row boundaries included): one C-level join + one hash."""
+    return hash("\n".join(col))
+
+
+def _side_car_put(side, guides, sim_col) -> str:
+    gpk, spk, L = side
+    token = "gm-cfd-%d-%x" % (len(_SIDE_CARS), id(gpk))
+    while len(_SIDE_CARS) >= _SIDE_CAR_LIMIT:
+        _SIDE_CARS.pop(next(iter(_SIDE_CARS)))
+    _SIDE_CARS[token] = (gpk, spk, L, _column_hash(guides), _column_hash(sim_col))
+    return token
 
 
 # ------------------------------------------------------------------------------------------------
@@ -814,23 +854,22 @@ def _split_similar(sim_col: List[str], L: int):
 
 
 def _cfd_side_car(df, guides, sim_col):
-    """The packed (guides, similar guides, L) that neighbor_table attached to the frame -- used only if it still
-    describes the frame: same number of rows and, on a few probe rows, the same sequences as the strings."""
-    side = df.attrs.get("gm_cfd_packed") if hasattr(df, "attrs") else None
+    """The packed (guides, similar guides, L) neighbor_table kept for this frame (token in df.attrs) -- used only if it
+    still describes the frame: same number of rows and the same hash over EVERY row of 'Guide sequence' and of
+    'Similar guides' as when it was made (a frame that was filtered, sorted, edited or concatenated since falls back to
+    the strings)."""
+    token = df.attrs.get("gm_cfd_token") if hasattr(df, "attrs") else None
+    side = _SIDE_CARS.get(token) if isinstance(token, str) else None
     if side is None:
         return None
-    gpk, spk, L = side
+    gpk, spk, L, h_guides, h_sim = side
     n = len(guides)
     if n == 0 or gpk.shape[0] != n or spk.shape[0] != n:
         return None
     try:
-        for i in sorted({0, n // 3, n // 2, n - 1}):
-            if len(guides[i]) != L or _pack_rna([guides[i]], L)[0] != gpk[i]:
-                return None
-            parts = sim_col[i].split(';')
-            if len(parts) != spk.shape[1] or any(len(x) != L for x in parts) or not (_pack_rna(parts, L) == spk[i]).all():
-                return None
-    except ValueError:
+        if _column_hash(guides) != h_guides or _column_hash(sim_col) != h_sim:
+            return None
+    except TypeError:      # (a non-string cell)
         return None
     return gpk, spk, L
 

@@ -18,6 +18,14 @@ struct gm_pigeon;   // K1P state (gm_pigeon.hip)
 // layout of its own (fewer, larger buckets: the set is a fraction of the candidates), and only what the last pass
 // leaves goes to the plain scan.  Every level owns its pool copies, workspaces and plan.
 constexpr int GM_PG_LEVELS = 3;
+// The planner's sample (gm_pg_sample_hist): per sampled candidate the number of pool targets within d = 0 .. 8.
+constexpr int GM_PG_SAMPLE_BINS = 9;
+struct gm_pg_sample {
+    int n = 0;                         // rows
+    const uint32_t* cum = nullptr;     // [n][GM_PG_SAMPLE_BINS] targets within d (cumulative)
+    int k = 0;                         // neighbours asked for: a row's k-th neighbour lies at the first d with cum >= k
+    int min_kth = -1;                  // only the rows whose k-th neighbour lies BEYOND this distance (a deeper cascade level)
+};
 struct gm_pg_level_state {
     gm_pigeon* pg = nullptr;
     int64_t plan_nq = -1;
@@ -75,6 +83,8 @@ struct gm_index {
     int plan_cascade = 0;         // the plan sends the rows it leaves short to a deeper K1P level
     double plan_cost = 1.0;       // the planner's cost of the plan (pool scans per candidate, re-scans included)
     std::vector<double> plan_p_short;      // measured share of the candidates whose k-th neighbour lies beyond r (empty: no sample)
+    std::vector<uint32_t> plan_cum;        // level 0's sample: targets within d = 0 .. 8 of every sampled candidate (gm_pg_sample)
+    int plan_cum_k = 0;
     gm_pg_level_state pg_deeper[GM_PG_LEVELS - 1];      // the state of levels 1 .. (swapped in while such a level runs)
     int pg_level = 0;             // cascade level whose state is in pg / plan_* right now
     int pg_cascade = 1;           // gm_set_param "pg_cascade": 0 = never, 1 = when the planner says so, 2 = whenever rows are left
@@ -140,7 +150,8 @@ GM_FOR_EACH_LEN(GM_DECL_PG)
 // gm_pg_incomplete: how many such rows (synchronises the stream); gm_pg_gather / gm_pg_scatter: move those rows
 // to / from a compact query.
 int gm_pg_plan(int64_t n_db, int64_t n_q, int L, int k, double p_match, gm_pg_layout* out, const double* p_short = nullptr,
-               int deeper_levels = 0, double* cost_out = nullptr, int* cascade_out = nullptr);
+               int deeper_levels = 0, double* cost_out = nullptr, int* cascade_out = nullptr, const gm_pg_sample* smp = nullptr);
+int gm_pg_sample_hist(gm_index* idx, int64_t n, hipStream_t st, std::vector<uint32_t>* cum);
 void gm_pg_inherit(gm_index* idx, const gm_pigeon* parent);      // a deeper level takes over the pool's composition + the knobs
 const gm_pigeon* gm_pg_state(const gm_index* idx);
 int gm_pg_sample_rows(gm_index* idx, int64_t n, int64_t stride, hipStream_t st);

@@ -55,6 +55,7 @@ struct PgCounters {               // device-resident
     unsigned long long pairs;     // pairs the last K1P launch evaluates (chunks x 64 x scanned groups x 64)
     unsigned long long bpairs[GM_PG_MAXB];      // ... per block
     int n_bad;                    // re-scanned rows that did not fill under the guessed bound
+    int n_bad_pub;                // ... as of the last k_publish (which re-zeroes n_bad): what a plain copy of the counters reads
     int n_over;                   // incomplete rows whose hit lists overflowed (nothing about them is known)
     int chist[24];                // the other incomplete rows by the number c < k of neighbours they have within r
 };
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(64) void k_publish(PgCounters* __restrict__ src, Pg
     if (threadIdx.x == 0) {
         __threadfence_system();
         box->seq = seq;
+        src->n_bad_pub = src->n_bad;
         src->n_bad = 0;      // (read: the next count starts from zero without a memset of its own)
     }
 }
@@ -463,6 +465,33 @@ __global__ __launch_bounds__(256) void k_collect_bad(const int32_t* __restrict__
 }
 
 
+// Planner sample: hist[s][d] = pool targets at Hamming distance d <= PG_SAMPLE_DMAX of sample row s (lane = target, the
+// sample rows broadcast from LDS, counters in LDS, one flush of the non-zero counters per workgroup).  2 048 rows x
+// 1.2 M targets = 2.4 10^9 popcount evaluations, ~0.4 ms once per plan: it gives the planner, per sample row, the
+// distance of its k-th neighbour AND the number of hits a layout of radius r would have to store for it.
+constexpr int PG_SAMPLE_DMAX = 8;
+constexpr int PG_SAMPLE_BINS = PG_SAMPLE_DMAX + 1;
+__global__ __launch_bounds__(1024) void k_sample_hist(const uint2* __restrict__ planes, int64_t n, const uint2* __restrict__ qs,
+                                                      int n_s, uint32_t* __restrict__ hist) {
+    extern __shared__ uint32_t s_mem[];      // [n_s * 2] sample planes, then [n_s * BINS] counters
+    uint2* s_q = reinterpret_cast<uint2*>(s_mem);
+    uint32_t* s_h = s_mem + 2 * n_s;
+    for (int i = threadIdx.x; i < n_s; i += blockDim.x) s_q[i] = qs[i];
+    for (int i = threadIdx.x; i < n_s * PG_SAMPLE_BINS; i += blockDim.x) s_h[i] = 0u;
+    __syncthreads();
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        const uint2 e = planes[t];
+        for (int sIdx = 0; sIdx < n_s; ++sIdx) {
+            const uint2 c = s_q[sIdx];      // (wave-uniform address: a broadcast read)
+            const int d = __popc((c.x ^ e.x) | (c.y ^ e.y));
+            if (d <= PG_SAMPLE_DMAX) atomicAdd(&s_h[sIdx * PG_SAMPLE_BINS + d], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_s * PG_SAMPLE_BINS; i += blockDim.x)
+        if (s_h[i] != 0u) atomicAdd(&hist[i], s_h[i]);
+}
+
 // id cut-off: per bucket of a pool copy, the number of its 64-target groups that hold a target with id < cut_id (ids
 // ascend inside a bucket: binary search for the first id >= cut_id)
 __global__ __launch_bounds__(256) void k_bucket_cut(const uint4* __restrict__ recs, const int2* __restrict__ bdesc, int nb,
@@ -538,8 +567,28 @@ inline dim3 grid_for(int64_t n, int block = 256) { return dim3((unsigned)((n + b
 
 }  // namespace
 
+// the pool side of one layout (everything gm_pg_prepare builds; it depends on the block lengths only), kept aside while
+// another layout is in use: get_control_seqs queries the same index with 10 n, 100 n, 1000 n ... candidates and
+// get_neighbors with yet another count -- each may plan other block lengths, and rebuilding the copies (radix sorts +
+// host round trips) per call would cost more than the queries
+struct PgPoolSide {
+    int B = 0;
+    int blen[GM_PG_MAXB]{}, bstart[GM_PG_MAXB]{}, ebase[GM_PG_MAXB + 1]{}, skiplen[GM_PG_MAXB]{}, Lp[GM_PG_MAXB]{}, max_bucket[GM_PG_MAXB]{};
+    uint32_t* table[GM_PG_MAXB]{};
+    uint4* recs[GM_PG_MAXB]{};
+    int2* bdesc[GM_PG_MAXB]{};
+    int32_t* coff[GM_PG_MAXB]{};
+    int* bcut[GM_PG_MAXB]{};
+    uint32_t bcut_for = 0xffffffffu;
+    int gap_mode = 0;
+    uint64_t stamp = 0;      // last use (the least recently used side is dropped)
+};
+constexpr int PG_POOL_SIDES = 3;      // layouts whose pool copies are kept per K1P level (the one in use included)
+
 struct gm_pigeon {
     int B = 0;
+    std::vector<PgPoolSide> stash;     // pool sides of other layouts
+    uint64_t use_stamp = 0;
     double p_match = 0.0;              // P(two pool sequences carry the same base at a position); 0 = not measured
     int max_bucket[GM_PG_MAXB]{};      // largest bucket of every pool copy
     int trad[GM_PG_MAXB]{};            // search radius of every block (gm_pg_layout): the layout serves
@@ -564,6 +613,8 @@ struct gm_pigeon {
     double base_freq[4] = {0.25, 0.25, 0.25, 0.25};      // base composition of the pool (gm_pg_pool_stats)
     uint8_t* cflag = nullptr;          // per candidate: takes the id cut-off
     int64_t cflag_cap = 0;
+    uint32_t* shist = nullptr;         // planner sample: distance histogram per sample row
+    int64_t shist_cap = 0;
     double cut_f = 1.0;                // fraction of the ids whose distance-r targets are taken (1.0 = no cut-off)
     uint32_t cut_id = 0xffffffffu;     // ... as an id
     int* bcut[GM_PG_MAXB]{};           // per copy: groups per bucket that hold an id below the cut-off
@@ -657,6 +708,88 @@ void free_pool_side(gm_pigeon* pg) {
     pg->bcut_for = 0xffffffffu;
 }
 
+void free_side(PgPoolSide& ps) {
+    for (int b = 0; b < GM_PG_MAXB; ++b) {
+        if (ps.table[b]) (void)hipFree(ps.table[b]);
+        if (ps.recs[b]) (void)hipFree(ps.recs[b]);
+        if (ps.bdesc[b]) (void)hipFree(ps.bdesc[b]);
+        if (ps.coff[b]) (void)hipFree(ps.coff[b]);
+        if (ps.bcut[b]) (void)hipFree(ps.bcut[b]);
+    }
+    ps = PgPoolSide();
+}
+
+// the layout in use -> the stash (its device arrays change owner; pg is left without a pool side)
+void stash_pool_side(gm_pigeon* pg) {
+    if (pg->B < 2) {
+        free_pool_side(pg);
+        return;
+    }
+    PgPoolSide ps;
+    ps.B = pg->B;
+    ps.bcut_for = pg->bcut_for;
+    ps.gap_mode = pg->tune_gap;
+    ps.stamp = pg->use_stamp;
+    for (int b = 0; b < GM_PG_MAXB; ++b) {
+        ps.blen[b] = pg->blen[b];
+        ps.bstart[b] = pg->bstart[b];
+        ps.skiplen[b] = pg->skiplen[b];
+        ps.Lp[b] = pg->Lp[b];
+        ps.max_bucket[b] = pg->max_bucket[b];
+        ps.table[b] = pg->table[b];
+        ps.recs[b] = pg->recs[b];
+        ps.bdesc[b] = pg->bdesc[b];
+        ps.coff[b] = pg->coff[b];
+        ps.bcut[b] = pg->bcut[b];
+        pg->table[b] = nullptr;
+        pg->recs[b] = nullptr;
+        pg->bdesc[b] = nullptr;
+        pg->coff[b] = nullptr;
+        pg->bcut[b] = nullptr;
+    }
+    for (int b = 0; b <= GM_PG_MAXB; ++b) ps.ebase[b] = pg->ebase[b];
+    pg->B = 0;
+    pg->cap_nq = -1;
+    pg->bcut_for = 0xffffffffu;
+    while ((int)pg->stash.size() >= PG_POOL_SIDES - 1) {      // drop the least recently used
+        size_t old = 0;
+        for (size_t i = 1; i < pg->stash.size(); ++i)
+            if (pg->stash[i].stamp < pg->stash[old].stamp) old = i;
+        free_side(pg->stash[old]);
+        pg->stash.erase(pg->stash.begin() + (long)old);
+    }
+    pg->stash.push_back(ps);
+}
+
+// a stashed pool side with these block lengths (and table gaps) -> pg; false: none
+bool unstash_pool_side(gm_pigeon* pg, const gm_pg_layout* lay) {
+    for (size_t i = 0; i < pg->stash.size(); ++i) {
+        const PgPoolSide& ps = pg->stash[i];
+        bool same = ps.B == lay->B && ps.gap_mode == pg->tune_gap;
+        for (int b = 0; b < lay->B && same; ++b) same = ps.blen[b] == lay->blen[b];
+        if (!same) continue;
+        pg->B = ps.B;
+        pg->bcut_for = ps.bcut_for;
+        for (int b = 0; b < GM_PG_MAXB; ++b) {
+            pg->blen[b] = ps.blen[b];
+            pg->bstart[b] = ps.bstart[b];
+            pg->skiplen[b] = ps.skiplen[b];
+            pg->Lp[b] = ps.Lp[b];
+            pg->max_bucket[b] = ps.max_bucket[b];
+            pg->table[b] = ps.table[b];
+            pg->recs[b] = ps.recs[b];
+            pg->bdesc[b] = ps.bdesc[b];
+            pg->coff[b] = ps.coff[b];
+            pg->bcut[b] = ps.bcut[b];
+        }
+        for (int b = 0; b <= GM_PG_MAXB; ++b) pg->ebase[b] = ps.ebase[b];
+        pg->cap_nq = -1;
+        pg->stash.erase(pg->stash.begin() + (long)i);
+        return true;
+    }
+    return false;
+}
+
 double log_choose(int n, int r) { return std::lgamma(n + 1.0) - std::lgamma(r + 1.0) - std::lgamma(n - r + 1.0); }
 
 }  // namespace
@@ -743,21 +876,64 @@ int gm_pg_layout_radius(const gm_pg_layout& lay) {
 // the whole pool per row).  When they are many they form a candidate set of their own, n_q x p_short[r] rows whose k-th
 // neighbour lies beyond r with the conditional shares p_short[r'] / p_short[r], and a deeper K1P level with a larger
 // radius (and, the set being small, fewer and larger buckets) serves them at its own planned cost + the fixed price of
-// one more level (grouping, merge, read-back: ~150 us, expressed in pool scans per row).  On a real genome the k-th
+// one more level (grouping, merge, read-back: ~300 us, expressed in pool scans per row).  On a real genome the k-th
 // neighbour's distance spreads over 3 .. 7 (P. aeruginosa PAO1, k = 10: 5 for half the guides, beyond 5 for 12.6 %),
 // and the first level then runs the radius the MAJORITY needs instead of the radius nearly all need.
 // Returns 1 and fills *out when a layout beats the plain scan clearly (cost < 0.45), else 0; *cost_out = its cost,
 // *cascade_out = 1 when the cost assumes that a deeper level takes the short rows.
 constexpr double PG_PAIR_RATE = 2.6e13;          // evaluated pairs per second of the look-up scans (S1 .. S4, profiles/r02)
-constexpr double PG_LEVEL_OVERHEAD_US = 150.0;   // fixed price of one more K1P level
+constexpr double PG_LEVEL_OVERHEAD_US = 300.0;   // fixed price of one more K1P level (small grouping kernels, two read-backs, launch gaps)
 constexpr double PG_CASCADE_MIN_ROWS = 4096.0;   // fewer short rows than this: the plain / prefix re-scan
+// Hits.  Every target within the radius is a hit: queued, its record gathered, its distance recomputed, a key stored.  On
+// P. aeruginosa PAO1 that is 57 % of the first level's scan (time-only ablation, profiles/r03/NOTES.md: 1.89 ms with, 0.82
+// without hits for 72 hits per candidate at r = 5), i.e. a hit costs about as much as 300 .. 450 pair evaluations, and
+// the hits per candidate grow 4 .. 5 x per unit of radius.  With a sample (gm_pg_sample: targets within d of every
+// sampled candidate) the planner prices them: + hits(r) x PG_HIT_PAIRS / n_db pool scans per candidate.
+constexpr double PG_HIT_PAIRS = 300.0;
+constexpr double PG_PLAIN_TAIL = 1.5;
+// Every level also pays per CANDIDATE, whatever its layout: the counting sort of the candidates by block value, the chunk
+// table and the merge of the hit lists -- S1: 0.17 of 0.93 ms for 599 093 candidates, PAO1: 0.53 of 3.8 ms for 1.17 M:
+// about 0.45 ns per candidate = 11 700 pair evaluations.  It does not move the choice between layouts of one level, so
+// it is charged where it matters: in the price of a FURTHER cascade level (a first level that leaves 60 % of the rows
+// short buys a second one for 60 % of them).
+constexpr double PG_ROW_PAIRS = 11700.0;
 int gm_pg_plan(int64_t n_db, int64_t n_q, int L, int k, double p_match, gm_pg_layout* out, const double* p_short,
-               int deeper_levels, double* cost_out, int* cascade_out) {
+               int deeper_levels, double* cost_out, int* cascade_out, const gm_pg_sample* smp) {
     if (cost_out) *cost_out = 1.0;
     if (cascade_out) *cascade_out = 0;
     if (L < 12 || L > GM_MAX_GUIDELEN || n_db < 32768 || k < 1 || k > 20) return 0;
     if (!(p_match >= 0.25 && p_match < 0.9)) p_match = 0.25;
     if (n_q < 1) n_q = n_db;
+    // from the sample: the share of the (selected) rows whose k-th neighbour lies beyond r, and their mean hits within r
+    double ps_smp[GM_MAX_GUIDELEN + 2], hits_smp[GM_MAX_GUIDELEN + 2];
+    const double* hits = nullptr;
+    if (smp != nullptr && smp->n > 0 && smp->cum != nullptr) {
+        int64_t rows = 0;
+        double beyond[GM_PG_SAMPLE_BINS + 1] = {0}, hsum[GM_PG_SAMPLE_BINS] = {0};
+        for (int i = 0; i < smp->n; ++i) {
+            const uint32_t* c = smp->cum + (size_t)i * GM_PG_SAMPLE_BINS;
+            int kth = GM_PG_SAMPLE_BINS;      // (beyond the histogram)
+            for (int d = 0; d < GM_PG_SAMPLE_BINS; ++d)
+                if (c[d] >= (uint32_t)smp->k) {
+                    kth = d;
+                    break;
+                }
+            if (kth <= smp->min_kth) continue;
+            ++rows;
+            for (int r = 0; r < kth && r <= GM_PG_SAMPLE_BINS; ++r) beyond[r] += 1.0;
+            for (int d = 0; d < GM_PG_SAMPLE_BINS; ++d) hsum[d] += (double)(c[d] < 4096u ? c[d] : 4096u);
+        }
+        if (rows > 0) {
+            for (int r = 0; r <= L + 1 && r <= GM_MAX_GUIDELEN + 1; ++r) {
+                const int rr = r < GM_PG_SAMPLE_BINS ? r : GM_PG_SAMPLE_BINS;      // (beyond d = 8: the share seen there)
+                ps_smp[r] = (beyond[rr] + 0.5) / ((double)rows + 1.0);
+                hits_smp[r] = r < GM_PG_SAMPLE_BINS ? hsum[r] / (double)rows
+                                                    : hits_smp[r - 1] * 4.0;      // (extrapolated)
+            }
+            p_short = ps_smp;
+            hits = hits_smp;
+        }
+    }
     const double rho = ((1.0 - p_match) / 3.0) / p_match;
     double best = 0.45;      // K1P has to be clearly cheaper than scanning everything
     int found = 0;
@@ -771,8 +947,10 @@ int gm_pg_plan(int64_t n_db, int64_t n_q, int L, int k, double p_match, gm_pg_la
     auto tail = [&](int r, double p_inc) {
         if (r > L) r = L;
         if (tail_of[r] >= 0.0) return tail_of[r];
-        double t = 1.0;
+        // the plain re-scan: the whole pool per row under a guessed bound, once more without it for the rows that still do not
+        // fill, gather / merge / scatter around both -- measured ~1.5 pool scans per row (PAO1: 10 766 rows, 0.6 ms)
         const double n_sub = (double)n_q * p_inc;
+        double t = (p_short != nullptr && n_sub >= 2.0 * PG_CASCADE_MIN_ROWS) ? PG_PLAIN_TAIL : 1.0;      // (a few thousand rows: the prefix re-scan, cheaper)
         if (deeper_levels > 0 && p_short != nullptr && p_inc > 0.0 && n_sub >= PG_CASCADE_MIN_ROWS) {
             double ps2[GM_MAX_GUIDELEN + 2];
             for (int rr = 0; rr <= L; ++rr) {
@@ -781,8 +959,14 @@ int gm_pg_plan(int64_t n_db, int64_t n_q, int L, int k, double p_match, gm_pg_la
             }
             gm_pg_layout sub{};
             double c2 = 1.0;
-            if (gm_pg_plan(n_db, (int64_t)n_sub, L, k, p_match, &sub, ps2, deeper_levels - 1, &c2, nullptr)) {
-                const double fixed = PG_LEVEL_OVERHEAD_US * 1e-6 * PG_PAIR_RATE / ((double)n_db * n_sub);
+            gm_pg_sample sub_smp{};
+            if (hits != nullptr) {      // the deeper level sees the rows whose k-th neighbour lies beyond r
+                sub_smp = *smp;
+                sub_smp.min_kth = r;
+            }
+            if (gm_pg_plan(n_db, (int64_t)n_sub, L, k, p_match, &sub, ps2, deeper_levels - 1, &c2, nullptr,
+                           hits != nullptr ? &sub_smp : nullptr)) {
+                const double fixed = PG_LEVEL_OVERHEAD_US * 1e-6 * PG_PAIR_RATE / ((double)n_db * n_sub) + PG_ROW_PAIRS / (double)n_db;
                 if (c2 + fixed < t) {
                     t = c2 + fixed;
                     tail_casc[r] = 1;
@@ -807,7 +991,8 @@ int gm_pg_plan(int64_t n_db, int64_t n_q, int L, int k, double p_match, gm_pg_la
                 if (mean > 700.0) p_inc = 0.0;
                 if (p_short != nullptr) p_inc = p_short[r < L ? r : L];
                 if (p_inc > 1.0) p_inc = 1.0;
-                const double p_tail = p_inc * tail(r, p_inc);
+                double p_tail = p_inc * tail(r, p_inc);
+                if (hits != nullptr) p_tail += hits[r < L ? r : L] * PG_HIT_PAIRS / (double)n_db;
                 if (p_tail >= best) continue;
                 for (int len2 = n2 ? 4 : 0; len2 <= (n2 ? GM_PG_MAXLEN : 0); ++len2)
                     for (int len1 = (n1 && n0) ? 2 : 0; len1 <= ((n1 && n0) ? GM_PG_MAXLEN : 0); ++len1)
@@ -988,10 +1173,12 @@ void gm_pg_free(gm_index* idx) {
     gm_pigeon* pg = idx->pg;
     if (!pg) return;
     free_pool_side(pg);
+    for (auto& ps : pg->stash) free_side(ps);
+    pg->stash.clear();
     for (int b = 0; b < GM_PG_MAXB; ++b)
         if (pg->cperm[b]) (void)hipFree(pg->cperm[b]);
     void* bufs[] = {pg->k0, pg->k1, pg->r0, pg->r1, pg->sort_tmp, pg->nch, pg->cbase, pg->hist, pg->cursor, pg->chunks, pg->ctr,
-                    pg->lists, pg->hdr, pg->raw_off, pg->inc, pg->inc_b, pg->cflag, pg->q2, pg->ids2, pg->dists2, pg->counts2};
+                    pg->lists, pg->hdr, pg->raw_off, pg->inc, pg->inc_b, pg->cflag, pg->shist, pg->q2, pg->ids2, pg->dists2, pg->counts2};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     if (pg->box) (void)hipHostFree(pg->box);
@@ -1016,8 +1203,13 @@ int gm_pg_prepare(gm_index* idx, const gm_pg_layout* lay, hipStream_t st) {
     bool same = pg->B == B;
     for (int b = 0; b < B && same; ++b) same = pg->blen[b] == lay->blen[b];
     for (int b = 0; b < B; ++b) pg->trad[b] = lay->trad[b];
+    ++pg->use_stamp;
     if (same) return GM_OK;
-    free_pool_side(pg);
+    stash_pool_side(pg);      // (the copies of the layout in use are kept for the next query that plans it again)
+    if (unstash_pool_side(pg, lay)) {
+        for (int b = 0; b < B; ++b) pg->trad[b] = lay->trad[b];
+        return GM_OK;
+    }
     for (int b = 0; b < B; ++b) pg->trad[b] = lay->trad[b];
     const int* blen = lay->blen;
     const int64_t n = idx->n_db;
@@ -1486,20 +1678,25 @@ static int pg_read_counters(gm_pigeon* pg, hipStream_t st) {
     const unsigned seq = ++pg->box_seq;
     hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, pg->ctr, pg->box_dev, seq);
     HIP_TRY(hipGetLastError());
-    const auto t0 = std::chrono::steady_clock::now();
+    // Poll the sequence word.  Whether the mailbox works is decided from the STREAM's progress, not from a wall-clock
+    // limit: a stream that legitimately needs seconds to reach k_publish (a large Levenshtein pass, the caller's own
+    // work queued in front) must not switch the mailbox off.  Only when the stream has drained and the word still has
+    // not arrived does this platform not make the store visible: plain copies from then on.
     for (unsigned spins = 0; pg->box->seq != seq; ++spins) {
 #if defined(__x86_64__) || defined(__i386__)
         __builtin_ia32_pause();
 #endif
-        if ((spins & 0x3ff) == 0x3ff &&
-            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 1.0) {
-            HIP_TRY(hipStreamSynchronize(st));
-            pg->box_off = true;      // (not one second per read-back from here on)
-            if (pg->box->seq != seq) {
-                HIP_TRY(hipMemcpy(&pg->box->c, pg->ctr, sizeof(PgCounters), hipMemcpyDeviceToHost));
-                HIP_TRY(hipMemset(&pg->ctr->n_bad, 0, sizeof(int)));
-                pg->box->seq = seq;
-            }
+        if ((spins & 0x3fff) == 0x3fff) {
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipErrorNotReady) continue;
+            if (q != hipSuccess) return gm_fail(GM_ERR_DEVICE, std::string("K1P read-back: ") + hipGetErrorString(q));
+            // the stream is idle: k_publish has run
+            std::atomic_thread_fence(std::memory_order_acquire);
+            if (pg->box->seq == seq) break;
+            pg->box_off = true;
+            HIP_TRY(hipMemcpy(&pg->box->c, pg->ctr, sizeof(PgCounters), hipMemcpyDeviceToHost));
+            pg->box->c.n_bad = pg->box->c.n_bad_pub;      // (k_publish has re-zeroed n_bad; it kept the value it published)
+            pg->box->seq = seq;
             break;
         }
     }
@@ -1681,6 +1878,31 @@ int gm_pg_sample_rows(gm_index* idx, int64_t n, int64_t stride, hipStream_t st) 
     if ((rc = ensure(&pg->inc, &pg->inc_cap, n, "incomplete rows"))) return rc;
     hipLaunchKernelGGL(k_stride_rows, grid_for(n), dim3(256), 0, st, pg->inc, n, stride);
     HIP_TRY(hipGetLastError());
+    return GM_OK;
+}
+// distance histogram of the n sample rows gathered in pg->q2 (gm_pg_sample_rows + gm_pg_gather) against the whole pool:
+// cum[s * GM_PG_SAMPLE_BINS + d] = targets within d of row s (d = 0 .. 8); synchronises the stream
+int gm_pg_sample_hist(gm_index* idx, int64_t n, hipStream_t st, std::vector<uint32_t>* cum) {
+    static_assert(PG_SAMPLE_BINS == GM_PG_SAMPLE_BINS, "sample bins");
+    gm_pigeon* pg = idx->pg;
+    if (!pg || !pg->q2 || n < 1 || n > 4096) return gm_fail(GM_ERR_ARG, "gm_pg_sample_hist: no sample gathered");
+    int rc;
+    if ((rc = ensure(&pg->shist, &pg->shist_cap, n * PG_SAMPLE_BINS, "sample histogram"))) return rc;
+    HIP_TRY(hipMemsetAsync(pg->shist, 0, sizeof(uint32_t) * (size_t)(n * PG_SAMPLE_BINS), st));
+    const size_t lds = sizeof(uint32_t) * (size_t)(n * (2 + PG_SAMPLE_BINS));
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sample_hist), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_sample_hist, dim3((unsigned)(idx->n_simd / 4)), dim3(1024), lds, st, idx->d_db, idx->n_db, pg->q2, (int)n,
+                       pg->shist);
+    HIP_TRY(hipGetLastError());
+    cum->resize((size_t)(n * PG_SAMPLE_BINS));
+    HIP_TRY(hipMemcpyAsync(cum->data(), pg->shist, sizeof(uint32_t) * cum->size(), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int64_t sI = 0; sI < n; ++sI)
+        for (int d = 1; d < PG_SAMPLE_BINS; ++d) (*cum)[(size_t)(sI * PG_SAMPLE_BINS + d)] += (*cum)[(size_t)(sI * PG_SAMPLE_BINS + d - 1)];
     return GM_OK;
 }
 bool gm_pg_sampling(const gm_index* idx) { return !idx->pg || idx->pg->tune_sample != 0; }

@@ -5,7 +5,10 @@
 #include "gm_lookup.hip.h"   // k_to_onehot only; the scan kernels are instantiated in gm_inst_lk.hip
 #include "gm_leven.hip.h"    // k_to_peq, k_leven_merge; the scan kernels are instantiated in gm_inst_lv.hip
 
+#include <atomic>
 #include <charconv>
+#include <cstdlib>
+#include <utility>
 #include <thread>
 #include <cmath>
 #include <cstdio>
@@ -452,6 +455,9 @@ struct PgLevelScope {
 };
 }  // namespace
 
+static const std::vector<uint32_t>& idx_cum(const gm_index* idx) { return idx->plan_cum; }      // (level 0's sample: not swapped)
+static int idx_cum_k(const gm_index* idx) { return idx->plan_cum_k; }
+
 static int run_pigeon_level(gm_index* idx, int level, bool nearest, int64_t n_q, int k, int32_t* ids, int32_t* dists,
                             int32_t* counts, hipStream_t st, bool* used, bool timed, const double* p_short_in,
                             int parent_radius) {
@@ -497,6 +503,7 @@ static int run_pigeon_level(gm_index* idx, int level, bool nearest, int64_t n_q,
             // spread between candidates or the repeats of a real genome
             std::vector<double> p_short;
             constexpr int64_t SAMPLE = 2048;
+            if (level == 0) idx->plan_cum.clear();      // (a sample belongs to the candidates it was drawn from)
             if (level > 0) {
                 if (p_short_in) p_short.assign(p_short_in, p_short_in + idx->L + 1);      // the parent's shares, conditional
             } else if (n_q >= 16 * SAMPLE && idx->n_db >= 32768 && idx->L >= 12 && gm_pg_sampling(idx)) {      // (gm_pg_plan's own preconditions)
@@ -504,15 +511,18 @@ static int run_pigeon_level(gm_index* idx, int level, bool nearest, int64_t n_q,
                 int32_t *ids_s = nullptr, *dists_s = nullptr, *counts_s = nullptr;
                 if ((rc = gm_pg_sample_rows(idx, SAMPLE, n_q / SAMPLE, st))) return rc;
                 if ((rc = gm_pg_gather(idx, SAMPLE, keff, nearest, &qs, &ids_s, &dists_s, &counts_s, st))) return rc;
-                if ((rc = run_hamming_lookup(idx, nearest, SAMPLE, keff, ids_s, dists_s, counts_s, false, st, qs))) return rc;
-                std::vector<int32_t> hd((size_t)SAMPLE * keff), hc((size_t)SAMPLE, keff);
-                HIP_TRY(hipMemcpyAsync(hd.data(), dists_s, sizeof(int32_t) * hd.size(), hipMemcpyDeviceToHost, st));
-                if (counts_s) HIP_TRY(hipMemcpyAsync(hc.data(), counts_s, sizeof(int32_t) * hc.size(), hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipStreamSynchronize(st));
+                (void)ids_s; (void)dists_s; (void)counts_s; (void)qs;
+                // targets within d = 0 .. 8 of every sample row: the k-th neighbour's distance AND the hits a radius costs
+                if ((rc = gm_pg_sample_hist(idx, SAMPLE, st, &idx->plan_cum))) return rc;
+                idx->plan_cum_k = keff;
                 std::vector<int64_t> beyond((size_t)idx->L + 2, 0);      // rows whose k-th neighbour lies beyond r
                 for (int64_t j = 0; j < SAMPLE; ++j) {
-                    int kth = hc[(size_t)j] >= keff ? hd[(size_t)j * keff + keff - 1] : idx->L + 1;
-                    if (kth < 0 || kth > idx->L + 1) kth = idx->L + 1;
+                    int kth = idx->L + 1;
+                    for (int d = 0; d < GM_PG_SAMPLE_BINS; ++d)
+                        if (idx->plan_cum[(size_t)(j * GM_PG_SAMPLE_BINS + d)] >= (uint32_t)keff) {
+                            kth = d;
+                            break;
+                        }
                     for (int r = 0; r < kth && r <= idx->L; ++r) ++beyond[(size_t)r];
                 }
                 p_short.resize((size_t)idx->L + 1);
@@ -522,12 +532,44 @@ static int run_pigeon_level(gm_index* idx, int level, bool nearest, int64_t n_q,
                 fprintf(stderr, "[gm] level %d planner (%lld rows): share with the k-th neighbour beyond r =", level, (long long)n_q);
                 for (int r = 2; r <= 9 && r <= idx->L; ++r) fprintf(stderr, " %d:%.4f", r, p_short[(size_t)r]);
                 fprintf(stderr, "\n");
+                if (!idx->plan_cum.empty()) {
+                    const int n_s = (int)(idx->plan_cum.size() / GM_PG_SAMPLE_BINS);
+                    fprintf(stderr, "[gm] level %d sample: mean targets within d (rows beyond the parent's radius %d) =", level, parent_radius);
+                    for (int d = 2; d < GM_PG_SAMPLE_BINS; ++d) {
+                        double sum = 0.0;
+                        int rows = 0;
+                        for (int j = 0; j < n_s; ++j) {
+                            const uint32_t* c = idx->plan_cum.data() + (size_t)j * GM_PG_SAMPLE_BINS;
+                            int kth = GM_PG_SAMPLE_BINS;
+                            for (int dd = 0; dd < GM_PG_SAMPLE_BINS; ++dd)
+                                if (c[dd] >= (uint32_t)keff) {
+                                    kth = dd;
+                                    break;
+                                }
+                            if (level > 0 && kth <= parent_radius) continue;
+                            sum += c[d];
+                            ++rows;
+                        }
+                        fprintf(stderr, " %d:%.1f", d, rows ? sum / rows : 0.0);
+                    }
+                    fprintf(stderr, "\n");
+                }
             }
             const int deeper = idx->pg_cascade != 0 ? GM_PG_LEVELS - 1 - level : 0;
             double cost = 1.0;
             idx->plan_cascade = 0;
+            // (the histogram sample belongs to level 0; a deeper level plans on its rows beyond the parent's radius)
+            gm_pg_sample smp{};
+            const bool have_smp = !idx_cum(idx).empty() && idx_cum_k(idx) == keff && !p_short.empty();
+            if (have_smp) {
+                smp.n = (int)(idx_cum(idx).size() / GM_PG_SAMPLE_BINS);
+                smp.cum = idx_cum(idx).data();
+                smp.k = keff;
+                smp.min_kth = level > 0 ? parent_radius : -1;
+            }
             idx->plan_found = gm_pg_plan(idx->n_db, n_q, idx->L, keff, p_match, &idx->plan_lay,
-                                         p_short.empty() ? nullptr : p_short.data(), deeper, &cost, &idx->plan_cascade);
+                                         p_short.empty() ? nullptr : p_short.data(), deeper, &cost, &idx->plan_cascade,
+                                         have_smp ? &smp : nullptr);
             double expect = 0.0;
             if (idx->plan_found && !p_short.empty()) {
                 const int r = gm_pg_layout_radius(idx->plan_lay);
@@ -539,6 +581,7 @@ static int run_pigeon_level(gm_index* idx, int level, bool nearest, int64_t n_q,
                 fprintf(stderr, " cost %.4f, expects %.4f short%s\n", cost, expect, idx->plan_cascade ? " -> deeper level" : "");
             }
             gm_pg_expect_short(idx, expect);
+            idx->pg_flooded_k1 = 0;      // (what a previous candidate set did to the hit lists says nothing about this one)
             idx->plan_cost = cost;
             idx->plan_p_short = p_short;
             idx->plan_nq = n_q;
@@ -549,8 +592,8 @@ static int run_pigeon_level(gm_index* idx, int level, bool nearest, int64_t n_q,
         if (level > 0 && idx->pg_cascade == 1) {
             // a level of its own has a fixed price (grouping, merge, read-back: ~150 us): for a few thousand rows the
             // prefix / plain re-scan of the parent is the cheaper way (S1: 5 414 rows, 0.10 ms against 0.19)
-            const double fixed = 150e-6 * 2.6e13 / ((double)idx->n_db * (double)n_q);
-            if (idx->plan_cost + fixed >= 0.5) return GM_OK;
+            const double fixed = 300e-6 * 2.6e13 / ((double)idx->n_db * (double)n_q) + 11700.0 / (double)idx->n_db;
+            if (idx->plan_cost + fixed >= 1.0) return GM_OK;
         }
         lay = idx->plan_lay;
         planned = true;
@@ -779,7 +822,7 @@ int gm_unpack(const uint64_t* packed, int64_t n, int guidelen, char* out) {
 static int64_t format_doubles_serial(const double* v, int64_t n, char* out, int64_t cap) {
     int64_t w = 0;
     for (int64_t i = 0; i < n; ++i) {
-        if (w + 26 > cap) return -1;
+        if (w + (i ? 25 : 24) > cap) return -1;      // (a value takes at most 24 characters, + the separator before it)
         if (i) out[w++] = '\n';
         const double x = v[i];
         if (x != x) {
@@ -863,7 +906,7 @@ static int64_t format_doubles_serial(const double* v, int64_t n, char* out, int6
 int64_t gm_format_doubles(const double* v, int64_t n, char* out, int64_t cap) {
     if (!v || !out || n < 0) return -1;
     if (n == 0) return 0;
-    if (cap < 26) return -1;
+    if (cap < 24) return -1;
     // slices on the host's threads, each into its own 25-byte-per-value region of `out`, then closed up in order
     unsigned hw = std::thread::hardware_concurrency();
     int64_t n_thr = hw ? (int64_t)hw : 4;
@@ -895,7 +938,7 @@ int64_t gm_format_doubles(const double* v, int64_t n, char* out, int64_t cap) {
 // (n * k * (guidelen + 1) and n * k * 12 bytes always suffice).
 static void format_rows_serial(const uint64_t* db, int64_t n_db, int L, const int32_t* ids, const int32_t* dists,
                                const int32_t* counts, int64_t n, int k, char* os, char* od, int64_t* ls, int64_t* ld,
-                               int* bad) {
+                               std::atomic<int>* bad) {
     // four bases per table look-up: byte of the packed word -> 4 characters
     static const struct Lut {
         uint32_t w[256];
@@ -921,7 +964,7 @@ static void format_rows_serial(const uint64_t* db, int64_t n_db, int L, const in
             }
             const int32_t id = ids[r * k + j];
             if (id < 0 || id >= n_db) {
-                *bad = 1;
+                bad->store(1, std::memory_order_relaxed);      // (several slices may report it)
                 continue;
             }
             uint64_t w = db[id];
@@ -964,7 +1007,7 @@ int gm_format_neighbor_rows(const uint64_t* db_packed, int64_t n_db, int guidele
     if (n == 0) return GM_OK;
     const int64_t ss = (int64_t)k * (guidelen + 1), sd = (int64_t)k * 12;      // bytes per row at most (incl. the separator)
     if (cap_seqs < n * ss || cap_dists < n * sd) return fail(GM_ERR_ARG, "gm_format_neighbor_rows: buffer too small");
-    int bad = 0;
+    std::atomic<int> bad{0};
     unsigned hw = std::thread::hardware_concurrency();
     int64_t n_thr = hw ? (int64_t)hw : 4;
     if (n_thr > 32) n_thr = 32;
@@ -972,7 +1015,7 @@ int gm_format_neighbor_rows(const uint64_t* db_packed, int64_t n_db, int guidele
     const int64_t per = (n + n_thr - 1) / n_thr;
     std::vector<int64_t> ls((size_t)n_thr, 0), ld((size_t)n_thr, 0);
     std::vector<std::thread> pool;
-    int* bad_p = &bad;
+    std::atomic<int>* bad_p = &bad;
     for (int64_t t = 0; t < n_thr; ++t) {
         const int64_t lo = t * per, hi = lo + per < n ? lo + per : n;
         if (lo >= hi) break;
@@ -982,7 +1025,7 @@ int gm_format_neighbor_rows(const uint64_t* db_packed, int64_t n_db, int guidele
         });
     }
     for (auto& th : pool) th.join();
-    if (bad) return fail(GM_ERR_ARG, "gm_format_neighbor_rows: id out of range");
+    if (bad.load()) return fail(GM_ERR_ARG, "gm_format_neighbor_rows: id out of range");
     int64_t ws = 0, wd = 0;
     for (int64_t t = 0; t < (int64_t)pool.size(); ++t) {
         if (t) {
@@ -1499,6 +1542,27 @@ int gm_pigeon_plan_dist(int64_t n_db, int64_t n_q, int guidelen, int k, double p
     if (levels < 1) levels = 1;
     if (levels > GM_PG_LEVELS) levels = GM_PG_LEVELS;
     const int found = gm_pg_plan(n_db, n_q, guidelen, k, p_match, &lay, p_short, levels - 1, &c, &casc);
+    if (cost) *cost = c;
+    if (cascade) *cascade = found ? casc : 0;
+    for (int b = 0; b < GM_PG_MAXB; ++b) {
+        if (blen) blen[b] = found && b < lay.B ? lay.blen[b] : 0;
+        if (trad) trad[b] = found && b < lay.B ? lay.trad[b] : 0;
+    }
+    return found ? lay.B : 0;
+}
+
+int gm_pigeon_plan_sample(int64_t n_db, int64_t n_q, int guidelen, int k, double p_match, const uint32_t* cum, int n_rows,
+                          int levels, int* blen, int* trad, double* cost, int* cascade) {
+    gm_pg_layout lay{};
+    double c = 1.0;
+    int casc = 0;
+    if (levels < 1) levels = 1;
+    if (levels > GM_PG_LEVELS) levels = GM_PG_LEVELS;
+    gm_pg_sample smp{};
+    smp.n = n_rows;
+    smp.cum = cum;
+    smp.k = k;
+    const int found = gm_pg_plan(n_db, n_q, guidelen, k, p_match, &lay, nullptr, levels - 1, &c, &casc, cum && n_rows > 0 ? &smp : nullptr);
     if (cost) *cost = c;
     if (cascade) *cascade = found ? casc : 0;
     for (int b = 0; b < GM_PG_MAXB; ++b) {

@@ -195,6 +195,11 @@ int gm_pigeon_plan(int64_t n_db, int guidelen, int k, double p_match);
  * *cascade (1: the cost assumes a deeper level takes the short rows).  Returns the number of blocks, 0 = plain scan. */
 int gm_pigeon_plan_dist(int64_t n_db, int64_t n_q, int guidelen, int k, double p_match, const double* p_short,
                         int levels, int* blen, int* trad, double* cost, int* cascade);
+/* The same with the planner's own kind of sample (what the library measures before it plans >= 32 768 candidates):
+ * cum[i * 9 + d] = pool targets within Hamming distance d = 0 .. 8 of sampled candidate i (i < n_rows).  From it the
+ * planner takes the share of candidates whose k-th neighbour lies beyond a radius AND the hits a radius costs. */
+int gm_pigeon_plan_sample(int64_t n_db, int64_t n_q, int guidelen, int k, double p_match, const uint32_t* cum, int n_rows,
+                          int levels, int* blen, int* trad, double* cost, int* cascade);
 /* The K1P cascade of the last query on this handle: number of levels that ran (0: the plain scan), and for level l
  * (0 = the first pass) its candidates, the radius its layout serves, the pairs it evaluated and the rows it left
  * short (handed to the next level or to the re-scan).  Returns the number of levels, or 0. */

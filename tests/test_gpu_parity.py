@@ -635,10 +635,23 @@ def test_output_columns_byte_identical(oracle, cfd_table, dtype):
         assert out["Max CFD"].tolist() == want_max
         # the packed side-car neighbor_table attaches is used only while it describes the frame: a filtered or
         # re-ordered frame goes through the strings and gives the same numbers
-        assert "gm_cfd_packed" in tab.attrs
+        import pandas as pd
+        assert isinstance(tab.attrs.get("gm_cfd_token"), str) and core._cfd_side_car(
+            tab, tab["Guide sequence"].tolist(), tab["Similar guides"].tolist()) is not None
         sub = tab.iloc[::-2].reset_index(drop=True)[["Guide sequence", "Similar guides"]]
         out2 = core.cfd_score(sub)
         assert out2["CFD Similar Guides"].tolist() == want_lists[::-2] and out2["Max CFD"].tolist() == want_max[::-2]
+        # same length, one row in the MIDDLE changed (not a probe row of the old check): the side-car must not be used
+        edit = tab[["Guide sequence", "Similar guides"]].copy()
+        edit.attrs["gm_cfd_token"] = tab.attrs["gm_cfd_token"]
+        r = len(edit) // 2 + 1
+        parts = edit.at[r, "Similar guides"].split(";")
+        edit.at[r, "Similar guides"] = ";".join(parts[::-1])
+        assert core._cfd_side_car(edit, edit["Guide sequence"].tolist(), edit["Similar guides"].tolist()) is None
+        out3 = core.cfd_score(edit)
+        assert out3["CFD Similar Guides"].tolist()[r] == want_lists[r][::-1] and out3["Max CFD"].tolist() == want_max
+        # frames made by neighbor_table concatenate (pandas compares attrs with ==: arrays in there raised)
+        assert len(pd.concat([tab, tab], ignore_index=True)) == 2 * len(tab)
 
 
 # ------------------------------------------------------------------ controls at genome scale (a6)

@@ -207,6 +207,49 @@ def test_pigeonhole_planner_choices():
     assert radius(_lib.pigeon_plan(20_000_000, 20, 10)) <= radius(_lib.pigeon_plan(600_000, 20, 10))
 
 
+def test_planner_prices_short_rows_by_a_deeper_level():
+    """The planner with a measured sample (host arithmetic, no GPU): per sampled candidate the pool targets within
+    d = 0 .. 8.  On a real-genome-like spread of the k-th neighbour's distance (P. aeruginosa PAO1, k = 10: 3: 3 %,
+    4: 37 %, 5: 49 %, 6: 10 %, 7: 1 %) a single K1P pass has to run the radius nearly every row needs (6); with deeper
+    levels allowed the first level runs the radius the majority needs (5), the rows it leaves short are priced as a
+    candidate set of their own, and the modelled cost drops.  On a uniform pool (the k-th neighbour at 6 for 99 % of the
+    rows) nothing changes."""
+    from guidemaker_amd import _lib
+
+    def sample(kth_probs, rows=1024, growth=4.6, seed=0):
+        rng = np.random.default_rng(seed)
+        ks = rng.choice(len(kth_probs), size=rows, p=np.array(kth_probs) / sum(kth_probs))
+        cum = np.zeros((rows, 9), np.uint32)
+        for i, t in enumerate(ks):
+            cum[i] = [max(1, int(round(10 * growth ** (d - t)))) for d in range(9)]
+        return cum
+
+    def radius(plan):
+        return sum(t + 1 for _, t in plan["blocks"]) - 1
+
+    pao = sample([0, 0, 0, .027, .373, .49, .098, .012, 0])
+    one = _lib.pigeon_plan_sample(1_159_446, 1_171_798, 20, 10, pao, 0.2816, levels=1)
+    three = _lib.pigeon_plan_sample(1_159_446, 1_171_798, 20, 10, pao, 0.2816, levels=3)
+    assert one["cascade"] == 0 and radius(one) == 6
+    assert three["cascade"] == 1 and radius(three) == 5 and three["cost"] < 0.7 * one["cost"]
+    assert sum(l for l, _ in three["blocks"]) == 20 and sum(l for l, _ in one["blocks"]) == 20
+    # the rows the first level leaves (k-th neighbour beyond 5) as a candidate set of their own: a wider radius, fewer buckets
+    kth = np.array([int(np.argmax(c >= 10)) if (c >= 10).any() else 9 for c in pao])
+    sub = _lib.pigeon_plan_sample(1_159_446, int(1_171_798 * (kth > 5).mean()), 20, 10, pao[kth > 5], 0.2816, levels=2)
+    assert radius(sub) >= 6 and max(l for l, _ in sub["blocks"]) <= 6
+    uni = sample([0, 0, 0, 0, 0, .002, .987, .011, 0])
+    for levels in (1, 3):
+        p = _lib.pigeon_plan_sample(599_093, 599_093, 20, 10, uni, 0.25, levels=levels)
+        assert p["blocks"] == [(6, 1), (5, 1), (5, 1), (4, 0)] and p["cascade"] == 0
+    # the share-only form (no hit counts): same first-level choice on the real-genome-like spread
+    ps = np.ones(21)
+    ps[:9] = [(kth > r).mean() for r in range(9)]
+    ps[9:] = ps[8]
+    d3 = _lib.pigeon_plan_dist(1_159_446, 1_171_798, 20, 10, ps, 0.2816, levels=3)
+    assert d3["cascade"] == 1 and radius(d3) == 5
+    assert _lib.pigeon_plan_dist(1_159_446, 1_171_798, 20, 10, ps, 0.2816, levels=1)["cascade"] == 0
+
+
 def test_format_neighbor_columns_matches_reference_closures(oracle):
     """the vectorised 'Similar guides' / 'Similar guide distances' columns are byte-identical to
     the reference's per-row closures (core.py:913-931, restated in the oracle), including rows with fewer than k
@@ -245,11 +288,16 @@ def test_pack_rejects_mixed_lengths_that_sum_right():
 
 
 def test_packed_side_car_travels_with_the_frame():
-    """find_targets attaches the 2-bit packed 'target' column (frame.attrs['gm_packed']); TargetProcessor uses it
-    instead of re-encoding the strings, checks it against the strings, and falls back when it does not fit."""
+    """find_targets keeps the 2-bit packed 'target' column for the frame (a string token in frame.attrs, the array in
+    the module's cache: arrays in attrs break pd.concat); TargetProcessor uses it instead of re-encoding the strings,
+    checks it against the strings, and falls back when it does not fit."""
+    import pandas as pd
     recs = carsonella()
     df = core.PamTarget("NGG", "5prime", "hamming").find_targets(recs, 20)
-    side = df.attrs["gm_packed"]
+    side = core.packed_side_car(df)
+    assert all(isinstance(v, (str, int)) for v in df.attrs.values())      # nothing in attrs that `==` chokes on
+    both = pd.concat([df, df], ignore_index=True)                        # (raised ValueError with an array in attrs)
+    assert len(both) == 2 * len(df)
     assert df.attrs["gm_guidelen"] == 20 and side.dtype == np.uint64 and len(side) == len(df)
     assert (side == _lib.pack(df["target"].tolist(), 20)).all()
     tp = core.TargetProcessor(df, lsr=10)
@@ -260,14 +308,17 @@ def test_packed_side_car_travels_with_the_frame():
     assert tp._packed_targets()[0] is pk[0]
     # a frame whose rows were filtered loses the alignment: the side-car is ignored, the strings are packed
     sub = df[df["strand"]].reset_index(drop=True)
-    sub.attrs["gm_packed"] = side                                      # stale on purpose
+    sub.attrs["gm_packed_token"] = df.attrs["gm_packed_token"]         # stale on purpose
     tp2 = core.TargetProcessor(sub, lsr=10)
     assert (tp2._packed_targets()[0] == _lib.pack(sub["target"].tolist(), 20)).all()
     # same length but different content: caught by the probe rows
     wrong = df.copy()
-    wrong.attrs["gm_packed"] = side[::-1].copy()
+    wrong.attrs["gm_packed_token"] = core._packed_side_car_put(side[::-1].copy())
     tp3 = core.TargetProcessor(wrong, lsr=10)
     assert (tp3._packed_targets()[0] == side).all()
+    # the concatenated frame above carries a token whose side-car has another length: ignored
+    tp4 = core.TargetProcessor(both, lsr=10)
+    assert (tp4._packed_targets()[0] == np.concatenate([side, side])).all()
 
 
 def test_real_genome_hook(tmp_path, monkeypatch):

@@ -98,7 +98,7 @@ def test_pao1_flow_gpu(oracle):
     assert (counts == 10).all() and (dists[:, 0] == 0).all() and (np.diff(dists, axis=1) >= 0).all()
     # the whole result against the plain two-phase scan
     qmask = ((t["isseedduplicated"] == False) | (t["hasrestrictionsite"] == False)).to_numpy()   # noqa: E712
-    q = df.attrs["gm_packed"][qmask]
+    q = core.packed_side_car(df)[qmask]
     idx.set_variant(8)
     i8, d8, c8 = idx.knn(q, 10)
     idx.set_variant(0)
@@ -112,10 +112,15 @@ def test_pao1_flow_gpu(oracle):
     assert (i0 == ids).all() and (d0 == dists).all() and (c0 == counts).all()
     i1, d1, c1 = idx.knn(q, 10)
     assert (i1 == ids).all() and (d1 == dists).all() and (c1 == counts).all()
-    # what the sample is for: on this genome the model's radius leaves an eighth of the rows to the re-scans
-    assert idx.last_evaluated()[1] < rescanned_model // 4
+    # what the sample is for: on this genome the model's radius leaves an eighth of the rows to the plain re-scans; with
+    # the measured spread of the k-th neighbour's distance the first K1P level runs the radius the majority needs, the
+    # rows it leaves go through deeper K1P levels (wider radius, layouts of their own) and hardly any reach the re-scans
+    levels = idx.cascade_info()
+    assert len(levels) >= 2 and levels[0]["n_q"] == n_q and levels[1]["n_q"] == levels[0]["left"], levels
+    assert all(b["radius"] > a["radius"] for a, b in zip(levels, levels[1:])), levels
+    assert levels[-1]["left"] < rescanned_model // 4, (levels, rescanned_model)
     # a row sample against the CPU oracle over the full pool (true units)
-    packed_db = df.attrs["gm_packed"][np.sort(np.unique(df.attrs["gm_packed"], return_index=True)[1])]
+    packed_db = core.packed_side_car(df)[np.sort(np.unique(core.packed_side_car(df), return_index=True)[1])]
     assert packed_db.shape[0] == s["n_unique"]
     rows = np.sort(np.random.default_rng(66).choice(n_q, size=256, replace=False))
     L = p["target_len"]
