@@ -251,7 +251,30 @@ def cpu_baseline(pool, seconds):
             td = td // 2
         n_all = pool["packed_all"].shape[0]
         est = build_s + query_s * n_all / n_s
+        notebook = None
+        try:      # how close the restatement is to nmslib on the one data set the reference published recall for
+            import gzip
+            rows = [ln.rstrip("\n").split("\t") for ln in
+                    gzip.open(os.path.join(ROOT, "tests", "golden", "carsonella_targets_NGG5p.tsv.gz"), "rt")]
+            ti = rows[0].index("target")
+            uniq = list(dict.fromkeys(r[ti] for r in rows[1:]))
+            cp = _lib.pack(uniq, 20)
+            cc = np.frombuffer("".join(uniq).encode(), np.uint8).reshape(-1, 20)
+            _, cod, _ = orc.knn(cc, cc, 20, "hamming", 3, 4)
+            notebook = {"data": "Carsonella ruddii NGG 5prime L=20, %d unique targets queried against themselves, k=3, 4 "
+                                "threads, recall on the first two distances (tests/GridOptimization.ipynb:147-233)" % len(uniq),
+                        "settings": []}
+            for (M_, efc_, ef_), theirs in (((16, 64, 256), 1.0), ((16, 13, 13), 0.987415), ((16, 16, 13), 0.990037)):
+                hh = orc.HnswBaseline(cp, 20, "hamming", M=M_, efc=efc_, post=1, threads=4, seed=1)
+                _, cd = hh.query(cp, 3, ef=ef_, threads=4)
+                hh.close()
+                notebook["settings"].append({"M": M_, "efConstruction": efc_, "ef": ef_, "post": 1,
+                                             "recall_restated": orc.top2_distance_recall(cd, cod // 2),
+                                             "recall_nmslib_notebook": theirs})
+        except Exception as e:
+            notebook = {"error": repr(e)}
         out["hnsw"] = {"kind": "reference algorithm restated (not nmslib)", "M": 16, "efConstruction": 10, "post": 1,
+                       "recall_vs_notebook": notebook,
                        "ef": 9, "cores": threads, "build_s_full_pool": build_s, "query_s_sample": query_s,
                        "n_query_sample": n_s, "genome_wide_s_estimate": est,
                        "value": float(n_all) * db.shape[0] / est, "unit": "guide-pair comparisons/s (resolved, approximate)",

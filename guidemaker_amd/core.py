@@ -640,6 +640,20 @@ class TargetProcessor:
             minimum_hmdist = int(min(sort_dist))
             sm_count += 1
             n_searched += n * search_mult
+            if minimum_hmdist < wanted_dist and sm_count < len(multiples):
+                # Fail fast.  The search is exact, so the nearest-distance histogram of this draw says whether the
+                # LARGEST multiple could ever yield n sequences at >= MINIMUM_HMDIST (the reference's HNSW misses
+                # neighbours and reports too-large distances, which is how its loop ends; an exact search on a large
+                # genome would draw 1.1 10^4 n more sequences and then walk off the list all the same).
+                expect = _controls_expected_at(d1, wanted_dist, length, n * largest_multiple, len(self._db_targets))
+                if expect < 0.1 * n:
+                    raise IndexError(
+                        "list index out of range: no %d control sequences at distance >= CONTROL.MINIMUM_HMDIST=%s "
+                        "from every target can be expected within CONTROL.CONTROL_SEARCH_MULTIPLE=%s x n draws: the "
+                        "exact nearest-distance histogram of the first %d draws (best minimum %d over %d targets) puts "
+                        "%.3g such sequences into the largest draw (the search is exact, so on large genomes lower "
+                        "MINIMUM_HMDIST in the config)"
+                        % (n, wanted_dist, multiples, n_searched, minimum_hmdist, len(self._db_targets), expect))
         dt = time.perf_counter() - t0
         logger.info("get_control_seqs: %d random %d-mers x N_db=%d targets in %.3f s (%.3e guide pairs/s), minimum "
                     "distance %s", n_searched, length, len(self._db_targets), dt,
@@ -652,6 +666,35 @@ class TargetProcessor:
             "Hamming distance": sort_dist,
         })
         return (min(sort_dist), statistics.median(sort_dist), table)
+
+
+def _controls_expected_at(d1, wanted, L, draws, n_db, min_count=30) -> float:
+    """Expected number of random controls at nearest distance >= `wanted` among `draws` draws, from the exact nearest
+    distances d1 of a first draw.  P(nearest >= s) = exp(-lambda(s - 1)), lambda(r) = expected targets within r of a random
+    sequence; it is read off the draw at the largest s <= wanted that still has `min_count` sequences, and carried to
+    `wanted` with the growth of lambda under uniform bases, lambda(r) / lambda(r - 1) = P(Bin(L, 3/4) <= r) / P(... <= r - 1)
+    -- a LOWER bound of the true growth for Levenshtein (lev <= hamming) and for skewed pools alike, so the figure
+    errs on the side of too many expected controls (the caller gives up only when even that is far too few)."""
+    d1 = np.asarray(d1, dtype=np.int64)
+    m = int(d1.shape[0])
+    if m == 0:
+        return float(draws)
+    wanted = int(wanted)
+    tail = np.array([(d1 >= s).sum() for s in range(wanted + 1)], dtype=np.int64)
+    if tail[wanted] >= min_count:
+        return float(draws) * float(tail[wanted]) / m
+    s_star = max((s for s in range(1, wanted + 1) if tail[s] >= min_count), default=0)
+    if s_star == 0:                       # (every control hits a target exactly: nothing to extrapolate from)
+        return 0.0 if n_db > 0 else float(draws)
+    lam = -np.log(min(float(tail[s_star]) / m, 1.0 - 0.5 / m))
+
+    def within(r):                        # P(Bin(L, 3/4) <= r)
+        from math import comb
+        return sum(comb(L, i) * 0.75 ** i * 0.25 ** (L - i) for i in range(0, min(r, L) + 1))
+
+    for s in range(s_star + 1, wanted + 1):
+        lam *= within(s - 1) / max(within(s - 2), 1e-300)
+    return float(draws) * float(np.exp(-lam))
 
 
 # ------------------------------------------------------------------------------------------------

@@ -21,7 +21,7 @@ import guidemaker_amd
 from guidemaker_amd import _lib, core, workloads
 
 pytestmark = pytest.mark.gpu
-ORACLE_ROWS = int(os.environ.get("GM_ORACLE_ROWS", "512"))      # (a one-off deeper check: GM_ORACLE_ROWS=16384)
+ORACLE_ROWS = int(os.environ.get("GM_ORACLE_ROWS", "4096"))      # (a one-off deeper check: GM_ORACLE_ROWS=16384)
 
 
 @functools.lru_cache(maxsize=None)
@@ -172,3 +172,55 @@ def test_leven_workload_full_size(oracle):
         assert (oc == counts[rows]).all() and (od == dists[rows]).all() and (oi == ids[rows]).all()
     finally:
         idx.close()
+
+
+# ------------------------------------------------------------------ multi-GPU decomposition at full size, on ONE GPU
+
+
+def test_sharded_knn_index_world2_full_s1_on_one_gpu():
+    """SURVEY.md 8(e) at BASELINE size: the FULL S1 candidate set through distributed.sharded_knn_index with two ranks
+    (torch.distributed.run, gloo, both on GPU 0 -- the rank arithmetic, padding and the one all-gather of packed keys are
+    the multi-GPU path's; only the transport differs from RCCL), against the single-rank table of all candidates."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(root, "tests", "_shard_child.py"), root],
+                         cwd=root, capture_output=True, text=True, timeout=400)
+    assert out.returncode == 0 and "shard ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+_MULTI_S3_CHILD = r"""
+import sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from guidemaker_amd import _lib, workloads
+assert "torch" not in sys.modules
+pool = workloads.make_pool("s3")
+L, k = pool["guidelen"], pool["k"]
+m = _lib.MultiIndex(pool["packed_db"], L, _lib.METRIC_HAMMING, [0])
+assert m.devices() == 1 and m.has_comm()
+ids, dists, counts = m.knn(pool["packed_all"], k)      # shard -> scan -> key packing -> ncclAllGather -> unpack
+m.close()
+idx = _lib.Index(pool["packed_db"], L, _lib.METRIC_HAMMING, 0)
+i1, d1, c1 = idx.knn(pool["packed_all"], k)
+idx.close()
+assert ids.shape == (pool["packed_all"].shape[0], k)
+assert (ids == i1).all() and (dists == d1).all() and (counts == c1).all()
+print("multi s3 ok", ids.shape)
+"""
+
+
+def test_multi_device_entry_at_s3_size():
+    """gm_multi_* over the device list [0] at BASELINE configs[3] size (891 138 candidates, k = 5): the one-process driver
+    of the same decomposition (ncclCommInitAll + one grouped ncclAllGather of the keys) against the plain handle."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _MULTI_S3_CHILD, root], capture_output=True, text=True, timeout=400)
+    assert out.returncode == 0 and "multi s3 ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

@@ -658,8 +658,8 @@ def test_output_columns_byte_identical(oracle, cfd_table, dtype):
 def test_get_control_seqs_at_genome_scale(tmp_path):
     """reference core.py:586-620 on an E. coli sized pool (workload S1).  The search is exact, so the shipped
     CONTROL.MINIMUM_HMDIST = 7 cannot be met (a random 20-mer has ~18 targets within 6 mismatches): the mirrored loop
-    walks off CONTROL_SEARCH_MULTIPLE after the 10 000 x draw and raises IndexError, as the reference's does, with
-    the config key named.  With a reachable minimum the call returns the (n, 3) table; the nearest distances behind
+    would walk off CONTROL_SEARCH_MULTIPLE after the 10 000 x draw and raise IndexError, as the reference's does -- here
+    the same IndexError comes after the first draw, with the config key named.  With a reachable minimum the call returns the (n, 3) table; the nearest distances behind
     it are the same from the pigeonhole-partitioned scan and from the plain scan."""
     import yaml
     from guidemaker_amd import workloads
@@ -671,8 +671,13 @@ def test_get_control_seqs_at_genome_scale(tmp_path):
     tl.nmslib_index = _lib.Index(pool["packed_db"], L, _lib.METRIC_HAMMING)
     genome = [Rec("ACGT" * 5000 + "GC" * 160, "g")]                                    # GC content 0.508
     np.random.seed(7)
-    with pytest.raises(IndexError, match="MINIMUM_HMDIST"):
+    import time
+    t0 = time.perf_counter()
+    with pytest.raises(IndexError, match="MINIMUM_HMDIST") as exc:
         tl.get_control_seqs(genome, configpath=CONFIG, length=L, n=10)
+    # ... and it does so after the FIRST draw (10 x n sequences): their exact nearest-distance histogram already rules
+    # the largest draw out, so the 1.1 10^4 x n further nearest-distance queries are not spent
+    assert "first 100 draws" in str(exc.value) and time.perf_counter() - t0 < 20.0
     with open(CONFIG) as fh:
         cfg = yaml.safe_load(fh)
     cfg["CONTROL"]["MINIMUM_HMDIST"] = 5

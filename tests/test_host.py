@@ -207,6 +207,25 @@ def test_pigeonhole_planner_choices():
     assert radius(_lib.pigeon_plan(20_000_000, 20, 10)) <= radius(_lib.pigeon_plan(600_000, 20, 10))
 
 
+def test_controls_fail_fast_estimate():
+    """get_control_seqs gives up after the first draw when the exact nearest-distance histogram rules the largest draw out
+    (core._controls_expected_at; the reference's loop, core.py:586-620, would draw 1.1 10^4 n sequences first)."""
+    rng = np.random.default_rng(0)
+    # E. coli sized pool: random 20-mers sit 3 .. 6 mismatches from their nearest target; MINIMUM_HMDIST 7 is out of reach
+    d1 = rng.choice([3, 4, 5, 6], p=[0.02, 0.45, 0.5, 0.03], size=100)
+    assert core._controls_expected_at(d1, 7, 20, 10 * 10000, 599_093) < 1e-6
+    d1 = rng.choice([3, 4, 5, 6], p=[0.02, 0.45, 0.5, 0.03], size=10_000)
+    assert core._controls_expected_at(d1, 7, 20, 1000 * 10000, 599_093) < 1.0
+    assert core._controls_expected_at(d1, 5, 20, 1000 * 10000, 599_093) > 1e6            # a reachable minimum: direct estimate
+    assert abs(core._controls_expected_at(d1, 6, 20, 10_000, 599_093) - (d1 >= 6).sum()) < 1e-9
+    # Carsonella sized pool: the nearest target is 6 .. 9 away, nothing to give up on
+    d1 = rng.choice([6, 7, 8, 9], p=[0.1, 0.5, 0.35, 0.05], size=100)
+    assert core._controls_expected_at(d1, 7, 20, 100_000, 3_814) > 50_000
+    # no data at all / every control an exact hit
+    assert core._controls_expected_at(np.zeros(0, int), 7, 20, 1000, 10) == 1000.0
+    assert core._controls_expected_at(np.zeros(50, int), 7, 20, 1000, 10) == 0.0
+
+
 def test_planner_prices_short_rows_by_a_deeper_level():
     """The planner with a measured sample (host arithmetic, no GPU): per sampled candidate the pool targets within
     d = 0 .. 8.  On a real-genome-like spread of the k-th neighbour's distance (P. aeruginosa PAO1, k = 10: 3: 3 %,

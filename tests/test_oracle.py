@@ -5,7 +5,9 @@ import random
 import numpy as np
 import pytest
 
-from conftest import load_json, load_carsonella
+import os
+
+from conftest import GOLDEN, load_json, load_carsonella
 
 
 def test_one_hot_matches_reference(oracle):
@@ -167,3 +169,39 @@ def test_hnsw_baseline_properties(oracle):
     ol, odl, _ = oracle.knn(chars[:1500], chars[:50], L, "leven", 2)
     assert (dl[:, 0] == 0).all() and (dl >= odl).all() and oracle.top2_distance_recall(dl, odl) > 0.9
     hl.close()
+
+
+def test_hnsw_baseline_against_the_notebook(oracle):
+    """The reference's own recall study (tests/GridOptimization.ipynb:147-233, 1101-1129, 1525: Carsonella NGG 5prime
+    L = 20, 3 814 unique targets queried against themselves, k = 3, 4 threads, recall on the first two distances) with
+    the restated HNSW: recall 1.0 at the original parameters (M 16, efC 64, ef 256; notebook 1.0), and at the tuned ones
+    within two points of nmslib's (M 16, efC 13, ef 13: notebook 0.987; M 16, efC 16, ef 13: 0.990).  What brought the
+    restatement there: nmslib's post-processing (a second graph, layer-0 lists merged) and its rule that fewer
+    candidates than M are all linked (efConstruction < M); a single graph with the selection heuristic always on gives
+    0.90 / 0.93.  The remaining gap is stated in bench.py's cpu_baseline.hnsw.recall_vs_notebook."""
+    import gzip
+    from guidemaker_amd import _lib
+    rows = [ln.rstrip("\n").split("\t") for ln in gzip.open(os.path.join(GOLDEN, "carsonella_targets_NGG5p.tsv.gz"), "rt")]
+    ti = rows[0].index("target")
+    uniq = list(dict.fromkeys(r[ti] for r in rows[1:]))
+    assert len(uniq) == 3814                                    # the notebook's N (SURVEY.md section 6)
+    L = 20
+    packed = _lib.pack(uniq, L)
+    chars = np.frombuffer("".join(uniq).encode(), np.uint8).reshape(-1, L)
+    _, od, _ = oracle.knn(chars, chars, L, "hamming", 3)
+    od = od // 2
+    got = {}
+    for (M, efc, ef), floor in (((16, 64, 256), 0.999), ((16, 13, 13), 0.968), ((16, 16, 13), 0.96), ((16, 10, 9), 0.93)):
+        rs = []
+        for seed in (1, 2, 3):
+            h = oracle.HnswBaseline(packed, L, "hamming", M=M, efc=efc, post=1, threads=4, seed=seed)
+            _, d = h.query(packed, 3, ef=ef, threads=4)
+            h.close()
+            rs.append(oracle.top2_distance_recall(d, od))
+        got[(M, efc, ef)] = rs
+        assert min(rs) >= floor, (M, efc, ef, rs)
+    # without the post-processing the tuned settings fall well below nmslib's figures
+    h = oracle.HnswBaseline(packed, L, "hamming", M=16, efc=13, post=0, threads=4, seed=1)
+    _, d = h.query(packed, 3, ef=13, threads=4)
+    h.close()
+    assert oracle.top2_distance_recall(d, od) < min(got[(16, 13, 13)])

@@ -122,7 +122,7 @@ def test_pao1_flow_gpu(oracle):
     # a row sample against the CPU oracle over the full pool (true units)
     packed_db = core.packed_side_car(df)[np.sort(np.unique(core.packed_side_car(df), return_index=True)[1])]
     assert packed_db.shape[0] == s["n_unique"]
-    rows = np.sort(np.random.default_rng(66).choice(n_q, size=256, replace=False))
+    rows = np.sort(np.random.default_rng(66).choice(n_q, size=2048, replace=False))
     L = p["target_len"]
     asc = np.frombuffer(b"ACGT", np.uint8)
     shifts = (2 * np.arange(L, dtype=np.uint64))[None, :]
@@ -164,7 +164,7 @@ def test_pao1_levenshtein_gpu(oracle):
         assert (i2 == ids).all() and (d2 == dists).all() and (c2 == counts).all()
     finally:
         idx.close()
-    rows = np.sort(np.random.default_rng(23).choice(q.shape[0], size=256, replace=False))
+    rows = np.sort(np.random.default_rng(23).choice(q.shape[0], size=2048, replace=False))
     asc = np.frombuffer(b"ACGT", np.uint8)
     shifts = (2 * np.arange(L, dtype=np.uint64))[None, :]
     db_b = np.ascontiguousarray(asc[((db[:, None] >> shifts) & np.uint64(3)).astype(np.uint8)])
