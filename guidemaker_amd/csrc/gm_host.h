@@ -12,6 +12,7 @@
 #include "gm_pg_types.h"
 
 struct gm_pigeon;   // K1P state (gm_pigeon.hip)
+struct gm_levpart;  // K2P state (gm_levpart.hip)
 
 // K1P cascade (gmhip.hip run_hamming_pigeon): the rows a K1P pass leaves short -- their k-th neighbour lies beyond the
 // pass's radius -- are searched again, as a compact candidate set, by a further K1P pass with a larger radius and a
@@ -75,6 +76,7 @@ struct gm_index {
     int lv_two_pass = 1;          // Levenshtein: narrow-band first pass + second pass for the short lists (gm_set_param "lv_two_pass")
     int lv_seg = 0;               // experiments (gm_set_param "lv_seg"): pool segments of the Levenshtein scan, 0 = choose
     int n_simd = 1024;            // CUs x 4
+    gm_levpart* lp = nullptr;     // K2P: the Levenshtein partition's pool copies + workspaces (built on first use)
     gm_pigeon* pg = nullptr;      // K1P: block-sorted pool copies + query workspaces (built on first use) of the
                                   // cascade level that is running (level 0 between queries)
     // the layout planner's last answer (the enumeration costs ~30 us of host time per query otherwise)
@@ -208,6 +210,27 @@ struct gm_lv_opt {
                             const gm_lv_opt* opt);
 GM_FOR_EACH_LEN(GM_DECL_LV)
 #undef GM_DECL_LV
+
+// K2P launchers, one per guide length (gm_inst_lv.hip), and its host side (gm_levpart.hip)
+#define GM_DECL_LVP(LEN)                                                                                              \
+    int gm_launch_lvp_L##LEN(const gm_lp_copies* P, const gm_lp_chunk* chunks, int64_t n_chunks, const uint2* q, int64_t n_q, \
+                             int k, int kcap, const int32_t* seed_d, const int32_t* seed_c, int seed_k, uint32_t* keys,      \
+                             hipStream_t st);
+GM_FOR_EACH_LEN(GM_DECL_LVP)
+#undef GM_DECL_LVP
+struct gm_levpart;      // K2P state (gm_levpart.hip)
+void gm_lp_free(gm_index* idx);
+int gm_lp_set_param(gm_index* idx, const char* name, int value, bool* known);
+int gm_lp_layout(int L, int r, double p_match, int* bstart, int* blen, int* copy_block, int* copy_shift, int* first_copy,
+                 double* fraction);
+int gm_lp_tune_radius(gm_index* idx);
+void gm_lp_plan_get(gm_index* idx, int64_t* nq, int* k, int* r);
+void gm_lp_plan_set(gm_index* idx, int64_t nq, int k, int r);
+int64_t gm_lp_last_pairs(gm_index* idx);
+int gm_lp_prepare(gm_index* idx, int r, hipStream_t st);
+int gm_lp_candidates(gm_index* idx, const uint2* q, int64_t n_q, hipStream_t st);
+int gm_lp_scan(gm_index* idx, const uint2* q, int64_t n_q, int k, int kcap, const int32_t* seed_d, const int32_t* seed_c, int seed_k,
+               hipStream_t st, const uint32_t** keys_out, int* n_lists);
 
 // K1v (scalar-load bit-sliced kernel), kept for L = 20 as an A/B baseline (gm_inst_bs20.hip)
 int gm_launch_bs20(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t* ids, int32_t* dists,

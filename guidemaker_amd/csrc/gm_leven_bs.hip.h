@@ -25,6 +25,7 @@
 #define GM_LVB_BAND_WAVES 4     /* ... and for the band-only kernel (~110 VGPRs with both halves of a group in flight) */
 #endif
 #include "gm_leven.hip.h"
+#include "gm_pg_types.h"
 
 #include <utility>
 
@@ -416,6 +417,137 @@ __global__ __launch_bounds__(WAVE, (FULL ? GM_LVB_WAVES : GM_LVB_BAND_WAVES)) vo
     }
     if (valid) {
         uint32_t* out = keys + ((int64_t)seg * n_q + qi) * KCAP;
+#pragma unroll
+        for (int s = 0; s < KCAP; ++s) out[s] = list.v[s];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K2P scan (gm_pg_types.h gm_lp_copies): K2B's evaluation over the target buckets a pigeonhole partition leaves.
+// Workgroup = one chunk of <= 64 candidates that carry the same bases v on block j (lane = candidate, through the
+// block's candidate order) against bucket v of every copy of that block (one copy per displacement of the block).
+// Targets arrive in copy order, not id order, and the same target can turn up under several displacements and blocks:
+// ids come from the copy's position -> id map, the register list takes a key only once (insert_unique) and the bound
+// while the list is full is "distance <= that of the k-th entry" (ties compete by id) instead of K2B's strict one.
+// keys: [n_blocks][n_q][KCAP] raw lists, folded by k_merge_lists_unique.
+// ---------------------------------------------------------------------------------------------------
+template <int L, int KCAP>
+__device__ __forceinline__ void lvp_take_hits(uint32_t hits, const uint32_t (&c)[5], const uint32_t* __restrict__ ord,
+                                              int64_t pos0, RegList<KCAP>& list, int& thr, int thr_seed, uint32_t (&Tb)[5]) {
+    while (hits != 0u) {
+        const int j = __builtin_ctz(hits);
+        hits &= hits - 1u;
+        const int s = (int)(((c[0] >> j) & 1u) | (((c[1] >> j) & 1u) << 1) | (((c[2] >> j) & 1u) << 2) |
+                            (((c[3] >> j) & 1u) << 3) | (((c[4] >> j) & 1u) << 4));
+        const int d = L - s;
+        if (d >= thr) continue;
+        const uint32_t id = ord[pos0 + j];
+        if (id == 0xffffffffu) continue;      // padding of the bucket
+        list.insert_unique(((uint32_t)d << ID_BITS) | id);
+        // (while the list is full a new target must be no farther than the k-th entry: ties compete by id)
+        int nt = list.v[KCAP - 1] == RegList<KCAP>::EMPTY ? L + 1 : (int)((list.v[KCAP - 1] - 1u) >> ID_BITS) + 1;
+        nt = nt < thr_seed ? nt : thr_seed;
+        if (nt != thr) {
+            thr = nt;
+            lk_set_bound(Tb, L, thr);
+        }
+    }
+}
+
+template <int L, int KCAP, bool FULL>
+__global__ __launch_bounds__(WAVE, (FULL ? GM_LVB_WAVES : GM_LVB_BAND_WAVES)) void k_leven_part_bs(
+    gm_lp_copies P, const gm_lp_chunk* __restrict__ chunks, const uint2* __restrict__ q, int64_t n_q, int k,
+    const int32_t* __restrict__ seed_dists, const int32_t* __restrict__ seed_counts, int seed_k, uint32_t* __restrict__ keys) {
+    extern __shared__ __align__(16) uint32_t smem[];
+    constexpr int TILE_W = lk_tile_bytes(L) / 4;
+    constexpr int GW = lk_group_words(L);
+    const int lane = threadIdx.x;
+    const gm_lp_chunk ch = chunks[blockIdx.x];
+    const bool valid = lane < ch.cn;
+    const int64_t qi = valid ? (int64_t)P.cperm[ch.j][ch.c0 + lane] : 0;
+    const uint2 qv = valid ? q[qi] : make_uint2(0u, 0u);
+
+    RegList<KCAP> list;
+    list.init(k, nullptr, lane);
+    int thr_seed = L + 1;
+    if (valid && seed_dists != nullptr && (seed_counts == nullptr || seed_counts[qi] >= seed_k))
+        thr_seed = seed_dists[qi * seed_k + (seed_k - 1)] + 1;      // lev <= hamming; ties at the seed distance compete by id
+    if (thr_seed > L + 1) thr_seed = L + 1;
+    int thr = valid ? thr_seed : 0;
+    {
+        const bool in_band = __builtin_amdgcn_ballot_w64(thr > 2 * lvb_band(L) + 2) == 0ull;
+        if (in_band == FULL) return;      // the other launch serves this workgroup
+    }
+    uint32_t Tb[5];
+    lk_set_bound(Tb, L, thr);
+
+    for (int cp = P.first_copy[ch.j]; cp < P.first_copy[ch.j + 1]; ++cp) {
+        const int2 bd = P.bdesc[cp][ch.v];      // (wave-uniform: scalar loads)
+        if (bd.y <= 0) continue;
+        const uint32_t* __restrict__ table = P.table[cp];
+        const uint32_t* __restrict__ ord = P.ord[cp];
+        const int t0 = bd.x, t1 = bd.x + bd.y;
+        lk_stage<L>(table, t0, smem, lane);
+        for (int t = t0; t < t1; ++t) {
+            const uint32_t* cur = smem + ((t - t0) & 1) * TILE_W;
+            lk_stage_wait();
+            if (t + 1 < t1) lk_stage<L>(table, t + 1, smem + ((t - t0 + 1) & 1) * TILE_W, lane);
+            uint32_t adr[L];
+            const uint32_t cur_b = (uint32_t)(size_t)cur;
+            uint32_t qx = qv.x, qy = qv.y;
+            asm volatile("" : "+v"(qx), "+v"(qy));
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+                const uint32_t code = ((qx >> i) & 1u) | (((qy >> i) & 1u) << 1);
+                adr[i] = cur_b + code * 8u;
+            }
+            for (int gl = 0; gl < LK_TG; ++gl) {
+                uint32_t c0[5], c1[5];
+                constexpr int BAND = lvb_band(L), NARROW = BAND - 1;
+                const bool banded = !FULL || __builtin_amdgcn_ballot_w64(thr > 2 * BAND + 2) == 0ull;
+                const bool narrow = NARROW >= 2 && __builtin_amdgcn_ballot_w64(thr > 2 * NARROW + 2) == 0ull;
+                if (narrow) {
+                    if constexpr (!FULL) {
+                        lvb_eval_group_banded<L, (NARROW >= 2 ? NARROW : 2)>(adr, c0, c1);
+                    } else {
+                        lvb_eval_half_banded<L, 0, (NARROW >= 2 ? NARROW : 2)>(adr, c0);
+                        lvb_eval_half_banded<L, 4, (NARROW >= 2 ? NARROW : 2)>(adr, c1);
+                    }
+#pragma unroll
+                    for (int i = 0; i < L; ++i) asm volatile("v_add_u32 %0, %1, %0" : "+v"(adr[i]) : "n"(GW * 4));
+                } else if (banded) {
+                    if constexpr (!FULL) {
+                        lvb_eval_group_banded<L, BAND>(adr, c0, c1);
+                    } else {
+                        lvb_eval_half_banded<L, 0, BAND>(adr, c0);
+                        lvb_eval_half_banded<L, 4, BAND>(adr, c1);
+                    }
+#pragma unroll
+                    for (int i = 0; i < L; ++i) asm volatile("v_add_u32 %0, %1, %0" : "+v"(adr[i]) : "n"(GW * 4));
+                } else if constexpr (FULL) {
+                    lvb_eval_half<L, 0>(adr, c0);
+#pragma unroll
+                    for (int i = 0; i < L; ++i) asm volatile("v_subrev_u32 %0, %1, %0" : "+v"(adr[i]) : "n"(GW * 4));
+                    lvb_eval_half<L, 4>(adr, c1);
+                } else {
+                    __builtin_unreachable();
+                }
+                uint32_t h0 = GM_BITOP3(c0[0], Tb[0], Tb[0], TT_A_OR_NOTB), h1 = GM_BITOP3(c1[0], Tb[0], Tb[0], TT_A_OR_NOTB);
+#pragma unroll
+                for (int b = 1; b < 5; ++b) {
+                    h0 = GM_BITOP3(c0[b], Tb[b], h0, TT_GE);
+                    h1 = GM_BITOP3(c1[b], Tb[b], h1, TT_GE);
+                }
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64((h0 | h1) != 0u) != 0ull, 0)) {
+                    const int64_t pos0 = ((int64_t)t * LK_TG + gl) * LK_GROUP;
+                    lvp_take_hits<L, KCAP>(h0, c0, ord, pos0, list, thr, thr_seed, Tb);
+                    lvp_take_hits<L, KCAP>(h1, c1, ord, pos0 + 32, list, thr, thr_seed, Tb);
+                }
+            }
+        }
+    }
+    if (valid) {
+        uint32_t* out = keys + ((int64_t)ch.j * n_q + qi) * KCAP;
 #pragma unroll
         for (int s = 0; s < KCAP; ++s) out[s] = list.v[s];
     }

@@ -1,0 +1,403 @@
+// gm_levpart.hip -- host side of K2P, the pigeonhole partition for the Levenshtein scan (kernels: k_leven_part_bs and
+// k_merge_lists_unique in gm_leven_bs.hip.h; driver: gmhip.hip run_leven_partition).
+//
+//   Two sequences of the same length L within edit distance r: cut the candidate into r + 1 disjoint blocks; at most r
+//   edits touch at most r blocks, so one block is copied to the target unchanged.  Where it lands is displaced by
+//   (insertions - deletions before it), and an alignment of equal-length sequences of cost <= r spends at most
+//   floor(r / 2) of either: |displacement| <= floor(r / 2).  So every target within r of a candidate carries, for some
+//   block j and displacement d, the candidate's bases of block j at the block's positions + d.
+//
+// Pool side (once per index and radius): for every (block, displacement) pair that stays inside the sequence a "copy" of
+// the pool, stable-sorted by the bases at the displaced positions, buckets padded to whole K2B tiles (256 targets), with
+// the position -> pool id map and the one-hot table of the copy (all L positions: the DP needs them all).  Query side:
+// per block one radix sort of the candidates by the block's value, bucket offsets read back, the chunk table (<= 64
+// candidates of one bucket per workgroup) built on the host.  One workgroup compares its chunk with bucket v of every
+// copy of its block.  Work on P. aeruginosa PAO1 cut at L = 23 (1.16 M targets), r = 5: 6 blocks x 5 displacements of
+// 4-base blocks: ~17 % of the pairs.  On pools where the k-th neighbour lies at 7 of 23 (S2: 136 k targets) eight 3-base
+// blocks x 7 displacements would visit 80 % of the pool: the planner (gmhip.hip) keeps those on the plain K2B scan.
+#include "gm_host.h"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "gm_lookup.hip.h"      // lk_group_words, LK_GROUP, LK_TG
+
+namespace {
+
+template <class T>
+int lp_ensure(T** p, int64_t* cap, int64_t need, const char* what) {
+    if (need <= *cap && *p != nullptr) return GM_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    if (need < 1) need = 1;
+    if (hipMalloc(reinterpret_cast<void**>(p), sizeof(T) * (size_t)need) != hipSuccess)
+        return gm_fail(GM_ERR_ALLOC, std::string("hipMalloc(") + what + ") failed");
+    *cap = need;
+    return GM_OK;
+}
+
+inline dim3 lp_grid(int64_t n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
+
+// key[i] = bases of sequence i at positions [start, start + len), rows[i] = i
+__global__ __launch_bounds__(256) void k_lp_keys(const uint2* __restrict__ planes, int64_t n, int start, int len,
+                                                 uint32_t* __restrict__ keys, uint32_t* __restrict__ rows) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint2 e = planes[i];
+    uint32_t key = 0;
+    for (int j = 0; j < len; ++j) {
+        const int p = start + j;
+        key |= (((e.x >> p) & 1u) | (((e.y >> p) & 1u) << 1)) << (2 * j);
+    }
+    keys[i] = key;
+    rows[i] = (uint32_t)i;
+}
+
+// off[v] = first sorted position whose key is >= v (v = 0 .. nb)
+__global__ __launch_bounds__(256) void k_lp_offsets(const uint32_t* __restrict__ keys, int64_t n, int nb, int32_t* __restrict__ off) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v > nb) return;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < (uint32_t)v) lo = mid + 1; else hi = mid;
+    }
+    off[v] = (int32_t)lo;
+}
+
+// sorted position i (key v, pool row rows[i]) -> position pad_off[v] + (i - raw_off[v]) of the padded copy
+__global__ __launch_bounds__(256) void k_lp_scatter_ord(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ rows, int64_t n,
+                                                        const int32_t* __restrict__ raw_off, const int64_t* __restrict__ pad_off,
+                                                        uint32_t* __restrict__ ord) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t v = keys[i];
+    ord[pad_off[v] + (i - raw_off[v])] = rows[i];
+}
+
+// one-hot table of a copy (format of gm::k_to_onehot, all L positions); padding positions (ord = 0xffffffff) set no bit
+__global__ __launch_bounds__(256) void k_lp_onehot(const uint2* __restrict__ planes, const uint32_t* __restrict__ ord,
+                                                   uint32_t* __restrict__ table, int64_t n_groups, int L) {
+    const int gw = gm::lk_group_words(L);
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_groups * gw) return;
+    const int64_t G = t / gw;
+    const int w = (int)(t % gw);
+    const int p = w >> 3, b = (w >> 1) & 3, h = w & 1;
+    uint32_t out = 0;
+    for (int j = 0; j < 32; ++j) {
+        const uint32_t id = ord[G * gm::LK_GROUP + 32 * h + j];
+        if (id == 0xffffffffu) continue;
+        const uint2 e = planes[id];
+        const uint32_t code = ((e.x >> p) & 1u) | (((e.y >> p) & 1u) << 1);
+        out |= (uint32_t)(code == (uint32_t)b) << j;
+    }
+    table[t] = out;
+}
+
+}  // namespace
+
+struct gm_levpart {
+    // layout
+    int r = -1;                                   // radius the copies were built for (-1: none)
+    int n_blocks = 0, sh = 0;
+    int bstart[GM_LP_MAXBLK]{}, blen[GM_LP_MAXBLK]{};
+    int n_copies = 0;
+    int copy_block[GM_LP_MAXCOPY]{}, copy_shift[GM_LP_MAXCOPY]{};
+    int first_copy[GM_LP_MAXBLK + 1]{};
+    // pool side
+    uint32_t* table[GM_LP_MAXCOPY]{};
+    uint32_t* ord[GM_LP_MAXCOPY]{};
+    int2* bdesc[GM_LP_MAXCOPY]{};
+    // query side (grow-only)
+    uint32_t* cperm[GM_LP_MAXBLK]{};
+    int64_t cperm_cap[GM_LP_MAXBLK]{};
+    uint32_t *k0 = nullptr, *k1 = nullptr, *r0 = nullptr, *r1 = nullptr;
+    int64_t k0_cap = 0, k1_cap = 0, r0_cap = 0, r1_cap = 0;
+    void* sort_tmp = nullptr;
+    size_t sort_tmp_cap = 0;
+    int32_t* off = nullptr;
+    int64_t off_cap = 0;
+    int64_t* pad_off = nullptr;
+    int64_t pad_off_cap = 0;
+    gm_lp_chunk* chunks = nullptr;
+    int64_t chunks_cap = 0;
+    int64_t n_chunks = 0;
+    uint32_t* keys = nullptr;
+    int64_t keys_cap = 0;
+    // knobs / plan cache (gmhip.hip)
+    int tune_radius = 0;                          // gm_set_param "lp_radius": 0 = choose, 1 .. 7 = that radius, -1 = never
+    int64_t plan_nq = -1;
+    int plan_k = -1, plan_r = 0;
+    int64_t last_pairs = 0;                       // pairs the last K2P launch evaluated
+};
+
+namespace {
+
+int lp_sort(gm_levpart* lp, int64_t n, int bits, hipStream_t st) {
+    size_t bytes = 0;
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, bytes, lp->k0, lp->k1, lp->r0, lp->r1, (size_t)n, 0u, (unsigned)bits, st));
+    if (bytes > lp->sort_tmp_cap || lp->sort_tmp == nullptr) {
+        if (lp->sort_tmp) (void)hipFree(lp->sort_tmp);
+        lp->sort_tmp = nullptr;
+        lp->sort_tmp_cap = 0;
+        if (hipMalloc(&lp->sort_tmp, bytes ? bytes : 1) != hipSuccess) return gm_fail(GM_ERR_ALLOC, "hipMalloc(radix sort workspace) failed");
+        lp->sort_tmp_cap = bytes;
+    }
+    HIP_TRY(rocprim::radix_sort_pairs(lp->sort_tmp, bytes, lp->k0, lp->k1, lp->r0, lp->r1, (size_t)n, 0u, (unsigned)bits, st));
+    return GM_OK;
+}
+
+int lp_sort_buffers(gm_levpart* lp, int64_t n) {
+    int rc;
+    if ((rc = lp_ensure(&lp->k0, &lp->k0_cap, n, "sort keys"))) return rc;
+    if ((rc = lp_ensure(&lp->k1, &lp->k1_cap, n, "sort keys"))) return rc;
+    if ((rc = lp_ensure(&lp->r0, &lp->r0_cap, n, "sort rows"))) return rc;
+    return lp_ensure(&lp->r1, &lp->r1_cap, n, "sort rows");
+}
+
+void lp_free_pool(gm_levpart* lp) {
+    for (int c = 0; c < GM_LP_MAXCOPY; ++c) {
+        if (lp->table[c]) (void)hipFree(lp->table[c]);
+        if (lp->ord[c]) (void)hipFree(lp->ord[c]);
+        if (lp->bdesc[c]) (void)hipFree(lp->bdesc[c]);
+        lp->table[c] = nullptr;
+        lp->ord[c] = nullptr;
+        lp->bdesc[c] = nullptr;
+    }
+    lp->r = -1;
+    lp->n_copies = 0;
+}
+
+}  // namespace
+
+// The layout for radius r on guides of L bases: r + 1 blocks as even as possible (longer ones first), displacements
+// -floor(r / 2) .. floor(r / 2) as far as the displaced block stays inside the sequence.  Returns the number of copies
+// (0: not a usable layout) and, in *fraction, the modelled share of the pool a candidate's workgroups visit
+// (sum over copies of p_match ^ block length).
+int gm_lp_layout(int L, int r, double p_match, int* bstart, int* blen, int* copy_block, int* copy_shift, int* first_copy,
+                 double* fraction) {
+    const int B = r + 1;
+    if (r < 1 || B > GM_LP_MAXBLK || L < 2 * B) return 0;
+    const int sh = r / 2;
+    int pos = 0, n_copies = 0;
+    double f = 0.0;
+    for (int j = 0; j < B; ++j) {
+        const int len = L / B + (j < L % B ? 1 : 0);
+        if (len > 8) return 0;      // (4^8 buckets at most; such radii need no partition)
+        bstart[j] = pos;
+        blen[j] = len;
+        first_copy[j] = n_copies;
+        for (int d = -sh; d <= sh; ++d) {
+            if (pos + d < 0 || pos + d + len > L) continue;
+            if (n_copies >= GM_LP_MAXCOPY) return 0;
+            copy_block[n_copies] = j;
+            copy_shift[n_copies] = d;
+            ++n_copies;
+            f += std::pow(p_match, (double)len);
+        }
+        pos += len;
+    }
+    first_copy[B] = n_copies;
+    if (fraction) *fraction = f;
+    return n_copies;
+}
+
+int gm_lp_set_param(gm_index* idx, const char* name, int value, bool* known) {
+    *known = false;
+    if (std::strcmp(name, "lp_radius") != 0) return GM_OK;
+    *known = true;
+    if (value < -1 || value > 7) return gm_fail(GM_ERR_ARG, "lp_radius: -1 (never), 0 (choose), 1..7");
+    if (!idx->lp) idx->lp = new gm_levpart();
+    idx->lp->tune_radius = value;
+    idx->lp->plan_nq = -1;
+    return GM_OK;
+}
+
+void gm_lp_free(gm_index* idx) {
+    gm_levpart* lp = idx->lp;
+    if (!lp) return;
+    lp_free_pool(lp);
+    for (int j = 0; j < GM_LP_MAXBLK; ++j)
+        if (lp->cperm[j]) (void)hipFree(lp->cperm[j]);
+    void* bufs[] = {lp->k0, lp->k1, lp->r0, lp->r1, lp->sort_tmp, lp->off, lp->pad_off, lp->chunks, lp->keys};
+    for (void* p : bufs)
+        if (p) (void)hipFree(p);
+    delete lp;
+    idx->lp = nullptr;
+}
+
+gm_levpart* gm_lp_state(gm_index* idx) {
+    if (!idx->lp) idx->lp = new gm_levpart();
+    return idx->lp;
+}
+int gm_lp_tune_radius(gm_index* idx) { return gm_lp_state(idx)->tune_radius; }
+void gm_lp_plan_get(gm_index* idx, int64_t* nq, int* k, int* r) {
+    gm_levpart* lp = gm_lp_state(idx);
+    *nq = lp->plan_nq;
+    *k = lp->plan_k;
+    *r = lp->plan_r;
+}
+void gm_lp_plan_set(gm_index* idx, int64_t nq, int k, int r) {
+    gm_levpart* lp = gm_lp_state(idx);
+    lp->plan_nq = nq;
+    lp->plan_k = k;
+    lp->plan_r = r;
+}
+int64_t gm_lp_last_pairs(gm_index* idx) { return idx->lp ? idx->lp->last_pairs : 0; }
+
+// pool copies for radius r (kept until another radius is asked for)
+int gm_lp_prepare(gm_index* idx, int r, hipStream_t st) {
+    gm_levpart* lp = gm_lp_state(idx);
+    if (lp->r == r) return GM_OK;
+    lp_free_pool(lp);
+    const int L = idx->L;
+    double frac = 0.0;
+    const int n_copies = gm_lp_layout(L, r, 0.25, lp->bstart, lp->blen, lp->copy_block, lp->copy_shift, lp->first_copy, &frac);
+    if (n_copies < 1) return gm_fail(GM_ERR_ARG, "K2P: no layout for this radius / guide length");
+    lp->n_blocks = r + 1;
+    lp->sh = r / 2;
+    const int64_t n = idx->n_db;
+    int rc;
+    if ((rc = lp_sort_buffers(lp, n))) return rc;
+    constexpr int TT = GM_LP_TILE_TARGETS;
+    for (int c = 0; c < n_copies && rc == GM_OK; ++c) {
+        const int j = lp->copy_block[c], len = lp->blen[j], start = lp->bstart[j] + lp->copy_shift[c];
+        const int nb = 1 << (2 * len);
+        if ((rc = lp_ensure(&lp->off, &lp->off_cap, nb + 1, "bucket offsets"))) break;
+        if ((rc = lp_ensure(&lp->pad_off, &lp->pad_off_cap, nb + 1, "padded bucket offsets"))) break;
+        hipLaunchKernelGGL(k_lp_keys, lp_grid(n), dim3(256), 0, st, idx->d_db, n, start, len, lp->k0, lp->r0);
+        if ((rc = lp_sort(lp, n, 2 * len, st))) break;
+        hipLaunchKernelGGL(k_lp_offsets, lp_grid(nb + 1), dim3(256), 0, st, lp->k1, n, nb, lp->off);
+        std::vector<int32_t> off((size_t)nb + 1);
+        if (hipMemcpyAsync(off.data(), lp->off, sizeof(int32_t) * off.size(), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) {
+            rc = gm_fail(GM_ERR_DEVICE, "K2P bucket offsets read-back failed");
+            break;
+        }
+        std::vector<int2> bdesc((size_t)nb);
+        std::vector<int64_t> pad((size_t)nb + 1);
+        int64_t tiles = 0;
+        for (int v = 0; v < nb; ++v) {
+            const int cnt = off[(size_t)v + 1] - off[(size_t)v];
+            const int t = (cnt + TT - 1) / TT;
+            bdesc[(size_t)v] = make_int2((int)tiles, t);
+            pad[(size_t)v] = tiles * TT;
+            tiles += t;
+        }
+        pad[(size_t)nb] = tiles * TT;
+        if (tiles < 1) tiles = 1;
+        if (tiles * TT >= ((int64_t)1 << 31)) {
+            rc = gm_fail(GM_ERR_ARG, "K2P: padded pool copy too large");
+            break;
+        }
+        const int64_t n_pad = tiles * TT, n_groups = n_pad / gm::LK_GROUP;
+        const int64_t words = n_groups * gm::lk_group_words(L);
+        if (hipMalloc(reinterpret_cast<void**>(&lp->ord[c]), sizeof(uint32_t) * (size_t)n_pad) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&lp->table[c]), sizeof(uint32_t) * (size_t)words) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&lp->bdesc[c]), sizeof(int2) * (size_t)nb) != hipSuccess) {
+            rc = gm_fail(GM_ERR_ALLOC, "hipMalloc(K2P pool copy) failed");
+            break;
+        }
+        hipError_t e = hipMemcpyAsync(lp->bdesc[c], bdesc.data(), sizeof(int2) * bdesc.size(), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(lp->pad_off, pad.data(), sizeof(int64_t) * pad.size(), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemsetAsync(lp->ord[c], 0xff, sizeof(uint32_t) * (size_t)n_pad, st);
+        if (e != hipSuccess) {
+            rc = gm_fail(GM_ERR_DEVICE, std::string("K2P pool copy: ") + hipGetErrorString(e));
+            break;
+        }
+        hipLaunchKernelGGL(k_lp_scatter_ord, lp_grid(n), dim3(256), 0, st, lp->k1, lp->r1, n, lp->off, lp->pad_off, lp->ord[c]);
+        hipLaunchKernelGGL(k_lp_onehot, lp_grid(words), dim3(256), 0, st, idx->d_db, lp->ord[c], lp->table[c], n_groups, L);
+        if (hipGetLastError() != hipSuccess) rc = gm_fail(GM_ERR_DEVICE, "K2P pool-copy kernels failed to launch");
+        // (the host vectors are pageable: staged by the runtime before the copies return; the kernels read device memory)
+        if (hipStreamSynchronize(st) != hipSuccess && rc == GM_OK) rc = gm_fail(GM_ERR_DEVICE, "K2P pool-copy build failed");
+    }
+    if (rc != GM_OK) {
+        lp_free_pool(lp);
+        return rc;
+    }
+    lp->r = r;
+    lp->n_copies = n_copies;
+    return GM_OK;
+}
+
+// group the candidates (planes q) by every block's value and build the chunk table; *pairs = pairs the scan will evaluate
+int gm_lp_candidates(gm_index* idx, const uint2* q, int64_t n_q, hipStream_t st) {
+    gm_levpart* lp = gm_lp_state(idx);
+    if (lp->r < 1) return gm_fail(GM_ERR_ARG, "gm_lp_candidates: no copies prepared");
+    int rc;
+    if ((rc = lp_sort_buffers(lp, n_q > idx->n_db ? n_q : idx->n_db))) return rc;
+    std::vector<gm_lp_chunk> chunks;
+    chunks.reserve((size_t)(n_q / 64 + 4096) * (size_t)lp->n_blocks);
+    std::vector<std::vector<int2>> bd((size_t)lp->n_copies);
+    for (int c = 0; c < lp->n_copies; ++c) {      // bucket sizes of the copies (for the pair count; small tables)
+        const int nb = 1 << (2 * lp->blen[lp->copy_block[c]]);
+        bd[(size_t)c].resize((size_t)nb);
+        HIP_TRY(hipMemcpyAsync(bd[(size_t)c].data(), lp->bdesc[c], sizeof(int2) * (size_t)nb, hipMemcpyDeviceToHost, st));
+    }
+    int64_t pairs = 0;
+    for (int j = 0; j < lp->n_blocks; ++j) {
+        const int len = lp->blen[j], nb = 1 << (2 * len);
+        if ((rc = lp_ensure(&lp->cperm[j], &lp->cperm_cap[j], n_q, "candidate order"))) return rc;
+        if ((rc = lp_ensure(&lp->off, &lp->off_cap, nb + 1, "bucket offsets"))) return rc;
+        hipLaunchKernelGGL(k_lp_keys, lp_grid(n_q), dim3(256), 0, st, q, n_q, lp->bstart[j], len, lp->k0, lp->r0);
+        if ((rc = lp_sort(lp, n_q, 2 * len, st))) return rc;
+        hipLaunchKernelGGL(k_lp_offsets, lp_grid(nb + 1), dim3(256), 0, st, lp->k1, n_q, nb, lp->off);
+        HIP_TRY(hipMemcpyAsync(lp->cperm[j], lp->r1, sizeof(uint32_t) * (size_t)n_q, hipMemcpyDeviceToDevice, st));
+        std::vector<int32_t> off((size_t)nb + 1);
+        HIP_TRY(hipMemcpyAsync(off.data(), lp->off, sizeof(int32_t) * off.size(), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (int v = 0; v < nb; ++v) {
+            const int c0 = off[(size_t)v], c1 = off[(size_t)v + 1];
+            if (c1 <= c0) continue;
+            int64_t tiles = 0;
+            for (int c = lp->first_copy[j]; c < lp->first_copy[j + 1]; ++c) tiles += bd[(size_t)c][(size_t)v].y;
+            if (tiles == 0) continue;      // (no target carries these bases at any displacement: nothing to compare)
+            for (int c = c0; c < c1; c += 64) {
+                chunks.push_back(gm_lp_chunk{j, v, c, c1 - c < 64 ? c1 - c : 64});
+                pairs += tiles * GM_LP_TILE_TARGETS * 64;
+            }
+        }
+    }
+    lp->n_chunks = (int64_t)chunks.size();
+    lp->last_pairs = pairs;
+    if ((rc = lp_ensure(&lp->chunks, &lp->chunks_cap, lp->n_chunks, "K2P chunk table"))) return rc;
+    if (lp->n_chunks > 0) {
+        HIP_TRY(hipMemcpyAsync(lp->chunks, chunks.data(), sizeof(gm_lp_chunk) * chunks.size(), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));      // (the host vector goes out of scope)
+    }
+    return GM_OK;
+}
+
+// the K2P launch over the chunk table: raw lists per block in lp->keys ([n_blocks][n_q][kcap])
+int gm_lp_scan(gm_index* idx, const uint2* q, int64_t n_q, int k, int kcap, const int32_t* seed_d, const int32_t* seed_c, int seed_k,
+               hipStream_t st, const uint32_t** keys_out, int* n_lists) {
+    gm_levpart* lp = gm_lp_state(idx);
+    int rc;
+    if ((rc = lp_ensure(&lp->keys, &lp->keys_cap, (int64_t)lp->n_blocks * n_q * kcap, "K2P block lists"))) return rc;
+    // (a candidate is in exactly one chunk per block unless no target shares the block's bases: those lists must read "empty")
+    HIP_TRY(hipMemsetAsync(lp->keys, 0xff, sizeof(uint32_t) * (size_t)((int64_t)lp->n_blocks * n_q * kcap), st));
+    gm_lp_copies P{};
+    for (int c = 0; c < lp->n_copies; ++c) {
+        P.table[c] = lp->table[c];
+        P.ord[c] = lp->ord[c];
+        P.bdesc[c] = lp->bdesc[c];
+    }
+    for (int j = 0; j < lp->n_blocks; ++j) P.cperm[j] = lp->cperm[j];
+    for (int j = 0; j <= lp->n_blocks; ++j) P.first_copy[j] = lp->first_copy[j];
+    P.n_blocks = lp->n_blocks;
+    *keys_out = lp->keys;
+    *n_lists = lp->n_blocks;
+    if (lp->n_chunks == 0) return GM_OK;
+    switch (idx->L) {
+#define GM_CASE(LEN) \
+    case LEN: return gm_launch_lvp_L##LEN(&P, lp->chunks, lp->n_chunks, q, n_q, k, kcap, seed_d, seed_c, seed_k, lp->keys, st);
+        GM_FOR_EACH_LEN(GM_CASE)
+#undef GM_CASE
+        default: return gm_fail(GM_ERR_ARG, "K2P: guidelen out of range");
+    }
+}

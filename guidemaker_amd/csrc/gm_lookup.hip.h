@@ -382,4 +382,35 @@ __global__ void k_merge_lists_split(const uint32_t* __restrict__ keys, int n_seg
     if (sub == 0 && valid) list.store(k, qi, ids, dists, counts, nearest != 0);
 }
 
+// fold the per-block raw lists [n_lists][n_q][KCAP] of K2P into the top k: a target found under several blocks /
+// displacements is taken once.  SPLIT lanes per candidate.
+template <int KCAP, int SPLIT>
+__global__ void k_merge_lists_unique(const uint32_t* __restrict__ keys, int n_lists, int64_t n_q, int k,
+                                     int32_t* __restrict__ ids, int32_t* __restrict__ dists, int32_t* __restrict__ counts) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int sub = (int)(t % SPLIT);
+    const int64_t qi_raw = t / SPLIT;
+    const bool valid = qi_raw < n_q;
+    const int64_t qi = valid ? qi_raw : n_q - 1;
+    RegList<KCAP> list;
+    list.init(k, nullptr, 0);
+    for (int s = sub; s < n_lists; s += SPLIT) {
+        const uint32_t* in = keys + ((int64_t)s * n_q + qi) * KCAP;
+#pragma unroll
+        for (int i = 0; i < KCAP; ++i) {
+            const uint32_t v = in[i];
+            if (v != 0u && v < list.v[KCAP - 1]) list.insert_unique(v - 1u);
+        }
+    }
+#pragma unroll
+    for (int off = SPLIT / 2; off >= 1; off >>= 1) {
+#pragma unroll
+        for (int i = 0; i < KCAP; ++i) {
+            const uint32_t v = __shfl_down(list.v[i], off, SPLIT);
+            if (sub < off && v != 0u && v < list.v[KCAP - 1]) list.insert_unique(v - 1u);
+        }
+    }
+    if (sub == 0 && valid) list.store(k, qi, ids, dists, counts, false);
+}
+
 }  // namespace gm

@@ -55,3 +55,24 @@ __host__ __device__ constexpr int gm_pg_buckets_of(int len, int t) {      // tar
 struct gm_pg_chunk {
     int b, v, c0, cn, e_lo, e_hi, lst, pad;
 };
+
+// ---- K2P: the pigeonhole partition for Levenshtein (gm_levpart.hip; kernel k_leven_part_bs in gm_leven_bs.hip.h) ----
+// Two sequences of the same length within edit distance r: cut the candidate into r + 1 blocks, at least one of them is
+// untouched by every edit and appears in the target unchanged, displaced by at most floor(r / 2) positions (an alignment
+// of equal-length sequences spends as many insertions as deletions).  Per block j and displacement d the pool is kept
+// sorted by the bases it carries at the block's positions + d ("copy"); a chunk of candidates with the block value v is
+// compared -- by the bit-sliced banded DP of K2B -- with bucket v of every copy of its block only.
+constexpr int GM_LP_MAXBLK = 8;       // blocks (radius r <= 7)
+constexpr int GM_LP_MAXCOPY = 56;     // (block, displacement) pairs: 8 x 7
+constexpr int GM_LP_TILE_TARGETS = 256;      // buckets of a copy are padded to whole K2B tiles (4 groups of 64)
+struct gm_lp_copies {                 // passed to the kernel by value
+    const uint32_t* table[GM_LP_MAXCOPY];     // one-hot table of the copy (K1L group format, all L positions; padding all-zero)
+    const uint32_t* ord[GM_LP_MAXCOPY];       // position in the copy -> pool id (0xffffffff = padding)
+    const int2* bdesc[GM_LP_MAXCOPY];         // bucket v -> (first tile, tiles)
+    const uint32_t* cperm[GM_LP_MAXBLK];      // candidates sorted by block j's value: sorted position -> candidate row
+    int first_copy[GM_LP_MAXBLK + 1];         // the copies of block j: [first_copy[j], first_copy[j + 1])
+    int n_blocks;
+};
+struct gm_lp_chunk {                  // one workgroup: cn (<= 64) candidates from sorted position c0 of block j, all with value v
+    int j, v, c0, cn;
+};

@@ -667,6 +667,24 @@ struct gm_pigeon {
 
 namespace {
 
+// the device counters + the host mailbox of the read-backs (also used by the Levenshtein passes, which may run without a
+// K1P layout ever having been prepared on the handle)
+int pg_ensure_counters(gm_pigeon* pg) {
+    if (!pg->ctr) {
+        if (hipMalloc(reinterpret_cast<void**>(&pg->ctr), sizeof(PgCounters)) != hipSuccess)
+            return gm_fail(GM_ERR_ALLOC, "hipMalloc(K1P counters) failed");
+        if (hipMemset(pg->ctr, 0, sizeof(PgCounters)) != hipSuccess) return gm_fail(GM_ERR_DEVICE, "hipMemset(K1P counters) failed");
+    }
+    if (!pg->box) {
+        if (hipHostMalloc(reinterpret_cast<void**>(&pg->box), sizeof(PgMailbox), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
+            return gm_fail(GM_ERR_ALLOC, "hipHostMalloc(K1P mailbox) failed");
+        std::memset(pg->box, 0, sizeof(PgMailbox));
+        if (hipHostGetDevicePointer(reinterpret_cast<void**>(&pg->box_dev), pg->box, 0) != hipSuccess)
+            return gm_fail(GM_ERR_ALLOC, "hipHostGetDevicePointer(K1P mailbox) failed");
+    }
+    return GM_OK;
+}
+
 int sort_pairs(gm_pigeon* pg, int64_t n, int bits, hipStream_t st) {
     size_t bytes = 0;
     HIP_TRY(rocprim::radix_sort_pairs(nullptr, bytes, pg->k0, pg->k1, pg->r0, pg->r1, (size_t)n, 0u, (unsigned)bits, st));
@@ -1224,15 +1242,7 @@ int gm_pg_prepare(gm_index* idx, const gm_pg_layout* lay, hipStream_t st) {
     }
     int rc;
     if ((rc = ensure_sort_buffers(pg, n))) return rc;
-    if (!pg->ctr && hipMalloc(reinterpret_cast<void**>(&pg->ctr), sizeof(PgCounters)) != hipSuccess)
-        return gm_fail(GM_ERR_ALLOC, "hipMalloc(K1P counters) failed");
-    if (!pg->box) {
-        if (hipHostMalloc(reinterpret_cast<void**>(&pg->box), sizeof(PgMailbox), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
-            return gm_fail(GM_ERR_ALLOC, "hipHostMalloc(K1P mailbox) failed");
-        std::memset(pg->box, 0, sizeof(PgMailbox));
-        if (hipHostGetDevicePointer(reinterpret_cast<void**>(&pg->box_dev), pg->box, 0) != hipSuccess)
-            return gm_fail(GM_ERR_ALLOC, "hipHostGetDevicePointer(K1P mailbox) failed");
-    }
+    if ((rc = pg_ensure_counters(pg))) return rc;
     // every pair of a bucket agrees on the copy's own block (a neighbour bucket differs there on known positions):
     // each copy's table leaves its own block out and the scan of that copy's chunks runs the kernel instantiated for
     // the remaining positions (at least 10: the look-up kernels start there)
@@ -1862,8 +1872,10 @@ int gm_pg_read_bad(gm_index* idx, int64_t* n_bad, hipStream_t st) {
 }
 
 int gm_pg_collect_short(gm_index* idx, int64_t n, int need, const int32_t* counts, hipStream_t st) {
+    if (!idx->pg) idx->pg = new gm_pigeon();
     gm_pigeon* pg = idx->pg;
     int rc;
+    if ((rc = pg_ensure_counters(pg))) return rc;
     if ((rc = ensure(&pg->inc, &pg->inc_cap, n, "incomplete rows"))) return rc;
     hipLaunchKernelGGL(k_collect_short, grid_for(n), dim3(256), 0, st, counts, n, need, pg->inc, &pg->ctr->n_bad);
     HIP_TRY(hipGetLastError());

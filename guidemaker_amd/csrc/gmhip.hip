@@ -284,6 +284,131 @@ __global__ __launch_bounds__(256) void k_lev_gather_seeds(const uint32_t* __rest
     if (j < n) seeds[j] = (int32_t)thr_all[inc[j]] - 1;
 }
 
+// ---- K2P (gm_levpart.hip): the pigeonhole partition for Levenshtein ----
+// every stride-th candidate with its Hamming seeds, compacted (the planner's sample)
+__global__ __launch_bounds__(256) void k_lev_sample_rows(const uint2* __restrict__ q, const int32_t* __restrict__ dists,
+                                                         const int32_t* __restrict__ counts, int64_t stride, int64_t n_s, int k,
+                                                         uint2* __restrict__ q_s, int32_t* __restrict__ d_s, int32_t* __restrict__ c_s) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_s * k) return;
+    const int64_t j = t / k;
+    const int s = (int)(t % k);
+    d_s[t] = dists[j * stride * k + s];
+    if (s == 0) {
+        q_s[j] = q[j * stride];
+        c_s[j] = counts[j * stride];
+    }
+}
+
+// rows the partition of radius r cannot vouch for (list not full, or its k-th entry beyond r): count 0 = "take the second pass"
+__global__ __launch_bounds__(256) void k_lev_unvouched(int32_t* __restrict__ counts, const int32_t* __restrict__ dists, int64_t n,
+                                                       int k, int r) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && (counts[i] < k || dists[i * k + (k - 1)] > r)) counts[i] = 0;
+}
+
+int launch_merge_unique(int kcap, const uint32_t* keys, int n_lists, int64_t n_q, int k, int32_t* ids, int32_t* dists,
+                        int32_t* counts, hipStream_t st) {
+    constexpr int SP = 4;
+    const dim3 grid((unsigned)((n_q * SP + 255) / 256)), block(256);
+    if (kcap == 10) hipLaunchKernelGGL((gm::k_merge_lists_unique<10, SP>), grid, block, 0, st, keys, n_lists, n_q, k, ids, dists, counts);
+    else hipLaunchKernelGGL((gm::k_merge_lists_unique<20, SP>), grid, block, 0, st, keys, n_lists, n_q, k, ids, dists, counts);
+    HIP_TRY(hipGetLastError());
+    return GM_OK;
+}
+
+// Partitioned first pass of run_leven_lookup.  ids / dists / counts hold the Hamming k-NN of the candidates (the seeds:
+// lev <= hamming) on entry and the partition's result on return (*used); rows it cannot vouch for come back with
+// count 0 and take the caller's second pass under their own seeds.  The radius is chosen from a sample: 1 024 candidates
+// through the plain K2B scan give the distribution of the k-th EDIT distance, and r minimises
+// [share of the pool the layout of radius r visits] x 1.2 + [share of the rows whose k-th neighbour lies beyond r].
+int run_leven_partition(gm_index* idx, int64_t n_q, int k, int kcap, int32_t* ids, int32_t* dists, int32_t* counts, hipStream_t st,
+                        bool* used, int* r_used) {
+    *used = false;
+    const int tune = gm_lp_tune_radius(idx);
+    if (tune < 0 || (kcap != 10 && kcap != 20) || idx->L < 12) return GM_OK;
+    int rc;
+    int r = tune;
+    if (r == 0) {
+        if (idx->n_db < 65536 || n_q < 8192) return GM_OK;
+        int64_t p_nq = -1;
+        int p_k = -1, p_r = 0;
+        gm_lp_plan_get(idx, &p_nq, &p_k, &p_r);
+        if (p_nq != n_q || p_k != k) {
+            double p_match = 0.25;
+            if ((rc = gm_pg_pool_stats(idx, st, &p_match))) return rc;
+            const int64_t n_s = 1024, stride = n_q / n_s;
+            uint2* q_s = nullptr;
+            int32_t *d_s = nullptr, *c_s = nullptr, *i_s = nullptr;
+            if (hipMalloc(reinterpret_cast<void**>(&q_s), sizeof(uint2) * n_s) != hipSuccess ||
+                hipMalloc(reinterpret_cast<void**>(&d_s), sizeof(int32_t) * n_s * k) != hipSuccess ||
+                hipMalloc(reinterpret_cast<void**>(&i_s), sizeof(int32_t) * n_s * k) != hipSuccess ||
+                hipMalloc(reinterpret_cast<void**>(&c_s), sizeof(int32_t) * n_s) != hipSuccess) {
+                (void)hipFree(q_s); (void)hipFree(d_s); (void)hipFree(i_s); (void)hipFree(c_s);
+                return fail(GM_ERR_ALLOC, "hipMalloc(K2P sample) failed");
+            }
+            hipLaunchKernelGGL(k_lev_sample_rows, dim3((unsigned)((n_s * k + 255) / 256)), dim3(256), 0, st, idx->d_q, dists, counts,
+                               stride, n_s, k, q_s, d_s, c_s);
+            const int64_t n_tiles = idx->n_lk_tiles;
+            int64_t want = 64 < n_tiles ? 64 : n_tiles;
+            const int tps = (int)((n_tiles + want - 1) / want);
+            const int n_seg = (int)((n_tiles + tps - 1) / tps);
+            rc = ensure_u32(&idx->d_keys2, &idx->keys2_cap, (int64_t)n_seg * n_s * kcap);
+            gm_lv_opt o{};
+            o.q = q_s;
+            if (!rc) rc = launch_lv_by_len(idx, 1, kcap, n_s, k, n_seg, tps, d_s, c_s, k, idx->d_keys2, st, &o);
+            if (!rc) rc = launch_merge(kcap, idx->d_keys2, n_seg, n_s, k, i_s, d_s, c_s, false, st);
+            std::vector<int32_t> hd((size_t)(n_s * k)), hc((size_t)n_s);
+            if (!rc && (hipMemcpyAsync(hd.data(), d_s, sizeof(int32_t) * hd.size(), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                        hipMemcpyAsync(hc.data(), c_s, sizeof(int32_t) * hc.size(), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                        hipStreamSynchronize(st) != hipSuccess))
+                rc = fail(GM_ERR_DEVICE, "K2P sample read-back failed");
+            (void)hipFree(q_s); (void)hipFree(d_s); (void)hipFree(i_s); (void)hipFree(c_s);
+            if (rc) return rc;
+            int best_r = 0;
+            double best = 0.6;      // the partition has to be clearly cheaper than the plain pass
+            for (int rr = 1; rr <= 7; ++rr) {
+                int bs[GM_LP_MAXBLK], bl[GM_LP_MAXBLK], cb[GM_LP_MAXCOPY], cs[GM_LP_MAXCOPY], fc[GM_LP_MAXBLK + 1];
+                double frac = 0.0;
+                if (!gm_lp_layout(idx->L, rr, p_match, bs, bl, cb, cs, fc, &frac)) continue;
+                int64_t beyond = 0;
+                for (int64_t j = 0; j < n_s; ++j)
+                    if (hc[(size_t)j] < k || hd[(size_t)(j * k + k - 1)] > rr) ++beyond;
+                const double cost = 1.2 * frac + (double)beyond / (double)n_s;
+                if (std::getenv("GM_DEBUG"))
+                    fprintf(stderr, "[gm] K2P radius %d: visits %.3f of the pool, %.3f of the sample beyond it -> cost %.3f\n", rr, frac,
+                            (double)beyond / (double)n_s, cost);
+                if (cost < best) {
+                    best = cost;
+                    best_r = rr;
+                }
+            }
+            gm_lp_plan_set(idx, n_q, k, best_r);
+            p_r = best_r;
+        }
+        r = p_r;
+    }
+    if (r <= 0) return GM_OK;
+    if ((rc = gm_lp_prepare(idx, r, st))) {
+        if (rc == GM_ERR_ARG || rc == GM_ERR_ALLOC) return GM_OK;      // no layout for this length / no room: the plain pass
+        return rc;
+    }
+    if ((rc = gm_lp_candidates(idx, idx->d_q, n_q, st))) return rc;
+    const uint32_t* keys = nullptr;
+    int n_lists = 0;
+    if ((rc = timing_begin(idx, st))) return rc;
+    idx->last_kernel = "k_leven_part_bs";
+    if ((rc = gm_lp_scan(idx, idx->d_q, n_q, k, kcap, dists, counts, k, st, &keys, &n_lists))) return rc;
+    if ((rc = timing_end(idx, st, n_q * idx->n_db))) return rc;
+    idx->last_evaluated = gm_lp_last_pairs(idx);
+    if ((rc = launch_merge_unique(kcap, keys, n_lists, n_q, k, ids, dists, counts, st))) return rc;
+    hipLaunchKernelGGL(k_lev_unvouched, dim3((unsigned)((n_q + 255) / 256)), dim3(256), 0, st, counts, dists, n_q, k, r);
+    HIP_TRY(hipGetLastError());
+    *used = true;
+    *r_used = r;
+    return GM_OK;
+}
+
 int run_leven_lookup(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* dists, int32_t* counts,
                      int32_t* d1, hipStream_t st) {
     const bool nearest = d1 != nullptr;
@@ -325,10 +450,14 @@ int run_leven_lookup(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* d
     // under their own seeds.  The kernel takes the decision from a counter on the device: no read-back for it.
     const int band = ((3 * idx->L + 4) / 8) / 2;      // lvb_band(L), gm_leven_bs.hip.h
     const int cap_thr = 2 * (band - 1) + 2;
-    const bool two_pass = !nearest && algo == 1 && seeded && band - 1 >= 2 && idx->lv_two_pass && n_q >= 4096;
+    bool two_pass = !nearest && algo == 1 && seeded && band - 1 >= 2 && idx->lv_two_pass && n_q >= 4096;
+    // the partitioned pass (K2P) where the planner finds a radius that pays; it needs the kept bounds for its second pass too
+    // (the Hamming k-NN of the candidates are in ids / dists / counts whichever scan produced them)
+    const bool try_part = !nearest && algo == 1 && gm_lp_tune_radius(idx) >= 0 &&
+                          (gm_lp_tune_radius(idx) > 0 || (idx->n_db >= 65536 && n_q >= 8192));
     gm_lv_opt opt{};
     uint32_t* thr_all = nullptr;
-    if (two_pass) {
+    if (two_pass || try_part) {
         // [n_q bounds][n_q compact seeds][1 counter]
         if ((rc = ensure_u32(&idx->d_lvthr, &idx->lvthr_cap, 2 * n_q + 4))) return rc;
         thr_all = idx->d_lvthr;
@@ -337,9 +466,18 @@ int run_leven_lookup(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* d
         hipLaunchKernelGGL(k_lev_seed_stats, dim3((unsigned)((n_q + 255) / 256)), dim3(256), 0, st, dists, counts, n_q, k, idx->L,
                            cap_thr, thr_all, cnt);
         HIP_TRY(hipGetLastError());
-        opt.cap_cnt = cnt;
-        opt.cap_thr = cap_thr;
+        if (two_pass) {
+            opt.cap_cnt = cnt;
+            opt.cap_thr = cap_thr;
+        }
     }
+    bool part_used = false;
+    if (try_part) {
+        int r_part = 0;
+        if ((rc = run_leven_partition(idx, n_q, k, kcap, ids, dists, counts, st, &part_used, &r_part))) return rc;
+        if (part_used) two_pass = true;      // (the rows it does not vouch for -- count 0 -- take the second pass below)
+    }
+    if (!part_used) {
     rc = timing_begin(idx, st);
     if (rc) return rc;
     idx->last_kernel = algo == 1 ? (nearest ? "k_leven_knn_bs(nearest)" : "k_leven_knn_bs")
@@ -351,13 +489,14 @@ int run_leven_lookup(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* d
     if (rc) return rc;
     rc = nearest ? launch_merge(kcap, idx->d_keys2, n_seg, n_q, 1, nullptr, d1, nullptr, true, st)
                  : launch_merge(kcap, idx->d_keys2, n_seg, n_q, k, ids, dists, counts, false, st);
+    }
     if (rc || !two_pass) return rc;
     // second pass: the candidates whose list did not fill (none when the first pass ran under the seeds themselves)
     if ((rc = gm_pg_collect_short(idx, n_q, k, counts, st))) return rc;
     int64_t n2 = 0;
     if ((rc = gm_pg_read_bad(idx, &n2, st))) return rc;
     idx->last_incomplete = n2;
-    if (n2 * 4 > n_q) idx->lv_two_pass = 0;      // the lowered bound left a quarter of the lists short on this pool: not again
+    if (n2 * 4 > n_q && !part_used) idx->lv_two_pass = 0;      // the lowered bound left a quarter of the lists short on this pool: not again
     if (n2 == 0) return GM_OK;
     const uint2* q2 = nullptr;
     int32_t *ids2 = nullptr, *dists2 = nullptr, *counts2 = nullptr;
@@ -1163,6 +1302,7 @@ void gm_index_free(gm_index* idx) {
     (void)hipSetDevice(idx->device);
     if (idx->d_db) (void)hipFree(idx->d_db);
     if (idx->d_vert) (void)hipFree(idx->d_vert);
+    gm_lp_free(idx);
     gm_pg_free(idx);
     for (auto& lv : idx->pg_deeper) {      // the deeper cascade levels' K1P state
         idx->pg = lv.pg;
@@ -1208,6 +1348,11 @@ int gm_set_param(gm_index* idx, const char* name, int value) {
     if (std::strcmp(name, "lv_two_pass") == 0) {
         idx->lv_two_pass = value;
         return GM_OK;
+    }
+    {
+        bool known = false;
+        const int rc = gm_lp_set_param(idx, name, value, &known);
+        if (known) return rc;
     }
     return gm_pg_set_param(idx, name, value);
 }

@@ -847,6 +847,55 @@ def test_cascade_of_k1p_levels_is_exact(oracle, n, L, k, planted, lay1, lay2):
         idx.close()
 
 
+@pytest.mark.parametrize("n,L,k,radius,planted", [(60_000, 20, 5, 3, 0.05), (60_000, 23, 5, 4, 0.05), (90_000, 23, 10, 5, 0.03),
+                                                   (50_000, 20, 10, 2, 0.1), (70_000, 27, 5, 6, 0.05), (40_000, 16, 20, 3, 0.05)])
+def test_leven_partition_is_exact(oracle, n, L, k, radius, planted):
+    """K2P, the pigeonhole partition for Levenshtein (gm_set_param "lp_radius" forces its radius; the planner takes it only
+    on pools of >= 65 536 targets where a sample says it pays): r + 1 blocks, a target within r carries one of them
+    unchanged, displaced by at most floor(r / 2).  Rows it vouches for (k-th entry within r) are final, the others take
+    the second pass under their Hamming seeds.  Against the plain K2B scan ("lp_radius" = -1), the single-pass scan and
+    the oracle on a sample that favours rows with near neighbours (planted near-duplicates incl. indels)."""
+    rng = np.random.default_rng(1500 + L + k)
+    codes = rng.integers(0, 4, size=(n, L), dtype=np.uint8)
+    m = int(n * planted)
+    dst, src = rng.integers(0, n, size=m), rng.integers(0, n, size=m)
+    codes[dst] = codes[src]
+    for i in range(m):      # 1 .. 3 edits per planted copy: substitutions and (shift-making) indels
+        row = codes[dst[i]].tolist()
+        for _ in range(int(rng.integers(1, 4))):
+            kind, pos = int(rng.integers(0, 3)), int(rng.integers(0, L))
+            if kind == 0:
+                row[pos] = int(rng.integers(0, 4))
+            elif kind == 1:
+                row = row[:pos] + row[pos + 1:] + [int(rng.integers(0, 4))]      # deletion (+ a base at the end)
+            else:
+                row = (row[:pos] + [int(rng.integers(0, 4))] + row[pos:])[:L]   # insertion (the last base falls off)
+        codes[dst[i]] = row
+    db = np.unique(core.pack_codes(codes))
+    rng.shuffle(db)
+    q = np.concatenate([db[: min(len(db), 20_000)], _random_packed(1500, L, seed=80)])
+    idx = _lib.Index(db, L, _lib.METRIC_LEVEN)
+    try:
+        idx.set_param("lp_radius", radius)
+        ids, dists, counts = idx.knn(q, k)
+        assert idx.last_kernel()[0] == "k_leven_part_bs"
+        evaluated, second = idx.last_evaluated()
+        assert evaluated > 0      # (pairs incl. the padding of the buckets to whole 256-target tiles)
+        idx.set_param("lp_radius", -1)
+        i0, d0, c0 = idx.knn(q, k)
+        assert idx.last_kernel()[0] == "k_leven_knn_bs"
+        assert (i0 == ids).all() and (d0 == dists).all() and (c0 == counts).all()
+        idx.set_param("lv_two_pass", 0)
+        i1, d1, c1 = idx.knn(q, k)
+        assert (i1 == ids).all() and (d1 == dists).all() and (c1 == counts).all()
+        near = np.flatnonzero(dists[:, 1] <= radius)[:200]
+        rows = np.unique(np.concatenate([near, rng.choice(q.shape[0], size=100, replace=False)]))
+        oi, od, oc = oracle.knn(_packed_to_bytes(db, L), _packed_to_bytes(q[rows], L), L, "leven", k)
+        assert (oc == counts[rows]).all() and (od == dists[rows]).all() and (oi == ids[rows]).all()
+    finally:
+        idx.close()
+
+
 @pytest.mark.parametrize("n,k,cut", [(500_000, 20, 0), (500_000, 20, 25), (500_000, 20, 4), (300_000, 5, 30), (300_000, 2, 10)])
 def test_id_cutoff_is_exact(oracle, n, k, cut):
     """Hits at the layout's radius only from targets with ids below a cut-off ("pg_cut": 0 = the library's choice, else

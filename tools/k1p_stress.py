@@ -80,8 +80,12 @@ def main():
             k = int(rng.choice([2, 3, 5, 10]))
             idx = _lib.Index(db, L, _lib.METRIC_LEVEN)
             try:
+                lpr = int(rng.choice([0, 0, 2, 3, 4, 5]))      # K2P (the Levenshtein partition) with a forced radius
+                if lpr:
+                    idx.set_param("lp_radius", lpr)
                 got = idx.knn(q, k)
                 name, resc = idx.last_kernel()[0], idx.last_evaluated()[1]
+                idx.set_param("lp_radius", -1)
                 idx.set_param("lv_two_pass", 0)
                 want = idx.knn(q, k)
             finally:
