@@ -242,7 +242,12 @@ int gm_set_variant(gm_index* idx, int variant);
  *   independent-base model of the pool's composition alone (A/B, tests).  The result is exact either way;
  *   "pg_msplit": lanes per candidate in K1P's merge (0 = choose, 1, 2, 4);
  *   "pg_debug": timing experiments only (bit 0: the scan skips its list stores; bit 1: the scan accepts no hit at
- *   all -- results are then WRONG). */
+ *   all -- results are then WRONG);
+ *   "pg_cascade": K1P levels for the rows a pass leaves short: 0 = never (they take the plain / prefix re-scan), 1 =
+ *   when the planner's sample says a deeper level pays (default), 2 = whenever >= 64 rows are left (tests);
+ *   "pg_layout2": forced layout of the deeper levels, digits as "pg_layout" (tests);
+ *   "lp_radius": K2P, the displaced-block partition of the Levenshtein scan: -1 = never, 0 = choose from a sample on
+ *   pools of >= 65 536 targets (default), 1 .. 7 = that radius (tests). */
 int gm_set_param(gm_index* idx, const char* name, int value);
 
 #ifdef __cplusplus

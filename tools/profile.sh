@@ -12,7 +12,7 @@ export TMPDIR=/tmp
 if [ "$WL" = "cfd" ]; then      # the CFD kernel: tools/cfd_bench.py (50 M device-resident pairs)
   CMD="python3 tools/cfd_bench.py --rounds 5 --no-cpu $*"
 else
-  CMD="python3 bench.py --workload $WL --steps 5 --warmup 2 --no-cpu-baseline $*"
+  CMD="python3 bench.py --workload $WL --steps 5 --warmup 2 --no-cpu-baseline --extra none $*"
 fi
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o p --output-format csv -- $CMD > $OUT/stats.log 2>&1
 echo "[$TAG] stats pass done"
