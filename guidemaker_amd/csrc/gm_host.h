@@ -159,6 +159,7 @@ const gm_pigeon* gm_pg_state(const gm_index* idx);
 int gm_pg_sample_rows(gm_index* idx, int64_t n, int64_t stride, hipStream_t st);
 bool gm_pg_sampling(const gm_index* idx);
 void gm_pg_expect_short(gm_index* idx, double share);      // (of the candidates, at the planned layout's radius)
+void gm_pg_expect_hits(gm_index* idx, double hits);        // (targets within that radius per candidate, from the sample; 0 = unknown)
 bool gm_pg_layout_make(int L, int B, int X, int lenx, int n2, gm_pg_layout* out);
 int gm_pg_layout_radius(const gm_pg_layout& lay);
 bool gm_pg_layout_forced(const gm_index* idx, gm_pg_layout* out);

@@ -720,6 +720,29 @@ static int run_pigeon_level(gm_index* idx, int level, bool nearest, int64_t n_q,
                 fprintf(stderr, " cost %.4f, expects %.4f short%s\n", cost, expect, idx->plan_cascade ? " -> deeper level" : "");
             }
             gm_pg_expect_short(idx, expect);
+            {      // targets within the planned radius per candidate of THIS level (sample rows beyond the parent's radius)
+                double hits = 0.0;
+                if (idx->plan_found && have_smp) {
+                    const int r = gm_pg_layout_radius(idx->plan_lay), rr = r < GM_PG_SAMPLE_BINS ? r : GM_PG_SAMPLE_BINS - 1;
+                    double sum = 0.0;
+                    int rows = 0;
+                    for (int j = 0; j < smp.n; ++j) {
+                        const uint32_t* c = smp.cum + (size_t)j * GM_PG_SAMPLE_BINS;
+                        int kth = GM_PG_SAMPLE_BINS;
+                        for (int dd = 0; dd < GM_PG_SAMPLE_BINS; ++dd)
+                            if (c[dd] >= (uint32_t)keff) {
+                                kth = dd;
+                                break;
+                            }
+                        if (kth <= smp.min_kth) continue;
+                        sum += (double)c[rr];
+                        ++rows;
+                    }
+                    hits = rows ? sum / rows : 0.0;
+                    for (int e = GM_PG_SAMPLE_BINS - 1; e < r; ++e) hits *= 4.0;      // (beyond the histogram: extrapolated)
+                }
+                gm_pg_expect_hits(idx, hits);
+            }
             idx->pg_flooded_k1 = 0;      // (what a previous candidate set did to the hit lists says nothing about this one)
             idx->plan_cost = cost;
             idx->plan_p_short = p_short;
@@ -783,7 +806,9 @@ static int run_pigeon_level(gm_index* idx, int level, bool nearest, int64_t n_q,
         // radius the majority needs) -> a deeper K1P level over the compact rows, planned for THEIR number and the
         // conditional distribution of their k-th neighbour; what that level leaves takes its own re-scan paths.
         if (level + 1 < GM_PG_LEVELS && idx->pg_cascade != 0 && idx->pg_flooded_k1 != keff + 1 &&
-            (idx->pg_cascade == 2 ? n_inc >= 64 : (n_inc >= 4096 && !idx->plan_p_short.empty()))) {
+            (idx->pg_cascade == 2 ? n_inc >= 64
+                                  : (n_inc >= 4096 && !idx->plan_p_short.empty() &&
+                                     (idx->plan_cascade != 0 || n_inc >= 16384)))) {      // (the plan counted on a deeper level, or far more rows are short than it expected)
             std::vector<double> ps2;
             if (!idx->plan_p_short.empty()) {
                 const int L = idx->L;
