@@ -1933,10 +1933,12 @@ int gm_pg_sample_hist(gm_index* idx, int64_t n, hipStream_t st, std::vector<uint
     if ((rc = ensure(&pg->shist, &pg->shist_cap, n * PG_SAMPLE_BINS, "sample histogram"))) return rc;
     HIP_TRY(hipMemsetAsync(pg->shist, 0, sizeof(uint32_t) * (size_t)(n * PG_SAMPLE_BINS), st));
     const size_t lds = sizeof(uint32_t) * (size_t)(n * (2 + PG_SAMPLE_BINS));
-    static bool attr_set = false;
-    if (!attr_set) {
+    // (function attributes belong to a device: gm_multi_* drives several devices from one process)
+    static bool attr_set[64] = {};
+    const int dev = idx->device >= 0 && idx->device < 64 ? idx->device : 0;
+    if (!attr_set[dev]) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sample_hist), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_set[dev] = true;
     }
     hipLaunchKernelGGL(k_sample_hist, dim3((unsigned)(idx->n_simd / 4)), dim3(1024), lds, st, idx->d_db, idx->n_db, pg->q2, (int)n,
                        pg->shist);
