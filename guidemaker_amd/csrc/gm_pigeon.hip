@@ -317,18 +317,20 @@ __global__ __launch_bounds__(1024) void k_cand_scatter(const uint2* __restrict__
         __syncthreads();
         // the workgroup's base in every bucket it touched: the returning atomics of a thread's (up to 16) entries are
         // independent -- issue them back to back instead of one memory round trip per loop iteration
-        int cs[16], bs[16];
+        for (int p0 = 0; p0 < n_ent; p0 += 16 * 1024) {      // (passes of 16 entries per thread: up to 36 864 entries)
+            int cs[16], bs[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int e = threadIdx.x + j * 1024;
-            cs[j] = e < n_ent ? s_cnt[e] : 0;
-        }
+            for (int j = 0; j < 16; ++j) {
+                const int e = p0 + threadIdx.x + j * 1024;
+                cs[j] = e < n_ent ? s_cnt[e] : 0;
+            }
 #pragma unroll
-        for (int j = 0; j < 16; ++j) bs[j] = cs[j] != 0 ? atomicAdd(&cursor[e_lo + threadIdx.x + j * 1024], cs[j]) : 0;
+            for (int j = 0; j < 16; ++j) bs[j] = cs[j] != 0 ? atomicAdd(&cursor[e_lo + p0 + threadIdx.x + j * 1024], cs[j]) : 0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int e = threadIdx.x + j * 1024;
-            if (e < n_ent) s_cnt[e] = bs[j];
+            for (int j = 0; j < 16; ++j) {
+                const int e = p0 + threadIdx.x + j * 1024;
+                if (e < n_ent) s_cnt[e] = bs[j];
+            }
         }
         __syncthreads();
     }
@@ -1482,7 +1484,20 @@ int gm_pg_candidates(gm_index* idx, int64_t n_q, hipStream_t st) {
     // tiles of 1024 candidates per workgroup: as many as leave ~128 workgroups
     const int tiles = n_q >= (int64_t)1024 * 128 * 4 ? 4 : (n_q >= (int64_t)1024 * 128 * 2 ? 2 : 1);
     const dim3 cgrid = grid_for(n_q, 1024 * tiles);
-    constexpr int LDS_ENTRIES = 16384;
+    // (up to 36 864 counters = 144 KiB of the CU's 160 KiB: the 7 / 7 / 6-base blocks of a large pool in ONE launch each
+    // for the histogram and the scatter instead of three; above the default 64 KiB the kernels need the attribute, per device)
+    constexpr int LDS_ENTRIES = 36864;
+    {
+        static bool attr_set[64] = {};
+        const int dev = idx->device >= 0 && idx->device < 64 ? idx->device : 0;
+        if (!attr_set[dev]) {
+            const void* fns[] = {reinterpret_cast<const void*>(k_cand_hist<1>), reinterpret_cast<const void*>(k_cand_hist<2>),
+                                 reinterpret_cast<const void*>(k_cand_hist<4>), reinterpret_cast<const void*>(k_cand_scatter<1>),
+                                 reinterpret_cast<const void*>(k_cand_scatter<2>), reinterpret_cast<const void*>(k_cand_scatter<4>)};
+            for (const void* f : fns) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ENTRIES * (int)sizeof(int)));
+            attr_set[dev] = true;
+        }
+    }
     struct Run { int lo, hi, lds; };
     Run runs[GM_PG_MAXB];
     int n_runs = 0;
