@@ -72,16 +72,25 @@ def _tree_ops(L):
     return ops
 
 
+# VALU instructions of ONE 64-target group evaluation of K2B's band-only kernel, counted in the ISA (hipcc 7.2,
+# `make asm LEN=23`: the fully unrolled block of k_leven_knn_bs<23, 10, false> with 149 / 187 ds_read_b64 -- DP cells of both
+# halves, streaming diagonal counter, threshold compare, address bumps): (guide length, band half-width) -> instructions.
+# The round-2 model (5 ops per cell + a count tree) over-counts by 7 %: the first and the last in-band cell of every column
+# fold two ops each (constant deltas entering the band).
+K2B_ISA_VALU_PER_GROUP = {(23, 3): 1472, (23, 4): 1855}
+
+
 def bitsliced_leven_ops_per_pair(L, narrow=False):
     """USEFUL VALU lane-ops per guide pair of K2B (gm_leven_bs.hip.h) on its banded path (every lane's bound within
-    2 BAND + 2, the common case once the bounds are seeded): per 32-target word 5 ops per DP cell of the band
-    |i - j| <= BAND = ((3L + 4) // 8) // 2, one count tree over the diagonal and the 5-op threshold compare.  Groups
-    that take the full-matrix path execute more, groups on the narrower band fewer; the counter-derived figure
-    (roofline.achieved) is the one that is measured."""
-    band = ((3 * L + 4) // 8) // 2 - (1 if narrow else 0)      # narrow: the first pass of the two-pass scan (bounds lowered)
+    2 BAND + 2, the common case once the bounds are seeded), band half-width BAND = ((3L + 4) // 8) // 2 (one less for the
+    narrow-band first pass of the two-pass scan): the static instruction count of the unrolled group evaluation in the ISA
+    where it was counted (L = 23), else the cell model scaled by the same folding (0.932)."""
+    band = ((3 * L + 4) // 8) // 2 - (1 if narrow else 0)
+    if (L, band) in K2B_ISA_VALU_PER_GROUP:
+        return K2B_ISA_VALU_PER_GROUP[(L, band)] / 64.0
     cells = L * (2 * band + 1) - band * (band + 1)
     per_word = 5.0 * cells + _tree_ops(L) + 5
-    return per_word / 32.0
+    return 0.932 * per_word / 32.0
 
 
 def roofline_block(workload, pool, kname, kern_s, n_timed, query_ms, launch_pairs, evaluated_pairs, rescanned,
@@ -131,8 +140,8 @@ def roofline_block(workload, pool, kname, kern_s, n_timed, query_ms, launch_pair
     elif "knn_bs" in kname:
         # candidates re-scanned > 0 <=> the timed launch was the narrow-band first pass of the two-pass scan
         useful_opp = bitsliced_leven_ops_per_pair(L, narrow=rescanned > 0)
-        model = ("5 ops per DP cell of the band per 32 pairs + diagonal count tree + comparator (banded path%s)"
-                 % (", narrow-band first pass" if rescanned > 0 else ""))
+        model = ("static VALU instruction count of the unrolled banded group evaluation in the ISA (DP cells of the band, "
+                 "diagonal counter, comparator) / 64 pairs (banded path%s)" % (", narrow-band first pass" if rescanned > 0 else ""))
     else:
         useful_opp = 11.0 * L + 12.0
         model = "per-pair Myers: 11 ops per text position + tail"
