@@ -121,6 +121,8 @@ def lib():
     L.gm_pigeon_plan_sample.argtypes = [i64, i64, i32, i32, c.c_double, c.POINTER(c.c_uint32), i32, i32, c.POINTER(i32),
                                         c.POINTER(i32), c.POINTER(c.c_double), c.POINTER(i32)]
     L.gm_pigeon_plan_sample.restype = i32
+    L.gm_levpart_layout.argtypes = [i32, i32, c.c_double, c.POINTER(i32), c.POINTER(i32), c.POINTER(c.c_double)]
+    L.gm_levpart_layout.restype = i32
     L.gm_pigeon_cascade_info.argtypes = [vp, i32, c.POINTER(i64), c.POINTER(i32), c.POINTER(i64), c.POINTER(i64)]
     L.gm_pigeon_cascade_info.restype = i32
     L.gm_set_variant.argtypes = [vp, i32]
@@ -173,7 +175,7 @@ EXPORTS = [
     "gm_cfd_batch_dev", "gm_last_kernel_ms", "gm_last_query_ms", "gm_last_kernel_name", "gm_last_kernel_pairs",
     "gm_set_variant", "gm_timing_reserve", "gm_timing_read", "gm_pam_count", "gm_pam_emit", "gm_pam_free",
     "gm_pack_keys_dev", "gm_unpack_keys_dev", "gm_site_flags", "gm_seed_duplicated",
-    "gm_last_kernel_evaluated", "gm_last_incomplete", "gm_pigeon_blocks", "gm_pigeon_plan", "gm_pigeon_plan_dist", "gm_pigeon_plan_sample", "gm_pigeon_cascade_info", "gm_pigeon_block_info", "gm_set_param",
+    "gm_last_kernel_evaluated", "gm_last_incomplete", "gm_pigeon_blocks", "gm_pigeon_plan", "gm_pigeon_plan_dist", "gm_pigeon_plan_sample", "gm_levpart_layout", "gm_pigeon_cascade_info", "gm_pigeon_block_info", "gm_set_param",
     "gm_multi_create", "gm_multi_knn_query", "gm_multi_devices", "gm_multi_has_comm", "gm_multi_index", "gm_multi_free",
 ]
 
@@ -491,6 +493,16 @@ def pigeon_plan_sample(n_db, n_q, guidelen, k, cum, p_match=0.25, levels=3):
                                         cm.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), int(cm.shape[0]), int(levels),
                                         blen, trad, ctypes.byref(cost), ctypes.byref(casc)))
     return dict(blocks=[(int(blen[b]), int(trad[b])) for b in range(B)], cost=float(cost.value), cascade=int(casc.value))
+
+
+def levpart_layout(guidelen, r, p_match=0.25):
+    """K2P's layout for radius r: dict(blocks=[lengths], copies, fraction) -- or None.  Host arithmetic, no GPU needed."""
+    blen = (ctypes.c_int32 * 8)()
+    n_copies, frac = ctypes.c_int32(0), ctypes.c_double(0.0)
+    B = int(lib().gm_levpart_layout(int(guidelen), int(r), float(p_match), blen, ctypes.byref(n_copies), ctypes.byref(frac)))
+    if B == 0:
+        return None
+    return dict(blocks=[int(blen[j]) for j in range(B)], copies=int(n_copies.value), fraction=float(frac.value))
 
 
 def pigeon_plan(n_db, guidelen, k, p_match=0.25):

@@ -1742,6 +1742,18 @@ int gm_pigeon_plan_sample(int64_t n_db, int64_t n_q, int guidelen, int k, double
     return found ? lay.B : 0;
 }
 
+int gm_levpart_layout(int guidelen, int r, double p_match, int* blen, int* n_copies, double* fraction) {
+    int bs[GM_LP_MAXBLK] = {0}, bl[GM_LP_MAXBLK] = {0}, cb[GM_LP_MAXCOPY], cs[GM_LP_MAXCOPY], fc[GM_LP_MAXBLK + 1];
+    double f = 0.0;
+    if (!(p_match >= 0.25 && p_match < 0.9)) p_match = 0.25;
+    const int n = gm_lp_layout(guidelen, r, p_match, bs, bl, cb, cs, fc, &f);
+    if (n_copies) *n_copies = n;
+    if (fraction) *fraction = n ? f : 0.0;
+    for (int j = 0; j < GM_LP_MAXBLK; ++j)
+        if (blen) blen[j] = n && j <= r ? bl[j] : 0;
+    return n ? r + 1 : 0;
+}
+
 int gm_pigeon_cascade_info(gm_index* idx, int level, int64_t* n_q, int* radius, int64_t* pairs, int64_t* left) {
     if (!idx || level < 0 || level >= idx->casc_levels || level >= GM_PG_LEVELS) return idx ? idx->casc_levels : 0;
     if (n_q) *n_q = idx->casc_nq[level];

@@ -200,6 +200,12 @@ int gm_pigeon_plan_dist(int64_t n_db, int64_t n_q, int guidelen, int k, double p
  * planner takes the share of candidates whose k-th neighbour lies beyond a radius AND the hits a radius costs. */
 int gm_pigeon_plan_sample(int64_t n_db, int64_t n_q, int guidelen, int k, double p_match, const uint32_t* cum, int n_rows,
                           int levels, int* blen, int* trad, double* cost, int* cascade);
+/* The layout K2P (the displaced-block partition of the Levenshtein scan) uses for radius r on guides of `guidelen` bases
+ * (host arithmetic only): r + 1 blocks, displacements -floor(r / 2) .. floor(r / 2) as far as the displaced block stays
+ * inside the sequence.  Fills blen[8] (block lengths), *n_copies (block x displacement pairs = sorted pool copies) and
+ * *fraction (modelled share of the pool a candidate's workgroups visit, sum over copies of p_match ^ block length).
+ * Returns the number of blocks, 0 when there is no layout (r < 1, r > 7, blocks shorter than two bases). */
+int gm_levpart_layout(int guidelen, int r, double p_match, int* blen, int* n_copies, double* fraction);
 /* The K1P cascade of the last query on this handle: number of levels that ran (0: the plain scan), and for level l
  * (0 = the first pass) its candidates, the radius its layout serves, the pairs it evaluated and the rows it left
  * short (handed to the next level or to the re-scan).  Returns the number of levels, or 0. */

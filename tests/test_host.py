@@ -207,6 +207,33 @@ def test_pigeonhole_planner_choices():
     assert radius(_lib.pigeon_plan(20_000_000, 20, 10)) <= radius(_lib.pigeon_plan(600_000, 20, 10))
 
 
+def test_levenshtein_partition_layouts():
+    """K2P's layouts (host arithmetic): r + 1 blocks covering the guide, displacements within floor(r / 2) that keep the
+    block inside the sequence, and the share of the pool they visit -- small for r = 4 / 5 on 23-mers (what a dense real
+    pool needs), most of the pool from r = 6 on (why S2, whose 5th neighbour sits at 7 of 23, stays on the plain scan)."""
+    from guidemaker_amd import _lib
+    for L in range(12, 28):
+        for r in range(1, 8):
+            lay = _lib.levpart_layout(L, r)
+            if lay is None:
+                assert L < 2 * (r + 1) or -(-L // (r + 1)) > 8
+                continue
+            assert len(lay["blocks"]) == r + 1 and sum(lay["blocks"]) == L and min(lay["blocks"]) >= 2
+            sh = r // 2
+            # copies: per block the displacements -sh .. sh that stay inside [0, L)
+            pos, want = 0, 0
+            for b in lay["blocks"]:
+                want += sum(1 for d in range(-sh, sh + 1) if pos + d >= 0 and pos + d + b <= L)
+                pos += b
+            assert lay["copies"] == want and lay["copies"] <= 56
+            assert abs(lay["fraction"] - sum(
+                0.25 ** b * sum(1 for d in range(-sh, sh + 1) if p + d >= 0 and p + d + b <= L)
+                for b, p in zip(lay["blocks"], np.cumsum([0] + lay["blocks"][:-1]))) ) < 1e-12
+    f = {r: _lib.levpart_layout(23, r)["fraction"] for r in range(3, 8)}
+    assert f[4] < 0.08 and f[5] < 0.25 and f[6] > 0.5 and f[7] > 0.9      # (uniform bases; PAO1's composition: 0.07 / 0.21 / 0.78 / 1.32)
+    assert _lib.levpart_layout(23, 0) is None and _lib.levpart_layout(23, 8) is None and _lib.levpart_layout(12, 7) is None
+
+
 def test_controls_fail_fast_estimate():
     """get_control_seqs gives up after the first draw when the exact nearest-distance histogram rules the largest draw out
     (core._controls_expected_at; the reference's loop, core.py:586-620, would draw 1.1 10^4 n sequences first)."""
