@@ -17,6 +17,13 @@ ids = torch.empty((n_q, k), dtype=torch.int32, device=dev); dists = torch.empty_
 st = torch.cuda.current_stream().cuda_stream
 ref = None
 PARAM = os.environ.get("DBG_PARAM", "pg_layout")
+# clock settle: the first configuration must not run at colder clocks than the others (half a second of the default one)
+_idx = _lib.Index.from_device(d_db.data_ptr(), d_db.shape[0], pool["guidelen"], _lib.METRIC_HAMMING, 0, st)
+_t0 = time.perf_counter()
+while time.perf_counter() - _t0 < 0.6:
+    _idx.knn_dev(d_q.data_ptr(), n_q, k, ids.data_ptr(), dists.data_ptr(), counts.data_ptr(), st)
+    torch.cuda.synchronize()
+_idx.close()
 for lay in [0] + [int(x) for x in sys.argv[2:]]:
     idx = _lib.Index.from_device(d_db.data_ptr(), d_db.shape[0], pool["guidelen"], _lib.METRIC_HAMMING, 0, st)
     if lay: idx.set_param(PARAM, lay)
