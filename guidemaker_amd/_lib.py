@@ -123,6 +123,8 @@ def lib():
     L.gm_pigeon_plan_sample.restype = i32
     L.gm_levpart_layout.argtypes = [i32, i32, c.c_double, c.POINTER(i32), c.POINTER(i32), c.POINTER(c.c_double)]
     L.gm_levpart_layout.restype = i32
+    L.gm_levpart_info.argtypes = [vp, c.POINTER(i32), c.POINTER(i32), c.POINTER(i64), c.POINTER(i64), c.POINTER(i64)]
+    L.gm_levpart_info.restype = i32
     L.gm_pigeon_cascade_info.argtypes = [vp, i32, c.POINTER(i64), c.POINTER(i32), c.POINTER(i64), c.POINTER(i64)]
     L.gm_pigeon_cascade_info.restype = i32
     L.gm_set_variant.argtypes = [vp, i32]
@@ -175,7 +177,7 @@ EXPORTS = [
     "gm_cfd_batch_dev", "gm_last_kernel_ms", "gm_last_query_ms", "gm_last_kernel_name", "gm_last_kernel_pairs",
     "gm_set_variant", "gm_timing_reserve", "gm_timing_read", "gm_pam_count", "gm_pam_emit", "gm_pam_free",
     "gm_pack_keys_dev", "gm_unpack_keys_dev", "gm_site_flags", "gm_seed_duplicated",
-    "gm_last_kernel_evaluated", "gm_last_incomplete", "gm_pigeon_blocks", "gm_pigeon_plan", "gm_pigeon_plan_dist", "gm_pigeon_plan_sample", "gm_levpart_layout", "gm_pigeon_cascade_info", "gm_pigeon_block_info", "gm_set_param",
+    "gm_last_kernel_evaluated", "gm_last_incomplete", "gm_pigeon_blocks", "gm_pigeon_plan", "gm_pigeon_plan_dist", "gm_pigeon_plan_sample", "gm_levpart_layout", "gm_levpart_info", "gm_pigeon_cascade_info", "gm_pigeon_block_info", "gm_set_param",
     "gm_multi_create", "gm_multi_knn_query", "gm_multi_devices", "gm_multi_has_comm", "gm_multi_index", "gm_multi_free",
 ]
 
@@ -376,6 +378,13 @@ class Index:
             lib().gm_pigeon_cascade_info(self._h, lv, ctypes.byref(nq), ctypes.byref(rad), ctypes.byref(pairs), ctypes.byref(left))
             out.append(dict(n_q=int(nq.value), radius=int(rad.value), pairs=int(pairs.value), left=int(left.value)))
         return out
+
+    def levpart_info(self):
+        """K2P levels of the last Levenshtein query: dict(r1, r2, rows2, pairs2, left2) -- r1 = 0: the plain K2B scan ran."""
+        r1, r2 = ctypes.c_int32(0), ctypes.c_int32(0)
+        rows2, pairs2, left2 = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        lib().gm_levpart_info(self._h, ctypes.byref(r1), ctypes.byref(r2), ctypes.byref(rows2), ctypes.byref(pairs2), ctypes.byref(left2))
+        return dict(r1=int(r1.value), r2=int(r2.value), rows2=int(rows2.value), pairs2=int(pairs2.value), left2=int(left2.value))
 
     def pigeon_blocks(self):
         """Blocks of the pigeonhole layout built for this index (0: the plain scan is in use)."""

@@ -77,6 +77,9 @@ struct gm_index {
     int lv_seg = 0;               // experiments (gm_set_param "lv_seg"): pool segments of the Levenshtein scan, 0 = choose
     int n_simd = 1024;            // CUs x 4
     gm_levpart* lp = nullptr;     // K2P: the Levenshtein partition's pool copies + workspaces (built on first use)
+    gm_levpart* lp_deeper = nullptr;      // ... and those of its second level (radius + 1, for the rows the first leaves short)
+    int64_t lp_rows2 = 0, lp_pairs2 = 0, lp_left2 = 0;      // last query: rows / pairs / rows left of the second level
+    int lp_r1 = 0, lp_r2 = 0;                               // last query: radii of the two levels (0 = not run)
     gm_pigeon* pg = nullptr;      // K1P: block-sorted pool copies + query workspaces (built on first use) of the
                                   // cascade level that is running (level 0 between queries)
     // the layout planner's last answer (the enumeration costs ~30 us of host time per query otherwise)
@@ -216,7 +219,7 @@ GM_FOR_EACH_LEN(GM_DECL_LV)
 #define GM_DECL_LVP(LEN)                                                                                              \
     int gm_launch_lvp_L##LEN(const gm_lp_copies* P, const gm_lp_chunk* chunks, int64_t n_chunks, const uint2* q, int64_t n_q, \
                              int k, int kcap, const int32_t* seed_d, const int32_t* seed_c, int seed_k, uint32_t* keys,      \
-                             hipStream_t st);
+                             int radius, hipStream_t st);
 GM_FOR_EACH_LEN(GM_DECL_LVP)
 #undef GM_DECL_LVP
 struct gm_levpart;      // K2P state (gm_levpart.hip)
@@ -225,8 +228,9 @@ int gm_lp_set_param(gm_index* idx, const char* name, int value, bool* known);
 int gm_lp_layout(int L, int r, double p_match, int* bstart, int* blen, int* copy_block, int* copy_shift, int* first_copy,
                  double* fraction);
 int gm_lp_tune_radius(gm_index* idx);
-void gm_lp_plan_get(gm_index* idx, int64_t* nq, int* k, int* r);
-void gm_lp_plan_set(gm_index* idx, int64_t nq, int k, int r);
+void gm_lp_plan_get(gm_index* idx, int64_t* nq, int* k, int* r, int* r2);
+void gm_lp_plan_set(gm_index* idx, int64_t nq, int k, int r, int r2);
+int gm_lp_tune_radius2(gm_index* idx);
 int64_t gm_lp_last_pairs(gm_index* idx);
 int gm_lp_prepare(gm_index* idx, int r, hipStream_t st);
 int gm_lp_candidates(gm_index* idx, const uint2* q, int64_t n_q, hipStream_t st);

@@ -457,7 +457,8 @@ __device__ __forceinline__ void lvp_take_hits(uint32_t hits, const uint32_t (&c)
 template <int L, int KCAP, bool FULL>
 __global__ __launch_bounds__(WAVE, (FULL ? GM_LVB_WAVES : GM_LVB_BAND_WAVES)) void k_leven_part_bs(
     gm_lp_copies P, const gm_lp_chunk* __restrict__ chunks, const uint2* __restrict__ q, int64_t n_q, int k,
-    const int32_t* __restrict__ seed_dists, const int32_t* __restrict__ seed_counts, int seed_k, uint32_t* __restrict__ keys) {
+    const int32_t* __restrict__ seed_dists, const int32_t* __restrict__ seed_counts, int seed_k, uint32_t* __restrict__ keys,
+    int radius) {
     extern __shared__ __align__(16) uint32_t smem[];
     constexpr int TILE_W = lk_tile_bytes(L) / 4;
     constexpr int GW = lk_group_words(L);
@@ -473,6 +474,9 @@ __global__ __launch_bounds__(WAVE, (FULL ? GM_LVB_WAVES : GM_LVB_BAND_WAVES)) vo
     if (valid && seed_dists != nullptr && (seed_counts == nullptr || seed_counts[qi] >= seed_k))
         thr_seed = seed_dists[qi * seed_k + (seed_k - 1)] + 1;      // lev <= hamming; ties at the seed distance compete by id
     if (thr_seed > L + 1) thr_seed = L + 1;
+    // the partition of radius r enumerates the targets within r and no others completely: a row is final only when k of them
+    // lie within r, so nothing beyond r is worth a list entry -- and the bound r + 1 keeps the DP in its narrowest band
+    if (thr_seed > radius + 1) thr_seed = radius + 1;
     int thr = valid ? thr_seed : 0;
     {
         const bool in_band = __builtin_amdgcn_ballot_w64(thr > 2 * lvb_band(L) + 2) == 0ull;
@@ -506,7 +510,13 @@ __global__ __launch_bounds__(WAVE, (FULL ? GM_LVB_WAVES : GM_LVB_BAND_WAVES)) vo
                 constexpr int BAND = lvb_band(L), NARROW = BAND - 1;
                 const bool banded = !FULL || __builtin_amdgcn_ballot_w64(thr > 2 * BAND + 2) == 0ull;
                 const bool narrow = NARROW >= 2 && __builtin_amdgcn_ballot_w64(thr > 2 * NARROW + 2) == 0ull;
-                if (narrow) {
+                // (radius <= 5: every bound is <= 6 and two diagonals either side hold every alignment that matters)
+                const bool tiny = !FULL && NARROW > 2 && __builtin_amdgcn_ballot_w64(thr > 2 * 2 + 2) == 0ull;
+                if (tiny) {
+                    if constexpr (!FULL && NARROW > 2) lvb_eval_group_banded<L, 2>(adr, c0, c1);
+#pragma unroll
+                    for (int i = 0; i < L; ++i) asm volatile("v_add_u32 %0, %1, %0" : "+v"(adr[i]) : "n"(GW * 4));
+                } else if (narrow) {
                     if constexpr (!FULL) {
                         lvb_eval_group_banded<L, (NARROW >= 2 ? NARROW : 2)>(adr, c0, c1);
                     } else {

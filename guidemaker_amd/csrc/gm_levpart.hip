@@ -4,8 +4,9 @@
 //   Two sequences of the same length L within edit distance r: cut the candidate into r + 1 disjoint blocks; at most r
 //   edits touch at most r blocks, so one block is copied to the target unchanged.  Where it lands is displaced by
 //   (insertions - deletions before it), and an alignment of equal-length sequences of cost <= r spends at most
-//   floor(r / 2) of either: |displacement| <= floor(r / 2).  So every target within r of a candidate carries, for some
-//   block j and displacement d, the candidate's bases of block j at the block's positions + d.
+//   floor(r / 2) of either: |displacement| <= floor(r / 2) -- and less for the LEFTMOST untouched block when it lies near
+//   either end (gm_lp_layout).  So every target within r of a candidate carries, for some block j and displacement d, the
+//   candidate's bases of block j at the block's positions + d.
 //
 // Pool side (once per index and radius): for every (block, displacement) pair that stays inside the sequence a "copy" of
 // the pool, stable-sorted by the bases at the displaced positions, buckets padded to whole K2B tiles (256 targets), with
@@ -132,7 +133,8 @@ struct gm_levpart {
     // knobs / plan cache (gmhip.hip)
     int tune_radius = 0;                          // gm_set_param "lp_radius": 0 = choose, 1 .. 7 = that radius, -1 = never
     int64_t plan_nq = -1;
-    int plan_k = -1, plan_r = 0;
+    int plan_k = -1, plan_r = 0, plan_r2 = 0;
+    int tune_radius2 = 0;                         // gm_set_param "lp_radius2": second level 0 = choose, 1 .. 7 = that radius, -1 = never
     int64_t last_pairs = 0;                       // pairs the last K2P launch evaluated
 };
 
@@ -175,20 +177,55 @@ void lp_free_pool(gm_levpart* lp) {
 
 }  // namespace
 
-// The layout for radius r on guides of L bases: r + 1 blocks as even as possible (longer ones first), displacements
-// -floor(r / 2) .. floor(r / 2) as far as the displaced block stays inside the sequence.  Returns the number of copies
-// (0: not a usable layout) and, in *fraction, the modelled share of the pool a candidate's workgroups visit
-// (sum over copies of p_match ^ block length).
+// The layout for radius r on guides of L bases: r + 1 blocks.  Displacements: take the LEFTMOST block j no edit touches
+// (an insertion between two blocks counts for the block on its left).  Every block before it holds an edit, so at least
+// j edits precede it and at most r - j follow; its displacement is the net insertion count before it (<= the edits
+// before) and, the lengths being equal, minus the net count after it (<= the edits after): |d| <= min(floor(r / 2), r - j),
+// and block 0 is not displaced at all.  Looking a pair up under its leftmost untouched block only therefore needs
+// 1, 2 floor(r/2) + 1, ..., 3, 1 copies per block instead of 2 floor(r/2) + 1 for each (r = 5: 20 instead of 30).  Block
+// lengths (2 .. 8 bases, sum L): the split that minimises the modelled share of the pool a candidate's workgroups visit,
+// sum over copies of p_match ^ length (dynamic programme over block index x start position; the blocks with many copies
+// get the long keys).  Returns the number of copies (0: not a usable layout) and that share in *fraction.
+int gm_lp_block_shift(int r, int j) {
+    if (j == 0) return 0;
+    const int a = r / 2, b = r - j;
+    return a < b ? a : b;
+}
+
 int gm_lp_layout(int L, int r, double p_match, int* bstart, int* blen, int* copy_block, int* copy_shift, int* first_copy,
                  double* fraction) {
     const int B = r + 1;
-    if (r < 1 || B > GM_LP_MAXBLK || L < 2 * B) return 0;
-    const int sh = r / 2;
+    if (r < 1 || B > GM_LP_MAXBLK || L < 2 * B || L > 8 * B || L > 32) return 0;
+    const double pm = p_match >= 0.25 && p_match < 1.0 ? p_match : 0.25;
+    auto copies_at = [&](int j, int pos, int len) {
+        const int sh = gm_lp_block_shift(r, j);
+        int c = 0;
+        for (int d = -sh; d <= sh; ++d)
+            if (pos + d >= 0 && pos + d + len <= L) ++c;
+        return c;
+    };
+    // best[j][pos] = least cost of blocks j .. B - 1 laid from position pos to L
+    constexpr double INF = 1e300;
+    double best[GM_LP_MAXBLK + 1][33];
+    int pick[GM_LP_MAXBLK][33];
+    for (int pos = 0; pos <= L; ++pos) best[B][pos] = pos == L ? 0.0 : INF;
+    for (int j = B - 1; j >= 0; --j)
+        for (int pos = 0; pos <= L; ++pos) {
+            best[j][pos] = INF;
+            pick[j][pos] = 0;
+            for (int len = 2; len <= 8 && pos + len <= L; ++len) {
+                if (best[j + 1][pos + len] >= INF) continue;
+                const double c = (double)copies_at(j, pos, len) * std::pow(pm, (double)len) + best[j + 1][pos + len];
+                if (c < best[j][pos] - 1e-15) {      // (ties: the shorter block first)
+                    best[j][pos] = c;
+                    pick[j][pos] = len;
+                }
+            }
+        }
+    if (best[0][0] >= INF) return 0;
     int pos = 0, n_copies = 0;
-    double f = 0.0;
     for (int j = 0; j < B; ++j) {
-        const int len = L / B + (j < L % B ? 1 : 0);
-        if (len > 8) return 0;      // (4^8 buckets at most; such radii need no partition)
+        const int len = pick[j][pos], sh = gm_lp_block_shift(r, j);
         bstart[j] = pos;
         blen[j] = len;
         first_copy[j] = n_copies;
@@ -198,28 +235,27 @@ int gm_lp_layout(int L, int r, double p_match, int* bstart, int* blen, int* copy
             copy_block[n_copies] = j;
             copy_shift[n_copies] = d;
             ++n_copies;
-            f += std::pow(p_match, (double)len);
         }
         pos += len;
     }
     first_copy[B] = n_copies;
-    if (fraction) *fraction = f;
+    if (fraction) *fraction = best[0][0];
     return n_copies;
 }
 
 int gm_lp_set_param(gm_index* idx, const char* name, int value, bool* known) {
     *known = false;
-    if (std::strcmp(name, "lp_radius") != 0) return GM_OK;
+    const bool first = std::strcmp(name, "lp_radius") == 0;
+    if (!first && std::strcmp(name, "lp_radius2") != 0) return GM_OK;
     *known = true;
-    if (value < -1 || value > 7) return gm_fail(GM_ERR_ARG, "lp_radius: -1 (never), 0 (choose), 1..7");
+    if (value < -1 || value > 7) return gm_fail(GM_ERR_ARG, "lp_radius / lp_radius2: -1 (never), 0 (choose), 1..7");
     if (!idx->lp) idx->lp = new gm_levpart();
-    idx->lp->tune_radius = value;
+    (first ? idx->lp->tune_radius : idx->lp->tune_radius2) = value;
     idx->lp->plan_nq = -1;
     return GM_OK;
 }
 
-void gm_lp_free(gm_index* idx) {
-    gm_levpart* lp = idx->lp;
+static void lp_free_one(gm_levpart* lp) {
     if (!lp) return;
     lp_free_pool(lp);
     for (int j = 0; j < GM_LP_MAXBLK; ++j)
@@ -228,7 +264,12 @@ void gm_lp_free(gm_index* idx) {
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     delete lp;
+}
+void gm_lp_free(gm_index* idx) {
+    lp_free_one(idx->lp);
+    lp_free_one(idx->lp_deeper);
     idx->lp = nullptr;
+    idx->lp_deeper = nullptr;
 }
 
 gm_levpart* gm_lp_state(gm_index* idx) {
@@ -236,17 +277,20 @@ gm_levpart* gm_lp_state(gm_index* idx) {
     return idx->lp;
 }
 int gm_lp_tune_radius(gm_index* idx) { return gm_lp_state(idx)->tune_radius; }
-void gm_lp_plan_get(gm_index* idx, int64_t* nq, int* k, int* r) {
+int gm_lp_tune_radius2(gm_index* idx) { return gm_lp_state(idx)->tune_radius2; }
+void gm_lp_plan_get(gm_index* idx, int64_t* nq, int* k, int* r, int* r2) {
     gm_levpart* lp = gm_lp_state(idx);
     *nq = lp->plan_nq;
     *k = lp->plan_k;
     *r = lp->plan_r;
+    *r2 = lp->plan_r2;
 }
-void gm_lp_plan_set(gm_index* idx, int64_t nq, int k, int r) {
+void gm_lp_plan_set(gm_index* idx, int64_t nq, int k, int r, int r2) {
     gm_levpart* lp = gm_lp_state(idx);
     lp->plan_nq = nq;
     lp->plan_k = k;
     lp->plan_r = r;
+    lp->plan_r2 = r2;
 }
 int64_t gm_lp_last_pairs(gm_index* idx) { return idx->lp ? idx->lp->last_pairs : 0; }
 
@@ -257,7 +301,12 @@ int gm_lp_prepare(gm_index* idx, int r, hipStream_t st) {
     lp_free_pool(lp);
     const int L = idx->L;
     double frac = 0.0;
-    const int n_copies = gm_lp_layout(L, r, 0.25, lp->bstart, lp->blen, lp->copy_block, lp->copy_shift, lp->first_copy, &frac);
+    double p_match = 0.25;      // (the pool's own base composition: the same layout the planner priced)
+    {
+        const int rc0 = gm_pg_pool_stats(idx, st, &p_match);
+        if (rc0) return rc0;
+    }
+    const int n_copies = gm_lp_layout(L, r, p_match, lp->bstart, lp->blen, lp->copy_block, lp->copy_shift, lp->first_copy, &frac);
     if (n_copies < 1) return gm_fail(GM_ERR_ARG, "K2P: no layout for this radius / guide length");
     lp->n_blocks = r + 1;
     lp->sh = r / 2;
@@ -395,7 +444,7 @@ int gm_lp_scan(gm_index* idx, const uint2* q, int64_t n_q, int k, int kcap, cons
     if (lp->n_chunks == 0) return GM_OK;
     switch (idx->L) {
 #define GM_CASE(LEN) \
-    case LEN: return gm_launch_lvp_L##LEN(&P, lp->chunks, lp->n_chunks, q, n_q, k, kcap, seed_d, seed_c, seed_k, lp->keys, st);
+    case LEN: return gm_launch_lvp_L##LEN(&P, lp->chunks, lp->n_chunks, q, n_q, k, kcap, seed_d, seed_c, seed_k, lp->keys, lp->r, st);
         GM_FOR_EACH_LEN(GM_CASE)
 #undef GM_CASE
         default: return gm_fail(GM_ERR_ARG, "K2P: guidelen out of range");

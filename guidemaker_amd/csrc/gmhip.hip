@@ -323,17 +323,18 @@ int launch_merge_unique(int kcap, const uint32_t* keys, int n_lists, int64_t n_q
 // through the plain K2B scan give the distribution of the k-th EDIT distance, and r minimises
 // [share of the pool the layout of radius r visits] x 1.2 + [share of the rows whose k-th neighbour lies beyond r].
 int run_leven_partition(gm_index* idx, int64_t n_q, int k, int kcap, int32_t* ids, int32_t* dists, int32_t* counts, hipStream_t st,
-                        bool* used, int* r_used) {
+                        bool* used, int* r_used, int* r2_used) {
     *used = false;
+    *r2_used = 0;
     const int tune = gm_lp_tune_radius(idx);
     if (tune < 0 || (kcap != 10 && kcap != 20) || idx->L < 12) return GM_OK;
     int rc;
-    int r = tune;
+    int r = tune, r2 = 0;
     if (r == 0) {
         if (idx->n_db < 65536 || n_q < 8192) return GM_OK;
         int64_t p_nq = -1;
-        int p_k = -1, p_r = 0;
-        gm_lp_plan_get(idx, &p_nq, &p_k, &p_r);
+        int p_k = -1, p_r = 0, p_r2 = 0;
+        gm_lp_plan_get(idx, &p_nq, &p_k, &p_r, &p_r2);
         if (p_nq != n_q || p_k != k) {
             double p_match = 0.25;
             if ((rc = gm_pg_pool_stats(idx, st, &p_match))) return rc;
@@ -365,29 +366,53 @@ int run_leven_partition(gm_index* idx, int64_t n_q, int k, int kcap, int32_t* id
                 rc = fail(GM_ERR_DEVICE, "K2P sample read-back failed");
             (void)hipFree(q_s); (void)hipFree(d_s); (void)hipFree(i_s); (void)hipFree(c_s);
             if (rc) return rc;
-            int best_r = 0;
-            double best = 0.6;      // the partition has to be clearly cheaper than the plain pass
+            // cost(r) = 1.2 x [share of the pool the layout of radius r visits] + [share of the rows whose k-th neighbour lies
+            // beyond r] x tail(r); tail = the plain pass over those rows (1.0), or -- enough rows -- a second partitioned level of
+            // radius r + 1 over them: its visits + a fixed price + the share of THEM beyond r + 1
+            double frac_r[9] = {0}, beyond_r[9] = {0};
+            bool have_r[9] = {false};
             for (int rr = 1; rr <= 7; ++rr) {
                 int bs[GM_LP_MAXBLK], bl[GM_LP_MAXBLK], cb[GM_LP_MAXCOPY], cs[GM_LP_MAXCOPY], fc[GM_LP_MAXBLK + 1];
-                double frac = 0.0;
-                if (!gm_lp_layout(idx->L, rr, p_match, bs, bl, cb, cs, fc, &frac)) continue;
+                if (!gm_lp_layout(idx->L, rr, p_match, bs, bl, cb, cs, fc, &frac_r[rr])) continue;
+                have_r[rr] = true;
                 int64_t beyond = 0;
                 for (int64_t j = 0; j < n_s; ++j)
                     if (hc[(size_t)j] < k || hd[(size_t)(j * k + k - 1)] > rr) ++beyond;
-                const double cost = 1.2 * frac + (double)beyond / (double)n_s;
+                beyond_r[rr] = (double)beyond / (double)n_s;
+            }
+            int best_r = 0, best_r2 = 0;
+            double best = 0.6;      // the partition has to be clearly cheaper than the plain pass
+            const int tune2 = gm_lp_tune_radius2(idx);
+            for (int rr = 1; rr <= 7; ++rr) {
+                if (!have_r[rr]) continue;
+                double tail = 1.0;
+                int r2 = 0;
+                if (tune2 >= 0 && rr + 1 <= 7 && have_r[rr + 1] && beyond_r[rr] * (double)n_q >= 16384.0) {
+                    const double t2 = 1.2 * frac_r[rr + 1] + 0.05 + beyond_r[rr + 1] / beyond_r[rr];
+                    if (t2 < 0.8) {
+                        tail = t2;
+                        r2 = rr + 1;
+                    }
+                }
+                const double cost = 1.2 * frac_r[rr] + beyond_r[rr] * tail;
                 if (std::getenv("GM_DEBUG"))
-                    fprintf(stderr, "[gm] K2P radius %d: visits %.3f of the pool, %.3f of the sample beyond it -> cost %.3f\n", rr, frac,
-                            (double)beyond / (double)n_s, cost);
+                    fprintf(stderr, "[gm] K2P radius %d: visits %.3f of the pool, %.3f of the sample beyond it, tail %.3f%s -> cost %.3f\n",
+                            rr, frac_r[rr], beyond_r[rr], tail, r2 ? " (second level)" : "", cost);
                 if (cost < best) {
                     best = cost;
                     best_r = rr;
+                    best_r2 = r2;
                 }
             }
-            gm_lp_plan_set(idx, n_q, k, best_r);
+            p_r2 = best_r2;
+            gm_lp_plan_set(idx, n_q, k, best_r, best_r2);
             p_r = best_r;
         }
         r = p_r;
+        r2 = p_r2;
     }
+    if (gm_lp_tune_radius2(idx) > 0) r2 = gm_lp_tune_radius2(idx);      // (tests, A/B)
+    if (gm_lp_tune_radius2(idx) < 0 || r2 <= r) r2 = 0;
     if (r <= 0) return GM_OK;
     if ((rc = gm_lp_prepare(idx, r, st))) {
         if (rc == GM_ERR_ARG || rc == GM_ERR_ALLOC) return GM_OK;      // no layout for this length / no room: the plain pass
@@ -406,6 +431,38 @@ int run_leven_partition(gm_index* idx, int64_t n_q, int k, int kcap, int32_t* id
     HIP_TRY(hipGetLastError());
     *used = true;
     *r_used = r;
+    *r2_used = r2;
+    idx->lp_r1 = r;
+    return GM_OK;
+}
+
+// Second K2P level: the n2 compact rows the first level could not vouch for (q2; bounds: their Hamming seeds) through the
+// layout of radius r2, into the compact result arrays; rows still beyond r2 come back with count 0.
+namespace {
+struct LpLevelScope {      // the second level's pool copies and workspaces stand in for the first's while it runs
+    gm_index* idx;
+    explicit LpLevelScope(gm_index* i) : idx(i) { std::swap(idx->lp, idx->lp_deeper); }
+    ~LpLevelScope() { std::swap(idx->lp, idx->lp_deeper); }
+};
+}  // namespace
+int run_leven_partition_deeper(gm_index* idx, int r2, const uint2* q2, int64_t n2, int k, int kcap, const int32_t* seeds2,
+                               int32_t* ids2, int32_t* dists2, int32_t* counts2, hipStream_t st, bool* used) {
+    *used = false;
+    LpLevelScope scope(idx);
+    int rc;
+    if ((rc = gm_lp_prepare(idx, r2, st))) {
+        if (rc == GM_ERR_ARG || rc == GM_ERR_ALLOC) return GM_OK;      // no layout / no room: the plain second pass takes the rows
+        return rc;
+    }
+    if ((rc = gm_lp_candidates(idx, q2, n2, st))) return rc;
+    const uint32_t* keys = nullptr;
+    int n_lists = 0;
+    if ((rc = gm_lp_scan(idx, q2, n2, k, kcap, seeds2, nullptr, 1, st, &keys, &n_lists))) return rc;
+    idx->lp_pairs2 = gm_lp_last_pairs(idx);
+    if ((rc = launch_merge_unique(kcap, keys, n_lists, n2, k, ids2, dists2, counts2, st))) return rc;
+    hipLaunchKernelGGL(k_lev_unvouched, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, counts2, dists2, n2, k, r2);
+    HIP_TRY(hipGetLastError());
+    *used = true;
     return GM_OK;
 }
 
@@ -472,9 +529,11 @@ int run_leven_lookup(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* d
         }
     }
     bool part_used = false;
+    int r_part = 0, r_part2 = 0;
+    idx->lp_r1 = idx->lp_r2 = 0;
+    idx->lp_rows2 = idx->lp_pairs2 = idx->lp_left2 = 0;
     if (try_part) {
-        int r_part = 0;
-        if ((rc = run_leven_partition(idx, n_q, k, kcap, ids, dists, counts, st, &part_used, &r_part))) return rc;
+        if ((rc = run_leven_partition(idx, n_q, k, kcap, ids, dists, counts, st, &part_used, &r_part, &r_part2))) return rc;
         if (part_used) two_pass = true;      // (the rows it does not vouch for -- count 0 -- take the second pass below)
     }
     if (!part_used) {
@@ -505,6 +564,30 @@ int run_leven_lookup(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* d
     hipLaunchKernelGGL(k_lev_gather_seeds, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, thr_all, gm_pg_inc_list(idx), n2,
                        seeds2);
     HIP_TRY(hipGetLastError());
+    if (part_used && r_part2 > r_part && (n2 >= 4096 || gm_lp_tune_radius2(idx) > 0)) {
+        // K2P's second level: these rows through the layout of radius r + 1, then only what THAT leaves takes the plain pass
+        bool used2 = false;
+        if ((rc = run_leven_partition_deeper(idx, r_part2, q2, n2, k, kcap, seeds2, ids2, dists2, counts2, st, &used2))) return rc;
+        if (used2) {
+            if ((rc = gm_pg_scatter(idx, n2, k, false, ids, dists, counts, st))) return rc;
+            idx->lp_r2 = r_part2;
+            idx->lp_rows2 = n2;
+            if ((rc = gm_pg_collect_short(idx, n_q, k, counts, st))) return rc;
+            int64_t n3 = 0;
+            if ((rc = gm_pg_read_bad(idx, &n3, st))) return rc;
+            idx->lp_left2 = n3;
+            idx->last_incomplete = n3;
+            if (std::getenv("GM_DEBUG"))
+                fprintf(stderr, "[gm] K2P second level: %lld rows, radius %d, %.3g pairs, %lld rows left for the plain pass\n",
+                        (long long)n2, r_part2, (double)idx->lp_pairs2, (long long)n3);
+            if (n3 == 0) return GM_OK;
+            n2 = n3;
+            if ((rc = gm_pg_gather(idx, n2, k, false, &q2, &ids2, &dists2, &counts2, st))) return rc;
+            hipLaunchKernelGGL(k_lev_gather_seeds, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, thr_all, gm_pg_inc_list(idx),
+                               n2, seeds2);
+            HIP_TRY(hipGetLastError());
+        }
+    }
     const int64_t chunks2 = (n2 + gm::WAVE - 1) / gm::WAVE;
     int64_t want2 = ((int64_t)idx->n_simd * 8 + chunks2 - 1) / chunks2;
     if (want2 > 64) want2 = 64;
@@ -1752,6 +1835,16 @@ int gm_levpart_layout(int guidelen, int r, double p_match, int* blen, int* n_cop
     for (int j = 0; j < GM_LP_MAXBLK; ++j)
         if (blen) blen[j] = n && j <= r ? bl[j] : 0;
     return n ? r + 1 : 0;
+}
+
+int gm_levpart_info(gm_index* idx, int* r1, int* r2, int64_t* rows2, int64_t* pairs2, int64_t* left2) {
+    if (!idx) return 0;
+    if (r1) *r1 = idx->lp_r1;
+    if (r2) *r2 = idx->lp_r2;
+    if (rows2) *rows2 = idx->lp_rows2;
+    if (pairs2) *pairs2 = idx->lp_pairs2;
+    if (left2) *left2 = idx->lp_left2;
+    return (idx->lp_r1 > 0 ? 1 : 0) + (idx->lp_r2 > 0 ? 1 : 0);
 }
 
 int gm_pigeon_cascade_info(gm_index* idx, int level, int64_t* n_q, int* radius, int64_t* pairs, int64_t* left) {

@@ -201,11 +201,17 @@ int gm_pigeon_plan_dist(int64_t n_db, int64_t n_q, int guidelen, int k, double p
 int gm_pigeon_plan_sample(int64_t n_db, int64_t n_q, int guidelen, int k, double p_match, const uint32_t* cum, int n_rows,
                           int levels, int* blen, int* trad, double* cost, int* cascade);
 /* The layout K2P (the displaced-block partition of the Levenshtein scan) uses for radius r on guides of `guidelen` bases
- * (host arithmetic only): r + 1 blocks, displacements -floor(r / 2) .. floor(r / 2) as far as the displaced block stays
- * inside the sequence.  Fills blen[8] (block lengths), *n_copies (block x displacement pairs = sorted pool copies) and
- * *fraction (modelled share of the pool a candidate's workgroups visit, sum over copies of p_match ^ block length).
- * Returns the number of blocks, 0 when there is no layout (r < 1, r > 7, blocks shorter than two bases). */
+ * (host arithmetic only): r + 1 blocks; block j is looked up under the displacements |d| <= min(floor(r / 2), r - j)
+ * (block 0: none) -- the bound for the LEFTMOST block no edit touches -- as far as the displaced block stays inside the
+ * sequence; the block lengths (2 .. 8 bases) minimise the share of the pool visited.  Fills blen[8] (block lengths),
+ * *n_copies (block x displacement pairs = sorted pool copies) and *fraction (modelled share of the pool a candidate's
+ * workgroups visit, sum over copies of p_match ^ block length).  Returns the number of blocks, 0 when there is no
+ * layout (r < 1, r > 7, guides shorter than 2 (r + 1) or longer than 8 (r + 1) bases). */
 int gm_levpart_layout(int guidelen, int r, double p_match, int* blen, int* n_copies, double* fraction);
+/* K2P levels of the last Levenshtein query on this handle: *r1 = radius of the partitioned first pass (0: the plain K2B
+ * scan ran), *r2 = radius of the second partitioned level (0: none), *rows2 / *pairs2 / *left2 = the rows that level took,
+ * the pairs it evaluated and the rows it left for the plain second pass.  Returns the number of partitioned levels. */
+int gm_levpart_info(gm_index* idx, int* r1, int* r2, int64_t* rows2, int64_t* pairs2, int64_t* left2);
 /* The K1P cascade of the last query on this handle: number of levels that ran (0: the plain scan), and for level l
  * (0 = the first pass) its candidates, the radius its layout serves, the pairs it evaluated and the rows it left
  * short (handed to the next level or to the re-scan).  Returns the number of levels, or 0. */
@@ -253,7 +259,9 @@ int gm_set_variant(gm_index* idx, int variant);
  *   when the planner's sample says a deeper level pays (default), 2 = whenever >= 64 rows are left (tests);
  *   "pg_layout2": forced layout of the deeper levels, digits as "pg_layout" (tests);
  *   "lp_radius": K2P, the displaced-block partition of the Levenshtein scan: -1 = never, 0 = choose from a sample on
- *   pools of >= 65 536 targets (default), 1 .. 7 = that radius (tests). */
+ *   pools of >= 65 536 targets (default), 1 .. 7 = that radius (tests);
+ *   "lp_radius2": K2P's second level (the rows the first leaves short, through the layout of a larger radius): -1 = never,
+ *   0 = where the planner's sample says it pays (default), 1 .. 7 = that radius (tests). */
 int gm_set_param(gm_index* idx, const char* name, int value);
 
 #ifdef __cplusplus

@@ -852,8 +852,9 @@ def test_cascade_of_k1p_levels_is_exact(oracle, n, L, k, planted, lay1, lay2):
 def test_leven_partition_is_exact(oracle, n, L, k, radius, planted):
     """K2P, the pigeonhole partition for Levenshtein (gm_set_param "lp_radius" forces its radius; the planner takes it only
     on pools of >= 65 536 targets where a sample says it pays): r + 1 blocks, a target within r carries one of them
-    unchanged, displaced by at most floor(r / 2).  Rows it vouches for (k-th entry within r) are final, the others take
-    the second pass under their Hamming seeds.  Against the plain K2B scan ("lp_radius" = -1), the single-pass scan and
+    unchanged, displaced by at most min(floor(r / 2), r - j) for the leftmost such block j.  Rows it vouches for (k-th entry
+    within r) are final, the others take a second partitioned level of a larger radius ("lp_radius2") and / or the second
+    pass under their Hamming seeds.  Against the plain K2B scan ("lp_radius" = -1), the single-pass scan and
     the oracle on a sample that favours rows with near neighbours (planted near-duplicates incl. indels)."""
     rng = np.random.default_rng(1500 + L + k)
     codes = rng.integers(0, 4, size=(n, L), dtype=np.uint8)
@@ -881,6 +882,16 @@ def test_leven_partition_is_exact(oracle, n, L, k, radius, planted):
         assert idx.last_kernel()[0] == "k_leven_part_bs"
         evaluated, second = idx.last_evaluated()
         assert evaluated > 0      # (pairs incl. the padding of the buckets to whole 256-target tiles)
+        info = idx.levpart_info()
+        assert info["r1"] == radius and info["r2"] == 0
+        # ... and with a second partitioned level of radius + 1 for the rows the first cannot vouch for
+        if radius < 7 and L >= 2 * (radius + 2):
+            idx.set_param("lp_radius2", radius + 1)
+            i2, d2, c2 = idx.knn(q, k)
+            info = idx.levpart_info()
+            assert info["r1"] == radius and info["r2"] == radius + 1 and info["rows2"] > 0 and info["left2"] <= info["rows2"]
+            assert (i2 == ids).all() and (d2 == dists).all() and (c2 == counts).all()
+            idx.set_param("lp_radius2", 0)
         idx.set_param("lp_radius", -1)
         i0, d0, c0 = idx.knn(q, k)
         assert idx.last_kernel()[0] == "k_leven_knn_bs"

@@ -208,30 +208,79 @@ def test_pigeonhole_planner_choices():
 
 
 def test_levenshtein_partition_layouts():
-    """K2P's layouts (host arithmetic): r + 1 blocks covering the guide, displacements within floor(r / 2) that keep the
-    block inside the sequence, and the share of the pool they visit -- small for r = 4 / 5 on 23-mers (what a dense real
-    pool needs), most of the pool from r = 6 on (why S2, whose 5th neighbour sits at 7 of 23, stays on the plain scan)."""
+    """K2P's layouts (host arithmetic): r + 1 blocks covering the guide; block j is looked up under the displacements
+    |d| <= min(floor(r / 2), r - j) (block 0: none) that keep it inside the sequence -- the bound for the LEFTMOST block no
+    edit touches --; the block lengths minimise the modelled share of the pool visited (checked against every split for
+    the short cases); and the layouts do find every pair within r (random edit scripts, pure-Python edit distance)."""
+    import itertools
+    import random
     from guidemaker_amd import _lib
+
+    def shift(r, j):
+        return 0 if j == 0 else min(r // 2, r - j)
+
+    def copies(L, r, blocks):
+        out, pos = [], 0
+        for j, b in enumerate(blocks):
+            out.append([d for d in range(-shift(r, j), shift(r, j) + 1) if pos + d >= 0 and pos + d + b <= L])
+            pos += b
+        return out
+
+    def fraction(L, r, blocks):
+        return sum(0.25 ** b * len(c) for b, c in zip(blocks, copies(L, r, blocks)))
+
     for L in range(12, 28):
         for r in range(1, 8):
             lay = _lib.levpart_layout(L, r)
             if lay is None:
-                assert L < 2 * (r + 1) or -(-L // (r + 1)) > 8
+                assert L < 2 * (r + 1) or L > 8 * (r + 1)
                 continue
-            assert len(lay["blocks"]) == r + 1 and sum(lay["blocks"]) == L and min(lay["blocks"]) >= 2
-            sh = r // 2
-            # copies: per block the displacements -sh .. sh that stay inside [0, L)
-            pos, want = 0, 0
-            for b in lay["blocks"]:
-                want += sum(1 for d in range(-sh, sh + 1) if pos + d >= 0 and pos + d + b <= L)
-                pos += b
-            assert lay["copies"] == want and lay["copies"] <= 56
-            assert abs(lay["fraction"] - sum(
-                0.25 ** b * sum(1 for d in range(-sh, sh + 1) if p + d >= 0 and p + d + b <= L)
-                for b, p in zip(lay["blocks"], np.cumsum([0] + lay["blocks"][:-1]))) ) < 1e-12
+            blocks = lay["blocks"]
+            assert len(blocks) == r + 1 and sum(blocks) == L and min(blocks) >= 2 and max(blocks) <= 8
+            assert lay["copies"] == sum(len(c) for c in copies(L, r, blocks)) <= 56
+            assert abs(lay["fraction"] - fraction(L, r, blocks)) < 1e-12
+            if (r + 1) <= 5 or L <= 16:      # every split into r + 1 blocks of 2 .. 8 bases: none visits less
+                best = min(fraction(L, r, c) for c in itertools.product(range(2, 9), repeat=r + 1) if sum(c) == L)
+                assert lay["fraction"] <= best + 1e-12
     f = {r: _lib.levpart_layout(23, r)["fraction"] for r in range(3, 8)}
-    assert f[4] < 0.08 and f[5] < 0.25 and f[6] > 0.5 and f[7] > 0.9      # (uniform bases; PAO1's composition: 0.07 / 0.21 / 0.78 / 1.32)
+    assert f[4] < 0.04 and f[5] < 0.10 and 0.2 < f[6] < 0.4 and f[7] > 0.5      # (uniform bases)
     assert _lib.levpart_layout(23, 0) is None and _lib.levpart_layout(23, 8) is None and _lib.levpart_layout(12, 7) is None
+
+    def edit_distance(a, b):
+        prev = list(range(len(b) + 1))
+        for i in range(1, len(a) + 1):
+            cur = [i] + [0] * len(b)
+            for jj in range(1, len(b) + 1):
+                cur[jj] = min(prev[jj] + 1, cur[jj - 1] + 1, prev[jj - 1] + (a[i - 1] != b[jj - 1]))
+            prev = cur
+        return prev[-1]
+
+    rng = random.Random(7)
+    checked = 0
+    for _ in range(60000):
+        L, r = rng.randint(12, 27), rng.randint(1, 7)
+        lay = _lib.levpart_layout(L, r)
+        if lay is None:
+            continue
+        a = [rng.choice("ACGT") for _ in range(L)]
+        s = list(a)
+        for _e in range(rng.randint(0, r)):
+            t = rng.random()
+            if t < 0.34:
+                s[rng.randrange(len(s))] = rng.choice("ACGT")
+            elif t < 0.67:
+                del s[rng.randrange(len(s))]
+            else:
+                s.insert(rng.randrange(len(s) + 1), rng.choice("ACGT"))
+        if len(s) != L or edit_distance(a, s) > r:
+            continue
+        checked += 1
+        pos, hit = 0, False
+        for b, ds in zip(lay["blocks"], copies(L, r, lay["blocks"])):
+            hit = hit or any(a[pos:pos + b] == s[pos + d:pos + d + b] for d in ds)
+            pos += b
+        assert hit, (L, r, "".join(a), "".join(s), lay)
+    assert checked > 10000
 
 
 def test_controls_fail_fast_estimate():

@@ -81,9 +81,16 @@ def main():
             idx = _lib.Index(db, L, _lib.METRIC_LEVEN)
             try:
                 lpr = int(rng.choice([0, 0, 2, 3, 4, 5]))      # K2P (the Levenshtein partition) with a forced radius
+                lp2 = ""
                 if lpr:
                     idx.set_param("lp_radius", lpr)
+                    if rng.random() < 0.5 and L >= 2 * (lpr + 2):      # ... and a forced second level for the rows it leaves
+                        r2 = int(rng.integers(lpr + 1, min(7, L // 2 - 1) + 1))
+                        idx.set_param("lp_radius2", r2)
+                        lp2 = " K2P %d -> %d" % (lpr, r2)
                 got = idx.knn(q, k)
+                if lp2:
+                    lp2 += " (%d rows, %d left)" % (idx.levpart_info()["rows2"], idx.levpart_info()["left2"])
                 name, resc = idx.last_kernel()[0], idx.last_evaluated()[1]
                 idx.set_param("lp_radius", -1)
                 idx.set_param("lv_two_pass", 0)
@@ -92,8 +99,8 @@ def main():
                 idx.close()
             used[name] = used.get(name, 0) + 1
             ok = all((x == y).all() for x, y in zip(got, want))
-            print("case %3d leven n_db=%d n_q=%d L=%d k=%d skew=%.1f planted=%.2f second pass %d rows %s" %
-                  (case, len(db), len(q), L, k, skew, planted, resc, "ok" if ok else "MISMATCH"), flush=True)
+            print("case %3d leven n_db=%d n_q=%d L=%d k=%d skew=%.1f planted=%.2f second pass %d rows%s %s" %
+                  (case, len(db), len(q), L, k, skew, planted, resc, lp2, "ok" if ok else "MISMATCH"), flush=True)
             if not ok:
                 sys.exit(1)
             continue

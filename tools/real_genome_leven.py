@@ -29,17 +29,19 @@ def main():
     try:
         got = None
         # K2P (the displaced-block partition, radius from a sample) -> the two-pass K2B scan -> the plain single pass
-        for label, lpr, two in (("K2P", 0, 1), ("K2B two-pass", -1, 1), ("K2B single pass", -1, 0)):
+        for label, lpr, lpr2, two in (("K2P", 0, 0, 1), ("K2P one level", 0, -1, 1), ("K2B two-pass", -1, -1, 1),
+                                      ("K2B single pass", -1, -1, 0)):
             idx.set_param("lp_radius", lpr)
+            idx.set_param("lp_radius2", lpr2)
             idx.set_param("lv_two_pass", two)
             idx.knn(q[:70000], k)      # warm
             idx.knn(q, k)              # (first full query: plan, pool copies)
             t0 = time.perf_counter()
             res = idx.knn(q, k)
             dt = time.perf_counter() - t0
-            print("%-16s %.3f s wall, device query %.1f ms, kernel %s (%.1f ms), second-pass rows %d, %.3g pairs/s"
+            print("%-16s %.3f s wall, device query %.1f ms, kernel %s (%.1f ms), plain second-pass rows %d, %.3g pairs/s, K2P levels %s"
                   % (label + ":", dt, idx.last_query_ms(), idx.last_kernel()[0], idx.last_kernel()[1], idx.last_evaluated()[1],
-                     q.shape[0] * db.shape[0] / (idx.last_query_ms() * 1e-3)), flush=True)
+                     q.shape[0] * db.shape[0] / (idx.last_query_ms() * 1e-3), idx.levpart_info()), flush=True)
             if got is None:
                 got = res
             else:
