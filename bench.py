@@ -78,6 +78,9 @@ def _tree_ops(L):
 # The round-2 model (5 ops per cell + a count tree) over-counts by 7 %: the first and the last in-band cell of every column
 # fold two ops each (constant deltas entering the band).
 K2B_ISA_VALU_PER_GROUP = {(23, 3): 1472, (23, 4): 1855}
+# ... and of k_leven_part_bs<23, 10, false> (K2P: the same evaluation inside the chunk loop; its bounds are clamped to the
+# layout's radius r, so the band is max(2, ceil((r - 1) / 2)): 109 / 149 / 187 ds_read_b64 per group)
+K2P_ISA_VALU_PER_GROUP = {(23, 2): 1078, (23, 3): 1479, (23, 4): 1855}
 
 
 def bitsliced_leven_ops_per_pair(L, narrow=False):
@@ -94,7 +97,7 @@ def bitsliced_leven_ops_per_pair(L, narrow=False):
 
 
 def roofline_block(workload, pool, kname, kern_s, n_timed, query_ms, launch_pairs, evaluated_pairs, rescanned,
-                   pigeon_blocks, n_q, n_db, block_info=None):
+                   pigeon_blocks, n_q, n_db, block_info=None, lp_radius=0):
     """Roofline of the dominant scan kernel.  The scans are integer-VALU bound (O(N) bytes for O(N^2) pair work, all
     of it on bit-sliced words in registers / LDS), so the roof is the int32 VALU issue rate: 256 CUs x 4 SIMD-32 x
     2.4 GHz = 78.6 T lane-ops/s.
@@ -137,6 +140,15 @@ def roofline_block(workload, pool, kname, kern_s, n_timed, query_ms, launch_pair
             useful_opp = lookup_ops_per_pair(L)
         model = ("2 v_bitop3 per adder of the carry-save tree over the match words (%.2f positions per pair on average) "
                  "+ 5 comparator ops per 32 pairs + 1 v_cmp per 64" % L_eval)
+    elif "part_bs" in kname:
+        # K2P: evaluated_pairs = the 64 x 64 groups its chunks compare; band from the layout's radius
+        band = max(2, (max(lp_radius, 1) - 1 + 1) // 2)
+        if (L, band) in K2P_ISA_VALU_PER_GROUP:
+            useful_opp = K2P_ISA_VALU_PER_GROUP[(L, band)] / 64.0
+        else:
+            useful_opp = 0.932 * (5.0 * (L * (2 * band + 1) - band * (band + 1)) + _tree_ops(L) + 5) / 32.0
+        model = ("static VALU instruction count of the unrolled banded group evaluation in the ISA (band half-width %d for the "
+                 "partition's radius %d) / 64 pairs; pairs = the 64 x 64 groups the chunks compare" % (band, lp_radius))
     elif "knn_bs" in kname:
         # candidates re-scanned > 0 <=> the timed launch was the narrow-band first pass of the two-pass scan
         useful_opp = bitsliced_leven_ops_per_pair(L, narrow=rescanned > 0)
@@ -346,7 +358,8 @@ def measure_workload(name, steps, warmup, dev, stream):
         evaluated, rescanned = idx.last_evaluated()
         roof = roofline_block(name, pool, kname, kern_s, len(kernel_ms), idx.last_query_ms(), float(idx.last_kernel()[2]),
                               float(evaluated), rescanned, idx.pigeon_blocks() if "scan_pg" in kname else 0, n_q, n_db,
-                              idx.pigeon_block_info() if "scan_pg" in kname else None)
+                              idx.pigeon_block_info() if "scan_pg" in kname else None,
+                              lp_radius=idx.levpart_info()["r1"] if pool["metric"] != "hamming" else 0)
         pairs = float(n_q) * n_db
         return {"workload": pool["label"], "data": "real genome" if pool.get("real_genome") else "synthetic",
                 "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
@@ -355,7 +368,8 @@ def measure_workload(name, steps, warmup, dev, stream):
                 "kernel": kname, "kernel_ms_avg": kern_s * 1e3, "issued_frac": roof.get("frac") if roof.get("counters") not in (None, "stale") else None,
                 "useful_frac": roof["useful"]["frac"], "traffic": roof.get("traffic"),
                 "pairs_evaluated": float(evaluated), "candidates_rescanned": int(rescanned),
-                "k1p_levels": idx.cascade_info(), "roofline": roof}
+                "k1p_levels": idx.cascade_info(),
+                "k2p_levels": idx.levpart_info() if pool["metric"] != "hamming" else None, "roofline": roof}
     finally:
         idx.close()
 
@@ -637,7 +651,8 @@ def main():
         evaluated_pairs = float(evaluated_pairs)
         roof = roofline_block(args.workload, pool, kname, kern_s, len(kernel_ms), query_ms, launch_pairs,
                               evaluated_pairs, rescanned, idx.pigeon_blocks() if "scan_pg" in kname else 0, n_q, n_db,
-                              idx.pigeon_block_info() if "scan_pg" in kname else None)
+                              idx.pigeon_block_info() if "scan_pg" in kname else None,
+                              lp_radius=idx.levpart_info()["r1"] if pool["metric"] != "hamming" else 0)
         out = {
             "metric": "guide-pair distance comparisons/sec (whole node)",
             "value": value, "unit": "guide-pair comparisons/s", "n_gpus": world, "steps": args.steps,

@@ -219,7 +219,7 @@ GM_FOR_EACH_LEN(GM_DECL_LV)
 #define GM_DECL_LVP(LEN)                                                                                              \
     int gm_launch_lvp_L##LEN(const gm_lp_copies* P, const gm_lp_chunk* chunks, int64_t n_chunks, const uint2* q, int64_t n_q, \
                              int k, int kcap, const int32_t* seed_d, const int32_t* seed_c, int seed_k, uint32_t* keys,      \
-                             int radius, hipStream_t st);
+                             int radius, const int* n_chunks_dev, hipStream_t st);
 GM_FOR_EACH_LEN(GM_DECL_LVP)
 #undef GM_DECL_LVP
 struct gm_levpart;      // K2P state (gm_levpart.hip)
@@ -231,9 +231,10 @@ int gm_lp_tune_radius(gm_index* idx);
 void gm_lp_plan_get(gm_index* idx, int64_t* nq, int* k, int* r, int* r2);
 void gm_lp_plan_set(gm_index* idx, int64_t nq, int k, int r, int r2);
 int gm_lp_tune_radius2(gm_index* idx);
-int64_t gm_lp_last_pairs(gm_index* idx);
+int64_t gm_lp_last_pairs(gm_index* idx, int level);      // (valid after the stream has been synchronised)
 int gm_lp_prepare(gm_index* idx, int r, hipStream_t st);
 int gm_lp_candidates(gm_index* idx, const uint2* q, int64_t n_q, hipStream_t st);
+int gm_lp_merge(gm_index* idx, int kcap, int64_t n_q, int k, int32_t* ids, int32_t* dists, int32_t* counts, hipStream_t st);
 int gm_lp_scan(gm_index* idx, const uint2* q, int64_t n_q, int k, int kcap, const int32_t* seed_d, const int32_t* seed_c, int seed_k,
                hipStream_t st, const uint32_t** keys_out, int* n_lists);
 

@@ -38,14 +38,15 @@ int launch_lvb_cfg(gm_index* idx, int64_t n_q, int k, int n_seg, int tiles_per_s
 
 template <int L, int KCAP>
 int launch_lvp_cfg(const gm_lp_copies& P, const gm_lp_chunk* chunks, int64_t n_chunks, const uint2* q, int64_t n_q, int k,
-                   const int32_t* seed_d, const int32_t* seed_c, int seed_k, uint32_t* keys, int radius, hipStream_t st) {
+                   const int32_t* seed_d, const int32_t* seed_c, int seed_k, uint32_t* keys, int radius, const int* n_chunks_dev,
+                   hipStream_t st) {
     const size_t lds = 2 * (size_t)gm::lk_tile_bytes(L);
     hipLaunchKernelGGL((gm::k_leven_part_bs<L, KCAP, false>), dim3((unsigned)n_chunks), dim3(gm::WAVE), lds, st, P, chunks, q, n_q, k,
-                       seed_d, seed_c, seed_k, keys, radius);
+                       seed_d, seed_c, seed_k, keys, radius, n_chunks_dev);
     // (every bound is <= radius + 1: the full-matrix launch has work only when that exceeds what the band serves)
     if (radius + 1 > 2 * gm::lvb_band(L) + 2)
         hipLaunchKernelGGL((gm::k_leven_part_bs<L, KCAP, true>), dim3((unsigned)n_chunks), dim3(gm::WAVE), lds, st, P, chunks, q, n_q, k,
-                           seed_d, seed_c, seed_k, keys, radius);
+                           seed_d, seed_c, seed_k, keys, radius, n_chunks_dev);
     HIP_TRY(hipGetLastError());
     return GM_OK;
 }
@@ -79,10 +80,10 @@ int GM_CAT(gm_launch_lv_L, GM_LEN)(gm_index* idx, int algo, int kcap, int64_t n_
 // K2P: the partitioned Levenshtein scan (gm_levpart.hip)
 int GM_CAT(gm_launch_lvp_L, GM_LEN)(const gm_lp_copies* P, const gm_lp_chunk* chunks, int64_t n_chunks, const uint2* q,
                                     int64_t n_q, int k, int kcap, const int32_t* seed_d, const int32_t* seed_c, int seed_k,
-                                    uint32_t* keys, int radius, hipStream_t st) {
+                                    uint32_t* keys, int radius, const int* n_chunks_dev, hipStream_t st) {
     switch (kcap) {
-        case 10: return launch_lvp_cfg<GM_LEN, 10>(*P, chunks, n_chunks, q, n_q, k, seed_d, seed_c, seed_k, keys, radius, st);
-        case 20: return launch_lvp_cfg<GM_LEN, 20>(*P, chunks, n_chunks, q, n_q, k, seed_d, seed_c, seed_k, keys, radius, st);
+        case 10: return launch_lvp_cfg<GM_LEN, 10>(*P, chunks, n_chunks, q, n_q, k, seed_d, seed_c, seed_k, keys, radius, n_chunks_dev, st);
+        case 20: return launch_lvp_cfg<GM_LEN, 20>(*P, chunks, n_chunks, q, n_q, k, seed_d, seed_c, seed_k, keys, radius, n_chunks_dev, st);
         default: return gm_fail(GM_ERR_ARG, "partitioned leven kernel: unsupported list capacity");
     }
 }

@@ -458,11 +458,12 @@ template <int L, int KCAP, bool FULL>
 __global__ __launch_bounds__(WAVE, (FULL ? GM_LVB_WAVES : GM_LVB_BAND_WAVES)) void k_leven_part_bs(
     gm_lp_copies P, const gm_lp_chunk* __restrict__ chunks, const uint2* __restrict__ q, int64_t n_q, int k,
     const int32_t* __restrict__ seed_dists, const int32_t* __restrict__ seed_counts, int seed_k, uint32_t* __restrict__ keys,
-    int radius) {
+    int radius, const int* __restrict__ n_chunks_dev) {
     extern __shared__ __align__(16) uint32_t smem[];
     constexpr int TILE_W = lk_tile_bytes(L) / 4;
     constexpr int GW = lk_group_words(L);
     const int lane = threadIdx.x;
+    if ((int)blockIdx.x >= *n_chunks_dev) return;      // (the launch covers an upper bound of the chunk table)
     const gm_lp_chunk ch = chunks[blockIdx.x];
     const bool valid = lane < ch.cn;
     const int64_t qi = valid ? (int64_t)P.cperm[ch.j][ch.c0 + lane] : 0;
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(WAVE, (FULL ? GM_LVB_WAVES : GM_LVB_BAND_WAVES)) vo
         if (bd.y <= 0) continue;
         const uint32_t* __restrict__ table = P.table[cp];
         const uint32_t* __restrict__ ord = P.ord[cp];
-        const int t0 = bd.x, t1 = bd.x + bd.y;
+        const int t0 = bd.x, t1 = bd.x + (bd.y + LK_TG - 1) / LK_TG;      // (.y = 64-target groups that hold targets)
         lk_stage<L>(table, t0, smem, lane);
         for (int t = t0; t < t1; ++t) {
             const uint32_t* cur = smem + ((t - t0) & 1) * TILE_W;
@@ -505,7 +506,8 @@ __global__ __launch_bounds__(WAVE, (FULL ? GM_LVB_WAVES : GM_LVB_BAND_WAVES)) vo
                 const uint32_t code = ((qx >> i) & 1u) | (((qy >> i) & 1u) << 1);
                 adr[i] = cur_b + code * 8u;
             }
-            for (int gl = 0; gl < LK_TG; ++gl) {
+            const int g_here = bd.y - (t - t0) * LK_TG < LK_TG ? bd.y - (t - t0) * LK_TG : LK_TG;      // (the last tile: no padding groups)
+            for (int gl = 0; gl < g_here; ++gl) {
                 uint32_t c0[5], c1[5];
                 constexpr int BAND = lvb_band(L), NARROW = BAND - 1;
                 const bool banded = !FULL || __builtin_amdgcn_ballot_w64(thr > 2 * BAND + 2) == 0ull;
@@ -548,7 +550,12 @@ __global__ __launch_bounds__(WAVE, (FULL ? GM_LVB_WAVES : GM_LVB_BAND_WAVES)) vo
                     h0 = GM_BITOP3(c0[b], Tb[b], h0, TT_GE);
                     h1 = GM_BITOP3(c1[b], Tb[b], h1, TT_GE);
                 }
+#ifdef GM_LVP_NOHITS      /* timing experiment only (results WRONG): the evaluation without the hit path */
+                asm volatile("" ::"v"(h0), "v"(h1));
+                if (false) {
+#else
                 if (__builtin_expect(__builtin_amdgcn_ballot_w64((h0 | h1) != 0u) != 0ull, 0)) {
+#endif
                     const int64_t pos0 = ((int64_t)t * LK_TG + gl) * LK_GROUP;
                     lvp_take_hits<L, KCAP>(h0, c0, ord, pos0, list, thr, thr_seed, Tb);
                     lvp_take_hits<L, KCAP>(h1, c1, ord, pos0 + 32, list, thr, thr_seed, Tb);

@@ -43,6 +43,38 @@ int lp_ensure(T** p, int64_t* cap, int64_t need, const char* what) {
 
 inline dim3 lp_grid(int64_t n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
 
+#include "gm_group.hip.h"      // the counting sort of the candidates by every block's value (shared with K1P)
+
+// per-query counters of the grouping (device; mirrored to pinned host memory after the chunk table is filled)
+struct LpCounters {
+    int cstart[GM_LP_MAXBLK + 1];      // chunk range of every block
+    int n_chunks;
+    int pad;
+    unsigned long long pairs;          // candidate x target pairs the scan will evaluate (64 x 64 groups)
+};
+
+// one thread per (block, bucket) entry: its chunks of <= 64 candidates into the block's range of the chunk table
+__global__ __launch_bounds__(256) void k_lp_fill_chunks(PgKeyArg K, const int* __restrict__ cbase, const uint32_t* __restrict__ gsum,
+                                                        gm_lp_chunk* __restrict__ chunks, LpCounters* __restrict__ ctr) {
+    __shared__ unsigned long long s_pairs;
+    if (threadIdx.x == 0) s_pairs = 0ull;
+    __syncthreads();
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < K.ebase[K.B]) {
+        int j = 0;
+        while (j + 1 < K.B && e >= K.ebase[j + 1]) ++j;
+        const int v = e - K.ebase[j];
+        const int c0 = K.coff[j][v], c1 = K.coff[j][v + 1];
+        if (c1 > c0) {
+            int w = ctr->cstart[j] + cbase[e];
+            for (int c = c0; c < c1; c += 64, ++w) chunks[w] = gm_lp_chunk{j, v, c, c1 - c < 64 ? c1 - c : 64};
+            atomicAdd(&s_pairs, (unsigned long long)((c1 - c0 + 63) / 64) * gsum[e] * (unsigned long long)(gm::LK_GROUP * 64));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_pairs != 0ull) atomicAdd(&ctr->pairs, s_pairs);
+}
+
 // key[i] = bases of sequence i at positions [start, start + len), rows[i] = i
 __global__ __launch_bounds__(256) void k_lp_keys(const uint2* __restrict__ planes, int64_t n, int start, int len,
                                                  uint32_t* __restrict__ keys, uint32_t* __restrict__ rows) {
@@ -113,7 +145,8 @@ struct gm_levpart {
     // pool side
     uint32_t* table[GM_LP_MAXCOPY]{};
     uint32_t* ord[GM_LP_MAXCOPY]{};
-    int2* bdesc[GM_LP_MAXCOPY]{};
+    int2* bdesc[GM_LP_MAXCOPY]{};              // bucket v of copy c -> (first tile, 64-target groups that hold targets)
+    std::vector<int2> bdesc_host[GM_LP_MAXCOPY];      // (the same on the host: the chunk table is built there)
     // query side (grow-only)
     uint32_t* cperm[GM_LP_MAXBLK]{};
     int64_t cperm_cap[GM_LP_MAXBLK]{};
@@ -127,7 +160,14 @@ struct gm_levpart {
     int64_t pad_off_cap = 0;
     gm_lp_chunk* chunks = nullptr;
     int64_t chunks_cap = 0;
-    int64_t n_chunks = 0;
+    int64_t n_chunks = 0;                         // workgroups of the scan launch (an upper bound; the table's length is ctr->n_chunks)
+    // candidate grouping on the device (gm_group.hip.h)
+    int ebase[GM_LP_MAXBLK + 1]{};                // (block, bucket) entries: block j's start
+    int32_t* coff_all = nullptr;                  // per block 4^len + 1 candidate offsets
+    int *hist = nullptr, *cursor = nullptr, *cbase = nullptr, *btot = nullptr;
+    uint32_t* gsum = nullptr;                     // per entry: 64-target groups of the bucket summed over the block's copies
+    void* ctr = nullptr;                          // LpCounters (device)
+    void* ctr_host = nullptr;                     // ... and its pinned mirror (valid after the next synchronisation)
     uint32_t* keys = nullptr;
     int64_t keys_cap = 0;
     // knobs / plan cache (gmhip.hip)
@@ -135,7 +175,6 @@ struct gm_levpart {
     int64_t plan_nq = -1;
     int plan_k = -1, plan_r = 0, plan_r2 = 0;
     int tune_radius2 = 0;                         // gm_set_param "lp_radius2": second level 0 = choose, 1 .. 7 = that radius, -1 = never
-    int64_t last_pairs = 0;                       // pairs the last K2P launch evaluated
 };
 
 namespace {
@@ -170,6 +209,7 @@ void lp_free_pool(gm_levpart* lp) {
         lp->table[c] = nullptr;
         lp->ord[c] = nullptr;
         lp->bdesc[c] = nullptr;
+        lp->bdesc_host[c].clear();
     }
     lp->r = -1;
     lp->n_copies = 0;
@@ -260,9 +300,11 @@ static void lp_free_one(gm_levpart* lp) {
     lp_free_pool(lp);
     for (int j = 0; j < GM_LP_MAXBLK; ++j)
         if (lp->cperm[j]) (void)hipFree(lp->cperm[j]);
-    void* bufs[] = {lp->k0, lp->k1, lp->r0, lp->r1, lp->sort_tmp, lp->off, lp->pad_off, lp->chunks, lp->keys};
+    void* bufs[] = {lp->k0, lp->k1, lp->r0, lp->r1, lp->sort_tmp, lp->off, lp->pad_off, lp->chunks, lp->keys,
+                    lp->coff_all, lp->hist, lp->cursor, lp->cbase, lp->btot, lp->gsum, lp->ctr};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
+    if (lp->ctr_host) (void)hipHostFree(lp->ctr_host);
     delete lp;
 }
 void gm_lp_free(gm_index* idx) {
@@ -292,7 +334,11 @@ void gm_lp_plan_set(gm_index* idx, int64_t nq, int k, int r, int r2) {
     lp->plan_r = r;
     lp->plan_r2 = r2;
 }
-int64_t gm_lp_last_pairs(gm_index* idx) { return idx->lp ? idx->lp->last_pairs : 0; }
+// pairs the last K2P grouping laid out (valid once the stream has been synchronised after gm_lp_candidates)
+int64_t gm_lp_last_pairs(gm_index* idx, int level) {
+    const gm_levpart* lp = level == 0 ? idx->lp : idx->lp_deeper;
+    return lp && lp->ctr_host ? (int64_t) static_cast<const LpCounters*>(lp->ctr_host)->pairs : 0;
+}
 
 // pool copies for radius r (kept until another radius is asked for)
 int gm_lp_prepare(gm_index* idx, int r, hipStream_t st) {
@@ -334,7 +380,7 @@ int gm_lp_prepare(gm_index* idx, int r, hipStream_t st) {
         for (int v = 0; v < nb; ++v) {
             const int cnt = off[(size_t)v + 1] - off[(size_t)v];
             const int t = (cnt + TT - 1) / TT;
-            bdesc[(size_t)v] = make_int2((int)tiles, t);
+            bdesc[(size_t)v] = make_int2((int)tiles, (cnt + gm::LK_GROUP - 1) / gm::LK_GROUP);
             pad[(size_t)v] = tiles * TT;
             tiles += t;
         }
@@ -352,6 +398,7 @@ int gm_lp_prepare(gm_index* idx, int r, hipStream_t st) {
             rc = gm_fail(GM_ERR_ALLOC, "hipMalloc(K2P pool copy) failed");
             break;
         }
+        lp->bdesc_host[c] = bdesc;
         hipError_t e = hipMemcpyAsync(lp->bdesc[c], bdesc.data(), sizeof(int2) * bdesc.size(), hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = hipMemcpyAsync(lp->pad_off, pad.data(), sizeof(int64_t) * pad.size(), hipMemcpyHostToDevice, st);
         if (e == hipSuccess) e = hipMemsetAsync(lp->ord[c], 0xff, sizeof(uint32_t) * (size_t)n_pad, st);
@@ -371,54 +418,81 @@ int gm_lp_prepare(gm_index* idx, int r, hipStream_t st) {
     }
     lp->r = r;
     lp->n_copies = n_copies;
+    // the candidate grouping's tables for this layout: (block, bucket) entries, offsets, counters, and per entry the
+    // 64-target groups its bucket holds over all copies of the block (what a chunk of that bucket will evaluate)
+    {
+        void* old_bufs[] = {lp->coff_all, lp->hist, lp->cursor, lp->cbase, lp->btot, lp->gsum, lp->ctr};
+        for (void* b : old_bufs)
+            if (b) (void)hipFree(b);
+        lp->coff_all = nullptr;
+        lp->hist = lp->cursor = lp->cbase = lp->btot = nullptr;
+        lp->gsum = nullptr;
+        lp->ctr = nullptr;
+        lp->ebase[0] = 0;
+        int64_t coff_words = 0;
+        for (int j = 0; j < lp->n_blocks; ++j) {
+            lp->ebase[j + 1] = lp->ebase[j] + (1 << (2 * lp->blen[j]));
+            coff_words += (1 << (2 * lp->blen[j])) + 1;
+        }
+        const int n_ent = lp->ebase[lp->n_blocks];
+        std::vector<uint32_t> gsum((size_t)n_ent, 0u);
+        for (int c = 0; c < n_copies; ++c) {
+            const int j = lp->copy_block[c];
+            for (size_t v = 0; v < lp->bdesc_host[c].size(); ++v) gsum[(size_t)lp->ebase[j] + v] += (uint32_t)lp->bdesc_host[c][v].y;
+        }
+        if (hipMalloc(reinterpret_cast<void**>(&lp->coff_all), sizeof(int32_t) * (size_t)coff_words) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&lp->hist), sizeof(int) * (size_t)n_ent) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&lp->cursor), sizeof(int) * (size_t)n_ent) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&lp->cbase), sizeof(int) * (size_t)n_ent) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&lp->btot), sizeof(int) * GM_PG_MAXB) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&lp->gsum), sizeof(uint32_t) * (size_t)n_ent) != hipSuccess ||
+            hipMalloc(&lp->ctr, sizeof(LpCounters)) != hipSuccess ||
+            (lp->ctr_host == nullptr && hipHostMalloc(&lp->ctr_host, sizeof(LpCounters)) != hipSuccess)) {
+            lp_free_pool(lp);
+            return gm_fail(GM_ERR_ALLOC, "hipMalloc(K2P grouping tables) failed");
+        }
+        std::memset(lp->ctr_host, 0, sizeof(LpCounters));
+        if (hipMemsetAsync(lp->hist, 0, sizeof(int) * (size_t)n_ent, st) != hipSuccess ||
+            hipMemcpyAsync(lp->gsum, gsum.data(), sizeof(uint32_t) * gsum.size(), hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) {
+            lp_free_pool(lp);
+            return gm_fail(GM_ERR_DEVICE, "K2P grouping tables upload failed");
+        }
+    }
     return GM_OK;
 }
 
-// group the candidates (planes q) by every block's value and build the chunk table; *pairs = pairs the scan will evaluate
+// group the candidates (planes q) by every block's value and lay out the chunk table -- on the device, no host round trip:
+// the scan is launched over an upper bound of the chunks and reads the table's length from ctr->n_chunks
 int gm_lp_candidates(gm_index* idx, const uint2* q, int64_t n_q, hipStream_t st) {
     gm_levpart* lp = gm_lp_state(idx);
     if (lp->r < 1) return gm_fail(GM_ERR_ARG, "gm_lp_candidates: no copies prepared");
+    if (n_q >= (int64_t)1 << 31) return gm_fail(GM_ERR_ARG, "gm_lp_candidates: too many candidates");
     int rc;
-    if ((rc = lp_sort_buffers(lp, n_q > idx->n_db ? n_q : idx->n_db))) return rc;
-    std::vector<gm_lp_chunk> chunks;
-    chunks.reserve((size_t)(n_q / 64 + 4096) * (size_t)lp->n_blocks);
-    std::vector<std::vector<int2>> bd((size_t)lp->n_copies);
-    for (int c = 0; c < lp->n_copies; ++c) {      // bucket sizes of the copies (for the pair count; small tables)
-        const int nb = 1 << (2 * lp->blen[lp->copy_block[c]]);
-        bd[(size_t)c].resize((size_t)nb);
-        HIP_TRY(hipMemcpyAsync(bd[(size_t)c].data(), lp->bdesc[c], sizeof(int2) * (size_t)nb, hipMemcpyDeviceToHost, st));
-    }
-    int64_t pairs = 0;
+    PgKeyArg K{};
+    K.B = lp->n_blocks;
+    int64_t grid = 0, coff_at = 0;
+    for (int j = 0; j <= lp->n_blocks; ++j) K.ebase[j] = lp->ebase[j];
     for (int j = 0; j < lp->n_blocks; ++j) {
-        const int len = lp->blen[j], nb = 1 << (2 * len);
         if ((rc = lp_ensure(&lp->cperm[j], &lp->cperm_cap[j], n_q, "candidate order"))) return rc;
-        if ((rc = lp_ensure(&lp->off, &lp->off_cap, nb + 1, "bucket offsets"))) return rc;
-        hipLaunchKernelGGL(k_lp_keys, lp_grid(n_q), dim3(256), 0, st, q, n_q, lp->bstart[j], len, lp->k0, lp->r0);
-        if ((rc = lp_sort(lp, n_q, 2 * len, st))) return rc;
-        hipLaunchKernelGGL(k_lp_offsets, lp_grid(nb + 1), dim3(256), 0, st, lp->k1, n_q, nb, lp->off);
-        HIP_TRY(hipMemcpyAsync(lp->cperm[j], lp->r1, sizeof(uint32_t) * (size_t)n_q, hipMemcpyDeviceToDevice, st));
-        std::vector<int32_t> off((size_t)nb + 1);
-        HIP_TRY(hipMemcpyAsync(off.data(), lp->off, sizeof(int32_t) * off.size(), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        for (int v = 0; v < nb; ++v) {
-            const int c0 = off[(size_t)v], c1 = off[(size_t)v + 1];
-            if (c1 <= c0) continue;
-            int64_t tiles = 0;
-            for (int c = lp->first_copy[j]; c < lp->first_copy[j + 1]; ++c) tiles += bd[(size_t)c][(size_t)v].y;
-            if (tiles == 0) continue;      // (no target carries these bases at any displacement: nothing to compare)
-            for (int c = c0; c < c1; c += 64) {
-                chunks.push_back(gm_lp_chunk{j, v, c, c1 - c < 64 ? c1 - c : 64});
-                pairs += tiles * GM_LP_TILE_TARGETS * 64;
-            }
-        }
+        K.bstart[j] = lp->bstart[j];
+        K.blen[j] = lp->blen[j];
+        K.coff[j] = lp->coff_all + coff_at;
+        K.cperm[j] = lp->cperm[j];
+        coff_at += (1 << (2 * lp->blen[j])) + 1;
+        grid += (n_q + 63) / 64 + (1 << (2 * lp->blen[j]));
     }
-    lp->n_chunks = (int64_t)chunks.size();
-    lp->last_pairs = pairs;
-    if ((rc = lp_ensure(&lp->chunks, &lp->chunks_cap, lp->n_chunks, "K2P chunk table"))) return rc;
-    if (lp->n_chunks > 0) {
-        HIP_TRY(hipMemcpyAsync(lp->chunks, chunks.data(), sizeof(gm_lp_chunk) * chunks.size(), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));      // (the host vector goes out of scope)
-    }
+    if ((rc = lp_ensure(&lp->chunks, &lp->chunks_cap, grid, "K2P chunk table"))) return rc;
+    PgSubArg nsub{};
+    for (int j = 0; j < lp->n_blocks; ++j) nsub.n[j] = 1;
+    LpCounters* ctr = static_cast<LpCounters*>(lp->ctr);
+    if ((rc = gm_group_launch(q, n_q, K, nsub, lp->hist, lp->cursor, lp->cbase, lp->btot, reinterpret_cast<int*>(ctr),
+                              (int)(sizeof(LpCounters) / sizeof(int)), ctr->cstart, &ctr->n_chunks, idx->device, st)))
+        return rc;
+    hipLaunchKernelGGL(k_lp_fill_chunks, lp_grid(lp->ebase[lp->n_blocks]), dim3(256), 0, st, K, lp->cbase, lp->gsum, lp->chunks, ctr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(lp->ctr_host, lp->ctr, sizeof(LpCounters), hipMemcpyDeviceToHost, st));
+    lp->n_chunks = grid;
     return GM_OK;
 }
 
@@ -428,7 +502,7 @@ int gm_lp_scan(gm_index* idx, const uint2* q, int64_t n_q, int k, int kcap, cons
     gm_levpart* lp = gm_lp_state(idx);
     int rc;
     if ((rc = lp_ensure(&lp->keys, &lp->keys_cap, (int64_t)lp->n_blocks * n_q * kcap, "K2P block lists"))) return rc;
-    // (a candidate is in exactly one chunk per block unless no target shares the block's bases: those lists must read "empty")
+    // (a candidate is in exactly one chunk per block: every list is written; the fill is a safeguard)
     HIP_TRY(hipMemsetAsync(lp->keys, 0xff, sizeof(uint32_t) * (size_t)((int64_t)lp->n_blocks * n_q * kcap), st));
     gm_lp_copies P{};
     for (int c = 0; c < lp->n_copies; ++c) {
@@ -442,11 +516,27 @@ int gm_lp_scan(gm_index* idx, const uint2* q, int64_t n_q, int k, int kcap, cons
     *keys_out = lp->keys;
     *n_lists = lp->n_blocks;
     if (lp->n_chunks == 0) return GM_OK;
+    const int* n_chunks_dev = &static_cast<const LpCounters*>(lp->ctr)->n_chunks;
     switch (idx->L) {
 #define GM_CASE(LEN) \
-    case LEN: return gm_launch_lvp_L##LEN(&P, lp->chunks, lp->n_chunks, q, n_q, k, kcap, seed_d, seed_c, seed_k, lp->keys, lp->r, st);
+    case LEN: return gm_launch_lvp_L##LEN(&P, lp->chunks, lp->n_chunks, q, n_q, k, kcap, seed_d, seed_c, seed_k, lp->keys, lp->r, n_chunks_dev, st);
         GM_FOR_EACH_LEN(GM_CASE)
 #undef GM_CASE
         default: return gm_fail(GM_ERR_ARG, "K2P: guidelen out of range");
     }
+}
+
+// the raw per-block lists of the last gm_lp_scan folded into the top k of every candidate (a target found under several
+// blocks / displacements is taken once)
+int gm_lp_merge(gm_index* idx, int kcap, int64_t n_q, int k, int32_t* ids, int32_t* dists, int32_t* counts, hipStream_t st) {
+    gm_levpart* lp = gm_lp_state(idx);
+    if (lp->r < 1 || !lp->keys) return gm_fail(GM_ERR_ARG, "gm_lp_merge: no scan to merge");
+    constexpr int SP = 4;
+    const dim3 grid((unsigned)((n_q * SP + 255) / 256)), block(256);
+    if (kcap == 10)
+        hipLaunchKernelGGL((gm::k_merge_lists_unique<10, SP>), grid, block, 0, st, lp->keys, lp->n_blocks, n_q, k, ids, dists, counts);
+    else
+        hipLaunchKernelGGL((gm::k_merge_lists_unique<20, SP>), grid, block, 0, st, lp->keys, lp->n_blocks, n_q, k, ids, dists, counts);
+    HIP_TRY(hipGetLastError());
+    return GM_OK;
 }

@@ -68,7 +68,7 @@ constexpr int GM_LP_TILE_TARGETS = 256;      // buckets of a copy are padded to 
 struct gm_lp_copies {                 // passed to the kernel by value
     const uint32_t* table[GM_LP_MAXCOPY];     // one-hot table of the copy (K1L group format, all L positions; padding all-zero)
     const uint32_t* ord[GM_LP_MAXCOPY];       // position in the copy -> pool id (0xffffffff = padding)
-    const int2* bdesc[GM_LP_MAXCOPY];         // bucket v -> (first tile, tiles)
+    const int2* bdesc[GM_LP_MAXCOPY];         // bucket v -> (first tile, 64-target groups that hold targets)
     const uint32_t* cperm[GM_LP_MAXBLK];      // candidates sorted by block j's value: sorted position -> candidate row
     int first_copy[GM_LP_MAXBLK + 1];         // the copies of block j: [first_copy[j], first_copy[j + 1])
     int n_blocks;

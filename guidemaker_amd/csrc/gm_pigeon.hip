@@ -132,222 +132,7 @@ __global__ __launch_bounds__(256) void k_base_counts(const uint2* __restrict__ p
     if (threadIdx.x < 4) atomicAdd(&counts[threadIdx.x], (unsigned long long)s[threadIdx.x]);
 }
 
-// ---- candidate grouping: one counting sort for ALL blocks (order inside a bucket is irrelevant) ----
-struct PgKeyArg {
-    int B;
-    int bstart[GM_PG_MAXB], blen[GM_PG_MAXB];
-    int ebase[GM_PG_MAXB + 1];
-    int32_t* coff[GM_PG_MAXB];
-    uint32_t* cperm[GM_PG_MAXB];
-};
-
-__device__ __forceinline__ int pg_key(const uint2 e, int start, int len) {
-    int key = 0;
-    for (int j = 0; j < len; ++j) {
-        const int p = start + j;
-        key |= (int)(((e.x >> p) & 1u) | (((e.y >> p) & 1u) << 1)) << (2 * j);
-    }
-    return key;
-}
-
-// hist[entry] += candidates with that (block, value); LDS-privatised per workgroup when the table fits.  A workgroup
-// takes T tiles of 1024 candidates: what reaches the device-wide histogram is one atomic per (workgroup, non-empty
-// bucket), and with a few thousand buckets a single tile hardly shares any (1024 candidates touch ~900 of the 4096
-// buckets of a 6-base block) -- T = 4 cuts those atomics by a third and the launch from 19 to 13 us on S1 (the scatter: 53 to 34).
-template <int T>
-__global__ __launch_bounds__(1024) void k_cand_hist(const uint2* __restrict__ planes, int64_t n, PgKeyArg K,
-                                                    int* __restrict__ hist, int use_lds, int b_lo, int b_hi) {
-    extern __shared__ int s_hist[];      // the (block, bucket) entries of blocks [b_lo, b_hi)
-    const int e_lo = K.ebase[b_lo], n_ent = K.ebase[b_hi] - e_lo;
-    if (use_lds) {
-        for (int e = threadIdx.x; e < n_ent; e += blockDim.x) s_hist[e] = 0;
-        __syncthreads();
-    }
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const int64_t i = ((int64_t)blockIdx.x * T + t) * blockDim.x + threadIdx.x;
-        if (i < n) {
-            const uint2 e = planes[i];
-            for (int b = b_lo; b < b_hi; ++b) {
-                const int ent = K.ebase[b] + pg_key(e, K.bstart[b], K.blen[b]);
-                if (use_lds) atomicAdd(&s_hist[ent - e_lo], 1); else atomicAdd(&hist[ent], 1);
-            }
-        }
-    }
-    if (use_lds) {
-        __syncthreads();
-        for (int e = threadIdx.x; e < n_ent; e += blockDim.x)
-            if (s_hist[e] != 0) atomicAdd(&hist[e_lo + e], s_hist[e]);
-    }
-}
-
-// One workgroup per block: exclusive scan of its buckets' candidate counts -> coff[b][0..nb] and the scatter cursors,
-// and in the same pass the chunk table's geometry -- chunks per (block, bucket) entry = ceil(count / 64) x the
-// workgroups an entry's target buckets are split over, their exclusive offsets INSIDE the block (cbase) and the block's
-// total (btot) --; it leaves the histogram zeroed for the next query.  (Count and chunk sums travel through the scan as
-// one 64-bit word.)  k_chunk_starts then turns the totals into the blocks' chunk ranges.
-struct PgSubArg {
-    int n[GM_PG_MAXB];      // workgroups an entry's target buckets are split over, per block
-};
-__global__ __launch_bounds__(1024) void k_cand_offsets(PgKeyArg K, PgSubArg nsub, int* __restrict__ hist,
-                                                       int* __restrict__ cursor, int* __restrict__ cbase,
-                                                       int* __restrict__ btot) {
-    __shared__ unsigned long long s[64];
-    const int tid = threadIdx.x;
-    const int b = blockIdx.x;
-    const int e0 = K.ebase[b], nb = K.ebase[b + 1] - e0, ns = nsub.n[b];
-    const int per = (nb + 1023) / 1024;
-    const int lo = tid * per, hi = lo + per < nb ? lo + per : nb;
-    // (one workgroup per block: the kernel is a handful of waves and lives on memory latency -- a thread's <= 16 counts
-    // are fetched with all loads in flight, and written back the same way: 49 -> ~12 us for three 16 384-bucket blocks)
-    constexpr int PER_REG = 16;
-    const bool in_regs = per <= PER_REG;
-    int cnt[PER_REG];
-    unsigned long long sum = 0;
-    if (in_regs) {
-#pragma unroll
-        for (int i = 0; i < PER_REG; ++i) cnt[i] = lo + i < hi ? hist[e0 + lo + i] : 0;
-#pragma unroll
-        for (int i = 0; i < PER_REG; ++i) {
-            const unsigned c = (unsigned)cnt[i];
-            sum += (unsigned long long)c | ((unsigned long long)((c + 63u) / 64u * (unsigned)ns) << 32);
-        }
-    } else {
-        for (int v = lo; v < hi; ++v) {
-            const unsigned c = (unsigned)hist[e0 + v];
-            sum += (unsigned long long)c | ((unsigned long long)((c + 63u) / 64u * (unsigned)ns) << 32);
-        }
-    }
-    // inclusive scan over the 1024 threads: shuffles inside a wave, the 16 wave totals through LDS
-    unsigned long long inc = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const unsigned long long t = __shfl_up(inc, d, 64);
-        if ((tid & 63) >= d) inc += t;
-    }
-    if ((tid & 63) == 63) s[tid >> 6] = inc;
-    __syncthreads();
-    if (tid < 64) {
-        unsigned long long w = tid < 16 ? s[tid] : 0ull;
-#pragma unroll
-        for (int d = 1; d < 16; d <<= 1) {
-            const unsigned long long t = __shfl_up(w, d, 64);
-            if (tid >= d) w += t;
-        }
-        if (tid < 16) s[32 + tid] = w;      // inclusive totals of waves 0 .. tid
-    }
-    __syncthreads();
-    const unsigned long long wave_before = (tid >> 6) ? s[32 + (tid >> 6) - 1] : 0ull;
-    const unsigned long long before = wave_before + inc - sum, total = s[32 + 15];
-    int run = (int)(unsigned)before, run_ch = (int)(before >> 32);
-    if (in_regs) {
-#pragma unroll
-        for (int i = 0; i < PER_REG; ++i) {
-            if (lo + i < hi) {
-                const int v = lo + i, c = cnt[i];
-                K.coff[b][v] = run;
-                cursor[e0 + v] = run;
-                cbase[e0 + v] = run_ch;
-                hist[e0 + v] = 0;
-                run += c;
-                run_ch += (c + 63) / 64 * ns;
-            }
-        }
-    } else {
-        for (int v = lo; v < hi; ++v) {
-            const int c = hist[e0 + v];
-            K.coff[b][v] = run;
-            cursor[e0 + v] = run;
-            cbase[e0 + v] = run_ch;
-            hist[e0 + v] = 0;
-            run += c;
-            run_ch += (c + 63) / 64 * ns;
-        }
-    }
-    if (tid == 1023) {
-        K.coff[b][nb] = (int)(unsigned)total;
-        btot[b] = (int)(total >> 32);
-    }
-}
-
-// the chunk range of every block (ctr->cstart) and the total; also clears the per-query counters
-__global__ __launch_bounds__(64) void k_chunk_starts(const int* __restrict__ btot, int B, int* __restrict__ ctr_words,
-                                                     int ctr_n_words, int* __restrict__ cstart, int* __restrict__ n_chunks) {
-    for (int i = threadIdx.x; i < ctr_n_words; i += 64) ctr_words[i] = 0;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int run = 0;
-        for (int b = 0; b < B; ++b) {
-            cstart[b] = run;
-            run += btot[b];
-        }
-        cstart[B] = run;
-        *n_chunks = run;
-    }
-}
-
-// cperm[b][position] = candidate row; positions handed out per bucket: rank inside the workgroup from an
-// LDS counter, one global atomic per (workgroup, non-empty bucket) for the workgroup's base; T tiles of 1024
-// candidates per workgroup (see k_cand_hist); blocks [b_lo, b_hi) per launch (their entries fit the LDS table)
-template <int T>
-__global__ __launch_bounds__(1024) void k_cand_scatter(const uint2* __restrict__ planes, int64_t n, PgKeyArg K,
-                                                       int* __restrict__ cursor, int use_lds, int b_lo, int b_hi) {
-    extern __shared__ int s_cnt[];      // [entries of the blocks] counts, then reused as bases
-    const int e_lo = K.ebase[b_lo], n_ent = K.ebase[b_hi] - e_lo;
-    int ent[T][GM_PG_MAXB], rank[T][GM_PG_MAXB];
-    if (use_lds) {
-        for (int e = threadIdx.x; e < n_ent; e += blockDim.x) s_cnt[e] = 0;
-        __syncthreads();
-    }
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const int64_t i = ((int64_t)blockIdx.x * T + t) * blockDim.x + threadIdx.x;
-        if (i < n) {
-            const uint2 e = planes[i];
-#pragma unroll
-            for (int b = 0; b < GM_PG_MAXB; ++b) {
-                if (b >= b_lo && b < b_hi) {
-                    ent[t][b] = K.ebase[b] + pg_key(e, K.bstart[b], K.blen[b]) - e_lo;
-                    rank[t][b] = use_lds ? atomicAdd(&s_cnt[ent[t][b]], 1) : atomicAdd(&cursor[e_lo + ent[t][b]], 1);
-                }
-            }
-        }
-    }
-    if (use_lds) {
-        __syncthreads();
-        // the workgroup's base in every bucket it touched: the returning atomics of a thread's (up to 16) entries are
-        // independent -- issue them back to back instead of one memory round trip per loop iteration
-        for (int p0 = 0; p0 < n_ent; p0 += 16 * 1024) {      // (passes of 16 entries per thread: up to 36 864 entries)
-            int cs[16], bs[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int e = p0 + threadIdx.x + j * 1024;
-                cs[j] = e < n_ent ? s_cnt[e] : 0;
-            }
-#pragma unroll
-            for (int j = 0; j < 16; ++j) bs[j] = cs[j] != 0 ? atomicAdd(&cursor[e_lo + p0 + threadIdx.x + j * 1024], cs[j]) : 0;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int e = p0 + threadIdx.x + j * 1024;
-                if (e < n_ent) s_cnt[e] = bs[j];
-            }
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const int64_t i = ((int64_t)blockIdx.x * T + t) * blockDim.x + threadIdx.x;
-        if (i < n) {
-#pragma unroll
-            for (int b = 0; b < GM_PG_MAXB; ++b) {
-                if (b >= b_lo && b < b_hi) {
-                    const int pos = use_lds ? s_cnt[ent[t][b]] + rank[t][b] : rank[t][b];
-                    K.cperm[b][pos] = (uint32_t)i;
-                }
-            }
-        }
-    }
-}
+#include "gm_group.hip.h"      // PgKeyArg, PgSubArg, k_cand_hist / k_cand_offsets / k_chunk_starts / k_cand_scatter, gm_group_launch
 
 // sorted position i (key v = keys[i], pool row rows[i]) -> position bdesc[v].x * 64 + (i - raw_off[v]) of the padded copy
 __global__ __launch_bounds__(256) void k_scatter_recs(const uint2* __restrict__ planes, const uint32_t* __restrict__ keys,
@@ -1481,57 +1266,9 @@ int gm_pg_candidates(gm_index* idx, int64_t n_q, hipStream_t st) {
     }
     PgSubArg nsub{};
     for (int b = 0; b < pg->B; ++b) nsub.n[b] = pg->nsub[b];
-    // tiles of 1024 candidates per workgroup: as many as leave ~128 workgroups
-    const int tiles = n_q >= (int64_t)1024 * 128 * 4 ? 4 : (n_q >= (int64_t)1024 * 128 * 2 ? 2 : 1);
-    const dim3 cgrid = grid_for(n_q, 1024 * tiles);
-    // (up to 36 864 counters = 144 KiB of the CU's 160 KiB: the 7 / 7 / 6-base blocks of a large pool in ONE launch each
-    // for the histogram and the scatter instead of three; above the default 64 KiB the kernels need the attribute, per device)
-    constexpr int LDS_ENTRIES = 36864;
-    {
-        static bool attr_set[64] = {};
-        const int dev = idx->device >= 0 && idx->device < 64 ? idx->device : 0;
-        if (!attr_set[dev]) {
-            const void* fns[] = {reinterpret_cast<const void*>(k_cand_hist<1>), reinterpret_cast<const void*>(k_cand_hist<2>),
-                                 reinterpret_cast<const void*>(k_cand_hist<4>), reinterpret_cast<const void*>(k_cand_scatter<1>),
-                                 reinterpret_cast<const void*>(k_cand_scatter<2>), reinterpret_cast<const void*>(k_cand_scatter<4>)};
-            for (const void* f : fns) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ENTRIES * (int)sizeof(int)));
-            attr_set[dev] = true;
-        }
-    }
-    struct Run { int lo, hi, lds; };
-    Run runs[GM_PG_MAXB];
-    int n_runs = 0;
-    for (int b = 0; b < pg->B;) {
-        const int nb = pg->ebase[b + 1] - pg->ebase[b];
-        if (nb > LDS_ENTRIES) {
-            runs[n_runs++] = Run{b, b + 1, 0};
-            ++b;
-            continue;
-        }
-        int hi = b + 1;
-        while (hi < pg->B && pg->ebase[hi + 1] - pg->ebase[b] <= LDS_ENTRIES) ++hi;
-        runs[n_runs++] = Run{b, hi, 1};
-        b = hi;
-    }
-#define GM_LAUNCH_T(KERN, ...)                                                                          \
-    do {                                                                                                \
-        if (tiles == 4) hipLaunchKernelGGL(KERN<4>, cgrid, dim3(1024), lds, st, __VA_ARGS__);            \
-        else if (tiles == 2) hipLaunchKernelGGL(KERN<2>, cgrid, dim3(1024), lds, st, __VA_ARGS__);       \
-        else hipLaunchKernelGGL(KERN<1>, cgrid, dim3(1024), lds, st, __VA_ARGS__);                       \
-    } while (0)
-    for (int i = 0; i < n_runs; ++i) {
-        const size_t lds = runs[i].lds ? sizeof(int) * (size_t)(pg->ebase[runs[i].hi] - pg->ebase[runs[i].lo]) : 0;
-        GM_LAUNCH_T(k_cand_hist, idx->d_q, n_q, K, pg->hist, runs[i].lds, runs[i].lo, runs[i].hi);
-    }
-    hipLaunchKernelGGL(k_cand_offsets, dim3(pg->B), dim3(1024), 0, st, K, nsub, pg->hist, pg->cursor, pg->cbase, pg->nch);
-    hipLaunchKernelGGL(k_chunk_starts, dim3(1), dim3(64), 0, st, pg->nch, pg->B, reinterpret_cast<int*>(pg->ctr),
-                       (int)(sizeof(PgCounters) / sizeof(int)), pg->ctr->cstart, &pg->ctr->n_chunks);
-    for (int i = 0; i < n_runs; ++i) {
-        const size_t lds = runs[i].lds ? sizeof(int) * (size_t)(pg->ebase[runs[i].hi] - pg->ebase[runs[i].lo]) : 0;
-        GM_LAUNCH_T(k_cand_scatter, idx->d_q, n_q, K, pg->cursor, runs[i].lds, runs[i].lo, runs[i].hi);
-    }
-#undef GM_LAUNCH_T
-    HIP_TRY(hipGetLastError());
+    if ((rc = gm_group_launch(idx->d_q, n_q, K, nsub, pg->hist, pg->cursor, pg->cbase, pg->nch, reinterpret_cast<int*>(pg->ctr),
+                              (int)(sizeof(PgCounters) / sizeof(int)), pg->ctr->cstart, &pg->ctr->n_chunks, idx->device, st)))
+        return rc;
     hipLaunchKernelGGL(k_fill_chunks, grid_for((int64_t)A.n_entries * A.smax), dim3(256), 0, st, A, pg->cbase, pg->chunks, pg->ctr);
     HIP_TRY(hipGetLastError());
     pg->grid = grid;

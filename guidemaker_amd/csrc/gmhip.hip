@@ -307,16 +307,6 @@ __global__ __launch_bounds__(256) void k_lev_unvouched(int32_t* __restrict__ cou
     if (i < n && (counts[i] < k || dists[i * k + (k - 1)] > r)) counts[i] = 0;
 }
 
-int launch_merge_unique(int kcap, const uint32_t* keys, int n_lists, int64_t n_q, int k, int32_t* ids, int32_t* dists,
-                        int32_t* counts, hipStream_t st) {
-    constexpr int SP = 4;
-    const dim3 grid((unsigned)((n_q * SP + 255) / 256)), block(256);
-    if (kcap == 10) hipLaunchKernelGGL((gm::k_merge_lists_unique<10, SP>), grid, block, 0, st, keys, n_lists, n_q, k, ids, dists, counts);
-    else hipLaunchKernelGGL((gm::k_merge_lists_unique<20, SP>), grid, block, 0, st, keys, n_lists, n_q, k, ids, dists, counts);
-    HIP_TRY(hipGetLastError());
-    return GM_OK;
-}
-
 // Partitioned first pass of run_leven_lookup.  ids / dists / counts hold the Hamming k-NN of the candidates (the seeds:
 // lev <= hamming) on entry and the partition's result on return (*used); rows it cannot vouch for come back with
 // count 0 and take the caller's second pass under their own seeds.  The radius is chosen from a sample: 1 024 candidates
@@ -381,7 +371,9 @@ int run_leven_partition(gm_index* idx, int64_t n_q, int k, int kcap, int32_t* id
                 beyond_r[rr] = (double)beyond / (double)n_s;
             }
             int best_r = 0, best_r2 = 0;
-            double best = 0.6;      // the partition has to be clearly cheaper than the plain pass
+            // (the model tracks the measurements: S2, r = 7: modelled 0.78 of the plain pass, measured 7.1 of 9.2 ms; PAO1 cut at
+            // L = 23, r = 5 + 6: 0.28 / 0.26 -- a partition has to promise 15 %)
+            double best = 0.85;
             const int tune2 = gm_lp_tune_radius2(idx);
             for (int rr = 1; rr <= 7; ++rr) {
                 if (!have_r[rr]) continue;
@@ -425,8 +417,7 @@ int run_leven_partition(gm_index* idx, int64_t n_q, int k, int kcap, int32_t* id
     idx->last_kernel = "k_leven_part_bs";
     if ((rc = gm_lp_scan(idx, idx->d_q, n_q, k, kcap, dists, counts, k, st, &keys, &n_lists))) return rc;
     if ((rc = timing_end(idx, st, n_q * idx->n_db))) return rc;
-    idx->last_evaluated = gm_lp_last_pairs(idx);
-    if ((rc = launch_merge_unique(kcap, keys, n_lists, n_q, k, ids, dists, counts, st))) return rc;
+    if ((rc = gm_lp_merge(idx, kcap, n_q, k, ids, dists, counts, st))) return rc;
     hipLaunchKernelGGL(k_lev_unvouched, dim3((unsigned)((n_q + 255) / 256)), dim3(256), 0, st, counts, dists, n_q, k, r);
     HIP_TRY(hipGetLastError());
     *used = true;
@@ -458,8 +449,7 @@ int run_leven_partition_deeper(gm_index* idx, int r2, const uint2* q2, int64_t n
     const uint32_t* keys = nullptr;
     int n_lists = 0;
     if ((rc = gm_lp_scan(idx, q2, n2, k, kcap, seeds2, nullptr, 1, st, &keys, &n_lists))) return rc;
-    idx->lp_pairs2 = gm_lp_last_pairs(idx);
-    if ((rc = launch_merge_unique(kcap, keys, n_lists, n2, k, ids2, dists2, counts2, st))) return rc;
+    if ((rc = gm_lp_merge(idx, kcap, n2, k, ids2, dists2, counts2, st))) return rc;
     hipLaunchKernelGGL(k_lev_unvouched, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, counts2, dists2, n2, k, r2);
     HIP_TRY(hipGetLastError());
     *used = true;
@@ -555,6 +545,7 @@ int run_leven_lookup(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* d
     int64_t n2 = 0;
     if ((rc = gm_pg_read_bad(idx, &n2, st))) return rc;
     idx->last_incomplete = n2;
+    if (part_used) idx->last_evaluated = gm_lp_last_pairs(idx, 0);      // (the read-back above synchronised the stream)
     if (n2 * 4 > n_q && !part_used) idx->lv_two_pass = 0;      // the lowered bound left a quarter of the lists short on this pool: not again
     if (n2 == 0) return GM_OK;
     const uint2* q2 = nullptr;
@@ -577,6 +568,7 @@ int run_leven_lookup(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* d
             if ((rc = gm_pg_read_bad(idx, &n3, st))) return rc;
             idx->lp_left2 = n3;
             idx->last_incomplete = n3;
+            idx->lp_pairs2 = gm_lp_last_pairs(idx, 1);
             if (std::getenv("GM_DEBUG"))
                 fprintf(stderr, "[gm] K2P second level: %lld rows, radius %d, %.3g pairs, %lld rows left for the plain pass\n",
                         (long long)n2, r_part2, (double)idx->lp_pairs2, (long long)n3);

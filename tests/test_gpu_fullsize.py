@@ -146,15 +146,26 @@ def test_leven_workload_full_size(oracle):
     idx = _lib.Index(db, L, _lib.METRIC_LEVEN)
     try:
         ids, dists, counts = idx.knn(q, k)
-        assert idx.last_kernel()[0] == "k_leven_knn_bs"
+        # what bench.py runs on S2: K2P, the displaced-block partition (radius 7 of 23: the 5th neighbour of ~97 % of the
+        # candidates lies within it; the planner's sample prices it at ~0.78 of the plain pass), the rest in a plain pass
+        assert idx.last_kernel()[0] == "k_leven_part_bs"
+        info = idx.levpart_info()
+        assert info["r1"] == 7 and info["r2"] == 0
+        evaluated, second = idx.last_evaluated()
+        assert 0 < evaluated < 0.8 * q.shape[0] * db.shape[0] and 0 < second < 0.1 * q.shape[0]
         _check_properties(pool, ids, dists, counts)
         # lev <= hamming, column by column
         hidx = _lib.Index(db, L, _lib.METRIC_HAMMING)
         _, hd, _ = hidx.knn(q, k)
         hidx.close()
         assert (dists <= hd).all()
-        # narrow-band first pass + second pass for the short lists (default) against one pass under the Hamming seeds
+        # ... against the plain K2B scan: narrow-band first pass + second pass for the short lists, then one pass under the
+        # Hamming seeds
+        idx.set_param("lp_radius", -1)
+        i0, d0, c0 = idx.knn(q, k)
+        assert idx.last_kernel()[0] == "k_leven_knn_bs"
         assert idx.last_evaluated()[1] > 0      # (S2: ~3 % of the candidates take the second pass)
+        assert (i0 == ids).all() and (d0 == dists).all() and (c0 == counts).all()
         idx.set_param("lv_two_pass", 0)
         i1, d1, c1 = idx.knn(q, k)
         assert (i1 == ids).all() and (d1 == dists).all() and (c1 == counts).all()
