@@ -9,13 +9,13 @@
 //   candidate's bases of block j at the block's positions + d.
 //
 // Pool side (once per index and radius): for every (block, displacement) pair that stays inside the sequence a "copy" of
-// the pool, stable-sorted by the bases at the displaced positions, buckets padded to whole K2B tiles (256 targets), with
-// the position -> pool id map and the one-hot table of the copy (all L positions: the DP needs them all).  Query side:
-// per block one radix sort of the candidates by the block's value, bucket offsets read back, the chunk table (<= 64
-// candidates of one bucket per workgroup) built on the host.  One workgroup compares its chunk with bucket v of every
-// copy of its block.  Work on P. aeruginosa PAO1 cut at L = 23 (1.16 M targets), r = 5: 6 blocks x 5 displacements of
-// 4-base blocks: ~17 % of the pairs.  On pools where the k-th neighbour lies at 7 of 23 (S2: 136 k targets) eight 3-base
-// blocks x 7 displacements would visit 80 % of the pool: the planner (gmhip.hip) keeps those on the plain K2B scan.
+// the pool, stable-sorted by the bases at the displaced positions, buckets starting on whole K2B tiles (256 targets), with
+// the position -> pool id map and the one-hot table of the copy (all L positions: the DP needs them all).  Query side: the
+// candidates grouped by every block's value on the device (gm_group.hip.h), chunk table (<= 64 candidates of one bucket
+// per workgroup) laid out there too.  One workgroup compares its chunk with bucket v of every copy of its block.  Work on
+// P. aeruginosa PAO1 cut at L = 23 (1.16 M targets): r = 5: 20 copies, ~13 % of the pairs, then r = 6 (30 copies, 38 %) for
+// the quarter of the rows whose k-th neighbour lies beyond 5.  S2 (136 k targets, k-th neighbour at 7 of 23): r = 7, 37
+// copies, 62 % of the pairs in the three-diagonal band -- 0.78 of the plain scan's time.
 #include "gm_host.h"
 
 #include <cmath>
