@@ -293,10 +293,10 @@ __global__ __launch_bounds__(256) void k_lev_sample_rows(const uint2* __restrict
     if (t >= n_s * k) return;
     const int64_t j = t / k;
     const int s = (int)(t % k);
-    d_s[t] = dists[j * stride * k + s];
+    if (dists != nullptr) d_s[t] = dists[j * stride * k + s];
     if (s == 0) {
         q_s[j] = q[j * stride];
-        c_s[j] = counts[j * stride];
+        if (counts != nullptr) c_s[j] = counts[j * stride];
     }
 }
 
@@ -307,11 +307,12 @@ __global__ __launch_bounds__(256) void k_lev_unvouched(int32_t* __restrict__ cou
     if (i < n && (counts[i] < k || dists[i * k + (k - 1)] > r)) counts[i] = 0;
 }
 
-// Partitioned first pass of run_leven_lookup.  ids / dists / counts hold the Hamming k-NN of the candidates (the seeds:
-// lev <= hamming) on entry and the partition's result on return (*used); rows it cannot vouch for come back with
-// count 0 and take the caller's second pass under their own seeds.  The radius is chosen from a sample: 1 024 candidates
-// through the plain K2B scan give the distribution of the k-th EDIT distance, and r minimises
-// [share of the pool the layout of radius r visits] x 1.2 + [share of the rows whose k-th neighbour lies beyond r].
+// Partitioned first pass of run_leven_lookup: ids / dists / counts receive the partition's result (*used); rows it cannot
+// vouch for come back with count 0 and go on to the caller's further passes.  It runs UNSEEDED: its bounds are clamped
+// to radius + 1 anyway, so the Hamming k-NN of all candidates (the seeds of the plain scan) would buy nothing -- only the
+// planner's sample and the rows that reach the plain pass get Hamming seeds.  The radius is chosen from a sample: 1 024
+// candidates through the plain K2B scan (under their own Hamming seeds) give the distribution of the k-th EDIT distance,
+// and r minimises the modelled cost below.
 int run_leven_partition(gm_index* idx, int64_t n_q, int k, int kcap, int32_t* ids, int32_t* dists, int32_t* counts, hipStream_t st,
                         bool* used, int* r_used, int* r2_used) {
     *used = false;
@@ -338,8 +339,13 @@ int run_leven_partition(gm_index* idx, int64_t n_q, int k, int kcap, int32_t* id
                 (void)hipFree(q_s); (void)hipFree(d_s); (void)hipFree(i_s); (void)hipFree(c_s);
                 return fail(GM_ERR_ALLOC, "hipMalloc(K2P sample) failed");
             }
-            hipLaunchKernelGGL(k_lev_sample_rows, dim3((unsigned)((n_s * k + 255) / 256)), dim3(256), 0, st, idx->d_q, dists, counts,
-                               stride, n_s, k, q_s, d_s, c_s);
+            hipLaunchKernelGGL(k_lev_sample_rows, dim3((unsigned)((n_s * k + 255) / 256)), dim3(256), 0, st, idx->d_q,
+                               (const int32_t*)nullptr, (const int32_t*)nullptr, stride, n_s, k, q_s, d_s, c_s);
+            // (the sample's seeds: the exact Hamming k-NN of these 1 024 rows, lev <= hamming)
+            if ((rc = run_hamming_lookup(idx, false, n_s, k, i_s, d_s, c_s, false, st, q_s))) {
+                (void)hipFree(q_s); (void)hipFree(d_s); (void)hipFree(i_s); (void)hipFree(c_s);
+                return rc;
+            }
             const int64_t n_tiles = idx->n_lk_tiles;
             int64_t want = 64 < n_tiles ? 64 : n_tiles;
             const int tps = (int)((n_tiles + want - 1) / want);
@@ -415,7 +421,7 @@ int run_leven_partition(gm_index* idx, int64_t n_q, int k, int kcap, int32_t* id
     int n_lists = 0;
     if ((rc = timing_begin(idx, st))) return rc;
     idx->last_kernel = "k_leven_part_bs";
-    if ((rc = gm_lp_scan(idx, idx->d_q, n_q, k, kcap, dists, counts, k, st, &keys, &n_lists))) return rc;
+    if ((rc = gm_lp_scan(idx, idx->d_q, n_q, k, kcap, nullptr, nullptr, 1, st, &keys, &n_lists))) return rc;
     if ((rc = timing_end(idx, st, n_q * idx->n_db))) return rc;
     if ((rc = gm_lp_merge(idx, kcap, n_q, k, ids, dists, counts, st))) return rc;
     hipLaunchKernelGGL(k_lev_unvouched, dim3((unsigned)((n_q + 255) / 256)), dim3(256), 0, st, counts, dists, n_q, k, r);
@@ -460,16 +466,27 @@ int run_leven_lookup(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* d
                      int32_t* d1, hipStream_t st) {
     const bool nearest = d1 != nullptr;
     const int kcap = nearest ? 1 : (k <= 10 ? 10 : 20);    // (a capacity-5 instantiation measured slower than 10)
-    // seeds: the exact Hamming k-NN of the same candidates (lev <= hamming) -- through the pigeonhole-partitioned scan
-    // where the planner finds a layout (pools >= 32 768), else the plain two-phase scan
-    bool seeded = false;
     int rc = GM_OK;
-    if (idx->variant == 0) {
+    // the partitioned pass (K2P) where the planner finds a radius that pays: it runs first and unseeded (its bounds are
+    // clamped to the radius); only the rows it cannot vouch for need Hamming seeds, further down
+    const bool try_part = !nearest && idx->variant != 2 && gm_lp_tune_radius(idx) >= 0 &&
+                          (gm_lp_tune_radius(idx) > 0 || (idx->n_db >= 65536 && n_q >= 8192));
+    bool part_used = false;
+    int r_part = 0, r_part2 = 0;
+    idx->lp_r1 = idx->lp_r2 = 0;
+    idx->lp_rows2 = idx->lp_pairs2 = idx->lp_left2 = 0;
+    if (try_part && (rc = run_leven_partition(idx, n_q, k, kcap, ids, dists, counts, st, &part_used, &r_part, &r_part2))) return rc;
+    // seeds of the plain scan: the exact Hamming k-NN of the same candidates (lev <= hamming) -- through the
+    // pigeonhole-partitioned scan where the planner finds a layout (pools >= 32 768), else the plain two-phase scan
+    bool seeded = false;
+    if (part_used) {
+        // (nothing to seed here)
+    } else if (idx->variant == 0) {
         rc = nearest ? run_hamming_pigeon(idx, true, n_q, 1, nullptr, d1, nullptr, st, &seeded, false)
                      : run_hamming_pigeon(idx, false, n_q, k, ids, dists, counts, st, &seeded, false);
         if (rc) return rc;
     }
-    if (!seeded)
+    if (!seeded && !part_used)
         rc = nearest ? run_hamming_lookup(idx, true, n_q, 1, nullptr, d1, nullptr, false, st)
                      : run_hamming_lookup(idx, false, n_q, k, ids, dists, counts, false, st);
     if (rc) return rc;
@@ -497,14 +514,10 @@ int run_leven_lookup(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* d
     // under their own seeds.  The kernel takes the decision from a counter on the device: no read-back for it.
     const int band = ((3 * idx->L + 4) / 8) / 2;      // lvb_band(L), gm_leven_bs.hip.h
     const int cap_thr = 2 * (band - 1) + 2;
-    bool two_pass = !nearest && algo == 1 && seeded && band - 1 >= 2 && idx->lv_two_pass && n_q >= 4096;
-    // the partitioned pass (K2P) where the planner finds a radius that pays; it needs the kept bounds for its second pass too
-    // (the Hamming k-NN of the candidates are in ids / dists / counts whichever scan produced them)
-    const bool try_part = !nearest && algo == 1 && gm_lp_tune_radius(idx) >= 0 &&
-                          (gm_lp_tune_radius(idx) > 0 || (idx->n_db >= 65536 && n_q >= 8192));
+    bool two_pass = part_used || (!nearest && algo == 1 && seeded && band - 1 >= 2 && idx->lv_two_pass && n_q >= 4096);
     gm_lv_opt opt{};
     uint32_t* thr_all = nullptr;
-    if (two_pass || try_part) {
+    if (two_pass && !part_used) {
         // [n_q bounds][n_q compact seeds][1 counter]
         if ((rc = ensure_u32(&idx->d_lvthr, &idx->lvthr_cap, 2 * n_q + 4))) return rc;
         thr_all = idx->d_lvthr;
@@ -517,14 +530,6 @@ int run_leven_lookup(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* d
             opt.cap_cnt = cnt;
             opt.cap_thr = cap_thr;
         }
-    }
-    bool part_used = false;
-    int r_part = 0, r_part2 = 0;
-    idx->lp_r1 = idx->lp_r2 = 0;
-    idx->lp_rows2 = idx->lp_pairs2 = idx->lp_left2 = 0;
-    if (try_part) {
-        if ((rc = run_leven_partition(idx, n_q, k, kcap, ids, dists, counts, st, &part_used, &r_part, &r_part2))) return rc;
-        if (part_used) two_pass = true;      // (the rows it does not vouch for -- count 0 -- take the second pass below)
     }
     if (!part_used) {
     rc = timing_begin(idx, st);
@@ -551,14 +556,18 @@ int run_leven_lookup(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* d
     const uint2* q2 = nullptr;
     int32_t *ids2 = nullptr, *dists2 = nullptr, *counts2 = nullptr;
     if ((rc = gm_pg_gather(idx, n2, k, false, &q2, &ids2, &dists2, &counts2, st))) return rc;
-    int32_t* seeds2 = reinterpret_cast<int32_t*>(idx->d_lvthr + n_q);
-    hipLaunchKernelGGL(k_lev_gather_seeds, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, thr_all, gm_pg_inc_list(idx), n2,
-                       seeds2);
-    HIP_TRY(hipGetLastError());
+    int32_t* seeds2 = nullptr;
+    if (!part_used) {
+        seeds2 = reinterpret_cast<int32_t*>(idx->d_lvthr + n_q);
+        hipLaunchKernelGGL(k_lev_gather_seeds, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, thr_all, gm_pg_inc_list(idx), n2,
+                           seeds2);
+        HIP_TRY(hipGetLastError());
+    }
     if (part_used && r_part2 > r_part && (n2 >= 4096 || gm_lp_tune_radius2(idx) > 0)) {
-        // K2P's second level: these rows through the layout of radius r + 1, then only what THAT leaves takes the plain pass
+        // K2P's second level: these rows through the layout of radius r + 1 (unseeded: bounds clamped to that radius), then
+        // only what THAT leaves takes the plain pass
         bool used2 = false;
-        if ((rc = run_leven_partition_deeper(idx, r_part2, q2, n2, k, kcap, seeds2, ids2, dists2, counts2, st, &used2))) return rc;
+        if ((rc = run_leven_partition_deeper(idx, r_part2, q2, n2, k, kcap, nullptr, ids2, dists2, counts2, st, &used2))) return rc;
         if (used2) {
             if ((rc = gm_pg_scatter(idx, n2, k, false, ids, dists, counts, st))) return rc;
             idx->lp_r2 = r_part2;
@@ -575,10 +584,17 @@ int run_leven_lookup(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* d
             if (n3 == 0) return GM_OK;
             n2 = n3;
             if ((rc = gm_pg_gather(idx, n2, k, false, &q2, &ids2, &dists2, &counts2, st))) return rc;
-            hipLaunchKernelGGL(k_lev_gather_seeds, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, thr_all, gm_pg_inc_list(idx),
-                               n2, seeds2);
-            HIP_TRY(hipGetLastError());
         }
+    }
+    int seed_k2 = 1;
+    const int32_t* seed_c2 = nullptr;
+    if (part_used) {
+        // the rows the partition leaves: their Hamming k-NN (plain two-phase look-up scan over the compact rows) are the
+        // seeds of the plain pass, read from the compact result arrays the pass then overwrites
+        if ((rc = run_hamming_lookup(idx, false, n2, k, ids2, dists2, counts2, false, st, q2))) return rc;
+        seeds2 = dists2;
+        seed_c2 = counts2;
+        seed_k2 = k;
     }
     const int64_t chunks2 = (n2 + gm::WAVE - 1) / gm::WAVE;
     int64_t want2 = ((int64_t)idx->n_simd * 8 + chunks2 - 1) / chunks2;
@@ -590,7 +606,7 @@ int run_leven_lookup(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* d
     if ((rc = ensure_u32(&idx->d_keys2, &idx->keys2_cap, (int64_t)n_seg2 * n2 * kcap))) return rc;
     gm_lv_opt opt2{};
     opt2.q = q2;
-    if ((rc = launch_lv_by_len(idx, algo, kcap, n2, k, n_seg2, tps2, seeds2, nullptr, 1, idx->d_keys2, st, &opt2))) return rc;
+    if ((rc = launch_lv_by_len(idx, algo, kcap, n2, k, n_seg2, tps2, seeds2, seed_c2, seed_k2, idx->d_keys2, st, &opt2))) return rc;
     if ((rc = launch_merge(kcap, idx->d_keys2, n_seg2, n2, k, ids2, dists2, counts2, false, st))) return rc;
     return gm_pg_scatter(idx, n2, k, false, ids, dists, counts, st);
 }
