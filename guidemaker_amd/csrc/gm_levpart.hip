@@ -18,6 +18,7 @@
 // copies, 62 % of the pairs in the three-diagonal band -- 0.78 of the plain scan's time.
 #include "gm_host.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -356,6 +357,41 @@ int gm_lp_prepare(gm_index* idx, int r, hipStream_t st) {
     if (n_copies < 1) return gm_fail(GM_ERR_ARG, "K2P: no layout for this radius / guide length");
     lp->n_blocks = r + 1;
     lp->sh = r / 2;
+    {
+        // Launch order: the chunk table is laid out block by block, and a chunk's work is (copies of its block) x (bucket
+        // size): blocks with the longest chunks first, so that the launch does not end on a few workgroups that each still
+        // have a seven-copy chunk of large buckets to go (S2: chunks of 63 .. 238 groups, four rounds of the wave slots).
+        const int B = lp->n_blocks;
+        int order[GM_LP_MAXBLK];
+        double work[GM_LP_MAXBLK];
+        for (int j = 0; j < B; ++j) {
+            order[j] = j;
+            work[j] = (double)(lp->first_copy[j + 1] - lp->first_copy[j]) * std::pow(p_match >= 0.25 ? p_match : 0.25, (double)lp->blen[j]);
+        }
+        std::stable_sort(order, order + B, [&](int a, int b) { return work[a] > work[b]; });
+        int bs[GM_LP_MAXBLK], bl[GM_LP_MAXBLK], cb[GM_LP_MAXCOPY], cs[GM_LP_MAXCOPY], fc[GM_LP_MAXBLK + 1];
+        int at = 0;
+        for (int slot = 0; slot < B; ++slot) {
+            const int j = order[slot];
+            bs[slot] = lp->bstart[j];
+            bl[slot] = lp->blen[j];
+            fc[slot] = at;
+            for (int c = lp->first_copy[j]; c < lp->first_copy[j + 1]; ++c, ++at) {
+                cb[at] = slot;
+                cs[at] = lp->copy_shift[c];
+            }
+        }
+        fc[B] = at;
+        for (int j = 0; j < B; ++j) {
+            lp->bstart[j] = bs[j];
+            lp->blen[j] = bl[j];
+        }
+        for (int j = 0; j <= B; ++j) lp->first_copy[j] = fc[j];
+        for (int c = 0; c < n_copies; ++c) {
+            lp->copy_block[c] = cb[c];
+            lp->copy_shift[c] = cs[c];
+        }
+    }
     const int64_t n = idx->n_db;
     int rc;
     if ((rc = lp_sort_buffers(lp, n))) return rc;
