@@ -27,9 +27,9 @@ struct gm_pg_blocks {
     int n_lists;
     int run;                             // consecutive chunk-table entries executed on the same XCD
     int debug;                           // timing experiments only (gm_set_param "pg_debug"): bit 0 = skip the list stores
-    int row_words;                       // words of one candidate's row of the hit buffer: [keys of list 0][keys of list 1] ...
-    int lcap[GM_PG_MAXLISTS];            // key capacity of list l (a multiple of 4)
-    int loff[GM_PG_MAXLISTS];            // the keys of list l of candidate q start at word q * row_words + loff[l]
+    int row_words;                       // words of one candidate's row of the hit buffer: [keys 0..3 of every list][keys 4.. of list 0] ...
+    int lcap[GM_PG_MAXLISTS];            // key capacity of list l (a multiple of 4, at least 4)
+    int loff[GM_PG_MAXLISTS];            // keys 0..3 of list l of candidate q: word q * row_words + 4 l; keys 4..: q * row_words + loff[l]
     uint32_t* hdr;                       // [n_q][hdr_words]: the keys appended to list l of candidate q (more than lcap[l]: the
                                          // list overflowed), written once by the list's workgroup -- a dense array of its own:
                                          // the merge reads the headers of consecutive candidates from consecutive lines

@@ -1318,8 +1318,15 @@ static void pg_list_capacity(const gm_index* idx, gm_pigeon* pg, int64_t n_q) {
             int cap = ((int)c + 3) / 4 * 4;
             if (cap < 4) cap = 4;
             P.lcap[l] = cap;
-            P.loff[l] = (int)words;
             words += cap;
+        }
+        // row = [keys 0 .. 3 of every list][keys 4 .. of list 0][of list 1] ...: loff[l] = where list l's keys 4 .. start
+        {
+            int64_t at = 4 * (int64_t)P.n_lists;
+            for (int l = 0; l < P.n_lists; ++l) {
+                P.loff[l] = (int)at;
+                at += P.lcap[l] - 4;
+            }
         }
         P.row_words = (int)words;
         if ((double)words * (double)n_q * 4.0 <= pg->mem_limit || scale < 0.05) break;

@@ -154,7 +154,7 @@ struct PgQueue {
 
 // FLUSH: n (<= 64, wave-uniform) queued hit words are turned into list entries, one per lane.
 __device__ __forceinline__ void pg_flush(PgQueue& Q, int n, int lane, const uint4* __restrict__ recs,
-                                         uint32_t* __restrict__ lists, int lcap, int row_words, int k, int thr0,
+                                         uint32_t* __restrict__ lists, int off_a, int off_b, int lcap, int row_words, int k, int thr0,
                                          int debug = 0, uint32_t cut_id = 0xffffffffu, int n_before = 0,
                                          const uint32_t* bmask = nullptr, const int* brad = nullptr) {
     uint32_t tg = 0;
@@ -189,7 +189,8 @@ __device__ __forceinline__ void pg_flush(PgQueue& Q, int n, int lane, const uint
         inc34 += (d < thr0 - 3 ? 1u : 0u) + (d < thr0 - 4 ? 0x10000u : 0u);
         if (!owned) continue;
         const int slot = atomicAdd(&Q.cnt[cl], 1);
-        if (slot < lcap && !(debug & 1)) lists[row * row_words + slot] = ((uint32_t)d << ID_BITS) | t.z;
+        // (the first four keys of every list of a row sit together at the row's start, the rest list by list)
+        if (slot < lcap && !(debug & 1)) lists[row * row_words + (slot < 4 ? off_a : off_b) + slot] = ((uint32_t)d << ID_BITS) | t.z;
     }
     if (k == 1) {
         if (best < 64) atomicMin(&Q.c12[cl], (uint32_t)best);
@@ -292,7 +293,9 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
         ptr[p] = tiles + p * 8 + (int)code * 2;
     }
     const int lcap = P.lcap[ch.lst], row_words = P.row_words;
-    uint32_t* __restrict__ mylists = lists + P.loff[ch.lst];     // keys of candidate row: mylists + row * row_words
+    // keys of candidate row: slots 0 .. 3 at lists + row * row_words + 4 lst, slot s >= 4 at ... + loff[lst] + (s - 4)
+    uint32_t* __restrict__ mylists = lists;
+    const int off_a = 4 * ch.lst, off_b = P.loff[ch.lst] - 4;
     int thr = valid && !(P.debug & 2) ? thr0 : 0;              // accept d < thr  (debug bit 1: no hits at all, timing only)
     uint32_t Tb[5];
     // the blocks before this one (position masks, radii): a pair one of them finds is theirs to report
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
     // flush when a full wave of entries is queued; afterwards the bounds may have tightened
 #define GM_PG_AFTER_GROUP()                                                       \
     if (Q.tail - Q.head >= WAVE) {                                                \
-        pg_flush(Q, WAVE, lane, recs, mylists, lcap, row_words, k, thr0, P.debug, cut_id, ch.b, bmask, brad); \
+        pg_flush(Q, WAVE, lane, recs, mylists, off_a, off_b, lcap, row_words, k, thr0, P.debug, cut_id, ch.b, bmask, brad); \
         const int nt = pg_bound(Q, lane, k, thr0);                                \
         if (valid && nt < thr) thr = nt;                                          \
         cur = -1;                                                                 \
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
 #undef GM_PG_BOUND
     while (Q.tail - Q.head > 0) {
         const int n_take = Q.tail - Q.head < WAVE ? Q.tail - Q.head : WAVE;
-        pg_flush(Q, n_take, lane, recs, mylists, lcap, row_words, k, thr0, P.debug, cut_id, ch.b, bmask, brad);
+        pg_flush(Q, n_take, lane, recs, mylists, off_a, off_b, lcap, row_words, k, thr0, P.debug, cut_id, ch.b, bmask, brad);
     }
     // every (list, candidate) pair has exactly one writer (the row number comes back from LDS: a 64-bit index kept in
     // registers across the scan loop is two VGPRs the loop does not have)
@@ -408,7 +411,7 @@ __global__ void k_merge_hits(gm_pg_blocks P, const uint32_t* __restrict__ lists,
     RegList<KCAP> list;
     list.init(k, nullptr, 0);
     int overflow = 0;
-    const uint32_t* __restrict__ row = lists + qi * P.row_words;      // [keys of list 0][keys of list 1] ...
+    const uint32_t* __restrict__ row = lists + qi * P.row_words;      // [keys 0..3 of every list][keys 4.. of list 0][of list 1] ...
     const uint32_t* __restrict__ hrow = P.hdr + qi * P.hdr_words;      // keys appended to every list of the row
     for (int l = sub; l < P.n_lists; l += SPLIT) {
         const int lcap = P.lcap[l];                    // multiple of 4
@@ -417,9 +420,11 @@ __global__ void k_merge_hits(gm_pg_blocks P, const uint32_t* __restrict__ lists,
             overflow = 1;
             c = lcap;
         }
-        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(row + P.loff[l]);
+        // (the first four keys of all lists share the row's first lines: a row of short lists is a few lines, not one per list)
+        const uint4* __restrict__ src_a = reinterpret_cast<const uint4*>(row + 4 * l);
+        const uint4* __restrict__ src_b = reinterpret_cast<const uint4*>(row + P.loff[l]);
         for (int base = 0; base < c; base += 4) {      // an empty list costs no key read
-            const uint4 w = src[base >> 2];
+            const uint4 w = base == 0 ? src_a[0] : src_b[(base >> 2) - 1];
             const uint32_t kk[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j)
