@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void k_lp_onehot(const uint2* __restrict__ pla
 struct gm_levpart {
     // layout
     int r = -1;                                   // radius the copies were built for (-1: none)
-    int n_blocks = 0, sh = 0;
+    int n_blocks = 0;
     int bstart[GM_LP_MAXBLK]{}, blen[GM_LP_MAXBLK]{};
     int n_copies = 0;
     int copy_block[GM_LP_MAXCOPY]{}, copy_shift[GM_LP_MAXCOPY]{};
@@ -356,7 +356,6 @@ int gm_lp_prepare(gm_index* idx, int r, hipStream_t st) {
     const int n_copies = gm_lp_layout(L, r, p_match, lp->bstart, lp->blen, lp->copy_block, lp->copy_shift, lp->first_copy, &frac);
     if (n_copies < 1) return gm_fail(GM_ERR_ARG, "K2P: no layout for this radius / guide length");
     lp->n_blocks = r + 1;
-    lp->sh = r / 2;
     {
         // Launch order: the chunk table is laid out block by block, and a chunk's work is (copies of its block) x (bucket
         // size): blocks with the longest chunks first, so that the launch does not end on a few workgroups that each still

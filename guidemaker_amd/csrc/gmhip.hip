@@ -504,8 +504,9 @@ int run_leven_lookup(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* d
     if (want > n_tiles) want = n_tiles;
     const int tiles_per_seg = (int)((n_tiles + want - 1) / want);
     const int n_seg = (int)((n_tiles + tiles_per_seg - 1) / tiles_per_seg);
-    // own scratch: the Hamming seeder enqueued above may still be using idx->d_keys
-    if ((rc = ensure_u32(&idx->d_keys2, &idx->keys2_cap, (int64_t)n_seg * n_q * kcap))) return rc;
+    // own scratch: the Hamming seeder enqueued above may still be using idx->d_keys (the plain first pass only: after K2P the
+    // scratch is sized for the rows it leaves, further down)
+    if (!part_used && (rc = ensure_u32(&idx->d_keys2, &idx->keys2_cap, (int64_t)n_seg * n_q * kcap))) return rc;
     // Narrow-band first pass (K2B, k-NN, pools large enough for the partitioned Hamming seeder).  The Hamming seeds put
     // most bounds one above what the next narrower band serves (S2, L = 23: 85 % of the candidates at "lev < 9", band 4),
     // while the k-th Levenshtein neighbour itself is closer (7 for 97 % of them).  So when most seeds are that close, ALL
@@ -526,23 +527,21 @@ int run_leven_lookup(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* d
         hipLaunchKernelGGL(k_lev_seed_stats, dim3((unsigned)((n_q + 255) / 256)), dim3(256), 0, st, dists, counts, n_q, k, idx->L,
                            cap_thr, thr_all, cnt);
         HIP_TRY(hipGetLastError());
-        if (two_pass) {
-            opt.cap_cnt = cnt;
-            opt.cap_thr = cap_thr;
-        }
+        opt.cap_cnt = cnt;
+        opt.cap_thr = cap_thr;
     }
-    if (!part_used) {
-    rc = timing_begin(idx, st);
-    if (rc) return rc;
-    idx->last_kernel = algo == 1 ? (nearest ? "k_leven_knn_bs(nearest)" : "k_leven_knn_bs")
-                                 : (nearest ? "k_leven_knn_lk(nearest)" : "k_leven_knn_lk");
-    rc = nearest ? launch_lv_by_len(idx, algo, kcap, n_q, 1, n_seg, tiles_per_seg, d1, nullptr, 1, idx->d_keys2, st)
-                 : launch_lv_by_len(idx, algo, kcap, n_q, k, n_seg, tiles_per_seg, dists, counts, k, idx->d_keys2, st, &opt);
-    if (rc) return rc;
-    rc = timing_end(idx, st, n_q * idx->n_db);
-    if (rc) return rc;
-    rc = nearest ? launch_merge(kcap, idx->d_keys2, n_seg, n_q, 1, nullptr, d1, nullptr, true, st)
-                 : launch_merge(kcap, idx->d_keys2, n_seg, n_q, k, ids, dists, counts, false, st);
+    if (!part_used) {      // the plain first pass over all candidates
+        rc = timing_begin(idx, st);
+        if (rc) return rc;
+        idx->last_kernel = algo == 1 ? (nearest ? "k_leven_knn_bs(nearest)" : "k_leven_knn_bs")
+                                     : (nearest ? "k_leven_knn_lk(nearest)" : "k_leven_knn_lk");
+        rc = nearest ? launch_lv_by_len(idx, algo, kcap, n_q, 1, n_seg, tiles_per_seg, d1, nullptr, 1, idx->d_keys2, st)
+                     : launch_lv_by_len(idx, algo, kcap, n_q, k, n_seg, tiles_per_seg, dists, counts, k, idx->d_keys2, st, &opt);
+        if (rc) return rc;
+        rc = timing_end(idx, st, n_q * idx->n_db);
+        if (rc) return rc;
+        rc = nearest ? launch_merge(kcap, idx->d_keys2, n_seg, n_q, 1, nullptr, d1, nullptr, true, st)
+                     : launch_merge(kcap, idx->d_keys2, n_seg, n_q, k, ids, dists, counts, false, st);
     }
     if (rc || !two_pass) return rc;
     // second pass: the candidates whose list did not fill (none when the first pass ran under the seeds themselves)
