@@ -304,6 +304,42 @@ def test_get_control_seqs(oracle):
     assert (data[0], data[1]) == otp.control_stats(sort_dist)
 
 
+def test_get_control_seqs_levenshtein(oracle, tmp_path):
+    """reference core.py:586-617 on a Levenshtein index (dtype != "hamming", core.py:458-466): the controls are queried as
+    raw sequences (:601-602), their nearest EDIT distances are reported as integers (no halving, :615), and the column is
+    still called "Hamming distance" (:624).  Same RNG stream through the oracle's restatement."""
+    import yaml
+    df = core.PamTarget("NGG", "5prime", "leven").find_targets(carsonella(), 20)
+    tl = core.TargetProcessor(targets=df, lsr=10, editdist=2, knum=5)
+    tl.check_restriction_enzymes(['NRAGCA'])
+    tl.find_unique_near_pam()
+    tl.create_index(configpath=CONFIG)
+    with open(CONFIG) as fh:
+        cfg = yaml.safe_load(fh)
+    cfg["CONTROL"]["MINIMUM_HMDIST"] = 7      # (edit distances to a 3 814-target pool: the twenty best of 200 draws reach 6, of 2 000 draws 7)
+    cfg_path = tmp_path / "cfg.yaml"
+    cfg_path.write_text(yaml.safe_dump(cfg))
+    np.random.seed(11)
+    mn, med, table = tl.get_control_seqs(carsonella(), length=20, n=20, num_threads=2, configpath=str(cfg_path))
+    assert table.shape == (20, 3) and list(table.columns) == ["name", "Sequences", "Hamming distance"]
+    assert all(isinstance(d, (int, np.integer)) for d in table["Hamming distance"].tolist())      # integers, not x / 2 floats
+    otp = oracle.OracleTargetProcessor(df["target"].tolist(), "leven", 2, 5)
+    otp.create_index()
+    np.random.seed(11)
+    gc = tl.gc_percent / 100
+    minimum, sm = 0, 0
+    while minimum < 7:
+        mult = [10, 100, 1000, 10000][sm]
+        seqs = core.TargetProcessor._draw_control_seqs(20 * mult, 20, gc)
+        sort_seq, sort_dist, minimum = otp.control_select(seqs, 20)
+        sm += 1
+    assert sm <= 2      # (keeps the oracle's share of this test to a few seconds)
+    assert table["Sequences"].tolist() == sort_seq
+    assert table["Hamming distance"].tolist() == sort_dist
+    assert (mn, med) == otp.control_stats(sort_dist)
+    assert tl.ncontrolsearched == 20 * [10, 100, 1000, 10000][sm - 1]
+
+
 # ------------------------------------------------------------------ CFD
 def test_cfd_golden(cfd_table):
     cases = load_json("cfd_kat.json")["cases"]
