@@ -75,9 +75,12 @@ def main():
         db = pool(rng, n, L, skew, planted)
         q = np.concatenate([db[: int(rng.integers(1000, min(len(db), a.max_q)))], pool(rng, 3000, L, skew, 0.0)])
         if rng.random() < a.leven:      # Levenshtein: two-pass scan (narrow band first) against the single pass
+            if rng.random() < 0.3:      # (guide lengths up to the maximum; the Hamming cases stay within the layouts' range)
+                L = int(rng.integers(14, 28))
+                db = pool(rng, n, L, skew, planted)
             db = db[: int(rng.integers(33_000, min(len(db), 90_000)))]
             q = np.concatenate([db[: int(rng.integers(4100, min(len(db), 30_000)))], pool(rng, 500, L, skew, 0.0)])
-            k = int(rng.choice([2, 3, 5, 10]))
+            k = int(rng.choice([2, 3, 5, 10, 13, 20]))
             idx = _lib.Index(db, L, _lib.METRIC_LEVEN)
             try:
                 lpr = int(rng.choice([0, 0, 2, 3, 4, 5]))      # K2P (the Levenshtein partition) with a forced radius
