@@ -147,7 +147,7 @@ struct gm_levpart {
     uint32_t* table[GM_LP_MAXCOPY]{};
     uint32_t* ord[GM_LP_MAXCOPY]{};
     int2* bdesc[GM_LP_MAXCOPY]{};              // bucket v of copy c -> (first tile, 64-target groups that hold targets)
-    std::vector<int2> bdesc_host[GM_LP_MAXCOPY];      // (the same on the host: the chunk table is built there)
+    std::vector<int2> bdesc_host[GM_LP_MAXCOPY];      // (the same on the host: the per-entry group sums are formed there)
     // query side (grow-only)
     uint32_t* cperm[GM_LP_MAXBLK]{};
     int64_t cperm_cap[GM_LP_MAXBLK]{};
