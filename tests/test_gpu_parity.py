@@ -943,6 +943,38 @@ def test_leven_partition_is_exact(oracle, n, L, k, radius, planted):
         idx.close()
 
 
+def test_leven_partition_handle_reuse():
+    """One Levenshtein handle, candidate sets of different sizes and k in turn (K2P's plan is cached per (n_q, k), its pool
+    copies per radius, its second level has a state of its own): every answer equals the plain K2B scan of a fresh handle
+    setting, whatever ran before on the handle."""
+    L = 23
+    rng = np.random.default_rng(77)
+    db = _random_packed(120_000, L, seed=4242, planted=0.04)
+    sets = [(db[:30_000], 5), (np.concatenate([db[40_000:49_000], _random_packed(500, L, seed=5)]), 10), (db[:30_000], 5),
+            (db[10_000:70_000], 3), (db[:8_200], 20)]
+    idx = _lib.Index(db, L, _lib.METRIC_LEVEN)
+    ref = _lib.Index(db, L, _lib.METRIC_LEVEN)
+    ref.set_param("lp_radius", -1)
+    try:
+        used = 0
+        for step, (q, k) in enumerate(sets):
+            if step == 3:
+                idx.set_param("lp_radius", 4)      # forced radii from here on (copies rebuilt for another radius)
+                idx.set_param("lp_radius2", 6)
+            got = idx.knn(q, k)
+            used += idx.last_kernel()[0] == "k_leven_part_bs"
+            want = ref.knn(q, k)
+            assert ref.last_kernel()[0] == "k_leven_knn_bs"
+            assert all((a == b).all() for a, b in zip(got, want)), (step, k)
+        assert used >= 3      # (the planner's own choice on the 120 k pool, then the forced radii)
+        idx.set_param("lp_radius", -1)
+        got = idx.knn(sets[0][0], 5)
+        assert idx.last_kernel()[0] == "k_leven_knn_bs" and all((a == b).all() for a, b in zip(got, ref.knn(sets[0][0], 5)))
+    finally:
+        idx.close()
+        ref.close()
+
+
 @pytest.mark.parametrize("n,k,cut", [(500_000, 20, 0), (500_000, 20, 25), (500_000, 20, 4), (300_000, 5, 30), (300_000, 2, 10)])
 def test_id_cutoff_is_exact(oracle, n, k, cut):
     """Hits at the layout's radius only from targets with ids below a cut-off ("pg_cut": 0 = the library's choice, else
