@@ -148,6 +148,13 @@ GM_FOR_EACH_LEN(GM_DECL_LK)
                             uint32_t* lists, hipStream_t st);
 GM_FOR_EACH_LEN(GM_DECL_PG)
 #undef GM_DECL_PG
+// ... and of the LDS-list scan (k_hamming_scan_pg3): keys = raw lists [n_lists][n_q][kcap]
+#define GM_DECL_PG3(LEN)                                                                                      \
+    int gm_launch_pg3_L##LEN(gm_index* idx, const gm_pg_blocks* blocks, const gm_pg_chunk* chunks,             \
+                             const int* c_begin, const int* c_end, int64_t grid, int64_t n_q, int k, int kcap,  \
+                             int thr0, uint32_t* keys, hipStream_t st);
+GM_FOR_EACH_LEN(GM_DECL_PG3)
+#undef GM_DECL_PG3
 
 // K1P host side (gm_pigeon.hip).  gm_pg_plan: number of blocks B (0 = the plain scan is the better choice);
 // gm_pg_prepare: block-sorted pool copies for B; gm_pg_candidates: group the candidates in idx->d_q;

@@ -70,6 +70,20 @@ int launch_pg_cfg(gm_index* idx, const gm_pg_blocks* blocks, const gm_pg_chunk* 
     return GM_OK;
 }
 
+template <int L>
+int launch_pg3_cfg(gm_index* idx, const gm_pg_blocks* blocks, const gm_pg_chunk* chunks, const int* c_begin,
+                   const int* c_end, int64_t grid, int64_t n_q, int k, int kcap, int thr0, uint32_t* keys, hipStream_t st) {
+    const size_t lds = gm::pg3_lds_bytes(L, k);
+    if (blocks->cut_id != 0xffffffffu)
+        hipLaunchKernelGGL((gm::k_hamming_scan_pg3<L, true>), dim3((unsigned)grid), dim3(gm::WAVE), lds, st, *blocks, chunks,
+                           c_begin, c_end, idx->d_q, n_q, k, kcap, thr0, keys);
+    else
+        hipLaunchKernelGGL((gm::k_hamming_scan_pg3<L, false>), dim3((unsigned)grid), dim3(gm::WAVE), lds, st, *blocks, chunks,
+                           c_begin, c_end, idx->d_q, n_q, k, kcap, thr0, keys);
+    HIP_TRY(hipGetLastError());
+    return GM_OK;
+}
+
 }  // namespace
 
 #define GM_CAT2(a, b) a##b
@@ -83,4 +97,10 @@ int GM_CAT(gm_launch_pg_L, GM_LEN)(gm_index* idx, const gm_pg_blocks* blocks, co
                                    const int* c_begin, const int* c_end, int64_t grid, int64_t n_q, int k, int thr0,
                                    uint32_t* lists, hipStream_t st) {
     return launch_pg_cfg<GM_LEN>(idx, blocks, chunks, c_begin, c_end, grid, n_q, k, thr0, lists, st);
+}
+
+int GM_CAT(gm_launch_pg3_L, GM_LEN)(gm_index* idx, const gm_pg_blocks* blocks, const gm_pg_chunk* chunks,
+                                    const int* c_begin, const int* c_end, int64_t grid, int64_t n_q, int k, int kcap,
+                                    int thr0, uint32_t* keys, hipStream_t st) {
+    return launch_pg3_cfg<GM_LEN>(idx, blocks, chunks, c_begin, c_end, grid, n_q, k, kcap, thr0, keys, st);
 }

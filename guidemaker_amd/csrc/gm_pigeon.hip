@@ -417,6 +417,8 @@ struct gm_pigeon {
     int64_t bgrid[GM_PG_MAXB]{};       // upper bound of block b's chunk count
     int64_t last_bpairs[GM_PG_MAXB]{}; // pairs block b's part of the last launch evaluated
     int tune_sub = 2;                  // workgroups per expansion chunk (gm_set_param "pg_sub")
+    int tune_per = 0;                  // target buckets per workgroup, 0 = 16 / pg_sub (gm_set_param "pg_per")
+    int tune_hit = 1;                  // 1 = hit lists in LDS (k_hamming_scan_pg3), 0 = hit buffer in HBM (gm_set_param "pg_hit")
     int tune_debug = 0;                // timing experiments (gm_set_param "pg_debug")
     int tune_layout = 0;               // experiments: forced layout, decimal digit pairs (len, radius) per block
     int tune_gap = 0;                  // table gaps: 0 = choose, 1 = common gap (one launch), 2 = per-block gaps
@@ -468,6 +470,8 @@ struct gm_pigeon {
     int64_t lists_cap = 0;
     uint32_t* hdr = nullptr;      // one header word per (candidate, list) (gm_pg_blocks::hdr)
     int64_t hdr_cap = 0;
+    uint32_t* keys3 = nullptr;    // LDS-list scan: raw lists [n_lists][n_q][kcap]
+    int64_t keys3_cap = 0;
     int64_t cap_nq = -1;          // candidate count / layout the list capacities were sized for
     int cap_sub_for = -1;
     uint64_t cap_layout_for = 0;
@@ -931,6 +935,8 @@ void gm_pg_inherit(gm_index* idx, const gm_pigeon* parent) {
     pg->p_match = parent->p_match;
     for (int b = 0; b < 4; ++b) pg->base_freq[b] = parent->base_freq[b];
     pg->tune_sub = parent->tune_sub;
+    pg->tune_per = parent->tune_per;
+    pg->tune_hit = parent->tune_hit;
     pg->tune_run = parent->tune_run;
     pg->tune_msplit = parent->tune_msplit;
     pg->tune_prefix = parent->tune_prefix;
@@ -963,6 +969,17 @@ int gm_pg_set_param(gm_index* idx, const char* name, int value) {
     if (std::strcmp(name, "pg_sub") == 0) {
         if (value < 1 || value > 19) return gm_fail(GM_ERR_ARG, "pg_sub: 1..19");
         idx->pg->tune_sub = value;
+        return GM_OK;
+    }
+    if (std::strcmp(name, "pg_per") == 0) {
+        if (value < 0 || value > 4096) return gm_fail(GM_ERR_ARG, "pg_per: 0 (from pg_sub), 1..4096");
+        idx->pg->tune_per = value;
+        return GM_OK;
+    }
+    if (std::strcmp(name, "pg_hit") == 0) {
+        if (value != 0 && value != 1) return gm_fail(GM_ERR_ARG, "pg_hit: 0 (hit buffer), 1 (lists in LDS)");
+        idx->pg->tune_hit = value;
+        idx->pg->cap_nq = -1;
         return GM_OK;
     }
     if (std::strcmp(name, "pg_layout") == 0) {
@@ -1014,7 +1031,7 @@ void gm_pg_free(gm_index* idx) {
     for (int b = 0; b < GM_PG_MAXB; ++b)
         if (pg->cperm[b]) (void)hipFree(pg->cperm[b]);
     void* bufs[] = {pg->k0, pg->k1, pg->r0, pg->r1, pg->sort_tmp, pg->nch, pg->cbase, pg->hist, pg->cursor, pg->chunks, pg->ctr,
-                    pg->lists, pg->hdr, pg->raw_off, pg->inc, pg->inc_b, pg->cflag, pg->shist, pg->q2, pg->ids2, pg->dists2, pg->counts2};
+                    pg->lists, pg->hdr, pg->keys3, pg->raw_off, pg->inc, pg->inc_b, pg->cflag, pg->shist, pg->q2, pg->ids2, pg->dists2, pg->counts2};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     if (pg->box) (void)hipHostFree(pg->box);
@@ -1189,7 +1206,7 @@ int gm_pg_prepare(gm_index* idx, const gm_pg_layout* lay, hipStream_t st) {
 // per workgroup, at most 6 workgroups per chunk -- every workgroup means one more hit list per candidate), and the
 // hit-list numbering
 static void pg_geometry(gm_pigeon* pg) {
-    const int per_target = (16 + pg->tune_sub - 1) / pg->tune_sub;
+    const int per_target = pg->tune_per > 0 ? pg->tune_per : (16 + pg->tune_sub - 1) / pg->tune_sub;
     int cap_sub = 6;
     for (;;) {
         int lists = 0;
@@ -1386,15 +1403,27 @@ int gm_pg_scan(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
             HIP_TRY(hipGetLastError());
         }
     }
-    if (pg->cap_nq != n_q || pg->cap_layout_for != lkey || pg->cap_sub_for != pg->tune_sub) {
-        pg_list_capacity(idx, pg, n_q);
-        pg->cap_nq = n_q;
-        pg->cap_layout_for = lkey;
-        pg->cap_sub_for = pg->tune_sub;
+    const int sub_key = pg->tune_sub * 8192 + pg->tune_per;
+    const int kcap3 = k <= 1 ? 1 : (k <= 5 ? 5 : (k <= 10 ? 10 : 20));
+    if (pg->tune_hit) {
+        pg_geometry(pg);
+        if ((rc = ensure(&pg->keys3, &pg->keys3_cap, (int64_t)pg->blocks.n_lists * n_q * kcap3, "K1P raw lists"))) return rc;
+#ifdef GM_PG_STATS      // instrumented build (tools only): eight 64-bit event counters per launch, printed to stderr
+        if ((rc = ensure(&pg->hdr, &pg->hdr_cap, 64, "K1P stats"))) return rc;
+        pg->blocks.hdr = pg->hdr;
+        HIP_TRY(hipMemsetAsync(pg->hdr, 0, 64 * sizeof(uint32_t), st));
+#endif
+    } else {
+        if (pg->cap_nq != n_q || pg->cap_layout_for != lkey || pg->cap_sub_for != sub_key) {
+            pg_list_capacity(idx, pg, n_q);
+            pg->cap_nq = n_q;
+            pg->cap_layout_for = lkey;
+            pg->cap_sub_for = sub_key;
+        }
+        if ((rc = ensure(&pg->lists, &pg->lists_cap, gm_pg_list_words(pg) * n_q, "K1P hit lists"))) return rc;
+        if ((rc = ensure(&pg->hdr, &pg->hdr_cap, (int64_t)pg->blocks.hdr_words * n_q, "K1P list headers"))) return rc;
+        pg->blocks.hdr = pg->hdr;
     }
-    if ((rc = ensure(&pg->lists, &pg->lists_cap, gm_pg_list_words(pg) * n_q, "K1P hit lists"))) return rc;
-    if ((rc = ensure(&pg->hdr, &pg->hdr_cap, (int64_t)pg->blocks.hdr_words * n_q, "K1P list headers"))) return rc;
-    pg->blocks.hdr = pg->hdr;
     gm_pg_blocks& blocks = pg->blocks;
     for (int b = 0; b < pg->B; ++b) {
         blocks.blen[b] = pg->blen[b];
@@ -1424,8 +1453,11 @@ int gm_pg_scan(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
         const int* c_end = &pg->ctr->cstart[b1];
         int rc2 = GM_OK;
         switch (pg->Lp[b0]) {            // the kernel instantiated for the positions actually evaluated
-#define GM_CASE(LEN) \
-    case LEN: rc2 = gm_launch_pg_L##LEN(idx, &blocks, pg->chunks, c_begin, c_end, grid, n_q, k, thr0, pg->lists, st); break;
+#define GM_CASE(LEN)                                                                                                     \
+    case LEN:                                                                                                            \
+        rc2 = pg->tune_hit ? gm_launch_pg3_L##LEN(idx, &blocks, pg->chunks, c_begin, c_end, grid, n_q, k, kcap3, thr0, pg->keys3, st) \
+                           : gm_launch_pg_L##LEN(idx, &blocks, pg->chunks, c_begin, c_end, grid, n_q, k, thr0, pg->lists, st);       \
+        break;
             GM_FOR_EACH_LEN(GM_CASE)
 #undef GM_CASE
             default: rc2 = gm_fail(GM_ERR_ARG, "pigeonhole kernel: guidelen out of range");
@@ -1433,6 +1465,15 @@ int gm_pg_scan(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
         if (rc2) return rc2;
         b0 = b1;
     }
+#ifdef GM_PG_STATS
+    if (pg->tune_hit) {
+        unsigned long long h[8];
+        HIP_TRY(hipMemcpyAsync(h, pg->hdr, sizeof(h), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        fprintf(stderr, "[gm stats] n_q %lld: workgroups %llu, rounds %llu (%llu at the end), hits dealt %llu, keys offered %llu, chain steps %llu\n",
+                (long long)n_q, h[5], h[0], h[4], h[1], h[2], h[3]);
+    }
+#endif
     return GM_OK;
 }
 
@@ -1447,7 +1488,17 @@ int gm_pg_merge(gm_index* idx, int kcap, int64_t n_q, int k, int32_t* ids, int32
     int split = kcap >= 20 ? 2 : 4;      // (S4, k = 20: 15.3 / 15.0 / 15.8 ms per query with 1 / 2 / 4; S1, k = 10: 1.23 / 1.15 / 1.13)
     if (pg->tune_msplit > 0) split = pg->tune_msplit;
     const dim3 grid = grid_for(n_q * split), block(256);
-#define GM_MERGE(KC, SP) hipLaunchKernelGGL((gm::k_merge_hits<KC, SP>), grid, block, 0, st, pg->blocks, pg->lists, n_q, k, ids, dists, counts, nr, pg->inc, n_inc, &pg->ctr->n_over, pg->ctr->chist, pg->cut_id != 0xffffffffu ? pg->cflag : nullptr)
+#define GM_MERGE(KC, SP)                                                                                                          \
+    do {                                                                                                                          \
+        if (pg->tune_hit)                                                                                                         \
+            hipLaunchKernelGGL((gm::k_merge_pg3<KC, SP>), grid, block, 0, st, pg->keys3, pg->blocks.n_lists, n_q, k, ids, dists,   \
+                               counts, nr, pg->inc, n_inc, &pg->ctr->n_over, pg->ctr->chist,                                      \
+                               pg->cut_id != 0xffffffffu ? pg->cflag : nullptr);                                                  \
+        else                                                                                                                      \
+            hipLaunchKernelGGL((gm::k_merge_hits<KC, SP>), grid, block, 0, st, pg->blocks, pg->lists, n_q, k, ids, dists, counts,  \
+                               nr, pg->inc, n_inc, &pg->ctr->n_over, pg->ctr->chist,                                              \
+                               pg->cut_id != 0xffffffffu ? pg->cflag : nullptr);                                                  \
+    } while (0)
 #define GM_MERGE_KC(KC) do { if (split == 1) GM_MERGE(KC, 1); else if (split == 2) GM_MERGE(KC, 2); else GM_MERGE(KC, 4); } while (0)
     switch (kcap) {
         case 1: GM_MERGE_KC(1); break;

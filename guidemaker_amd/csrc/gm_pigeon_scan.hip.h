@@ -219,9 +219,9 @@ __device__ __forceinline__ int pg_bound(const PgQueue& Q, int lane, int k, int t
 }
 
 // evaluate one 64-target group from LDS (word offset WOFF) and queue the lanes that have hits
-template <int L, int WOFF>
+template <int L, int WOFF, class QT>
 __device__ __forceinline__ void pg_group(const uint32_t* const (&ptr)[L], const uint32_t (&Tb)[5], int g, int lane,
-                                         PgQueue& Q) {
+                                         QT& Q) {
     LkGroupRegs<L> r;
     lk_read_group<L, WOFF>(r, ptr);
     uint32_t c0[5], c1[5];
@@ -368,6 +368,280 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
     if (lane < ch.cn) P.hdr[(int64_t)((uint32_t)Q.qrow[lane] & 0x7fffffffu) * P.hdr_words + ch.lst] = (uint32_t)Q.cnt[lane];
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// K1P with the hit lists in LDS (k_hamming_scan_pg3; gm_set_param "pg_hit" = 1).
+//
+// What the counters of the kernel above say on a real genome (profiles/r03: PAO1, ~72 targets within r per candidate):
+// the hit path is 57 % of the launch, and it is not instruction issue -- it is the vector-memory pipeline: every hit
+// is a scattered 4-byte store into a multi-GB hit buffer (one line per lane), every store stays in the wave's in-order
+// vmcnt queue in front of the next table unit, and the bound a workgroup works under (four counted levels) is loose.
+// Here a workgroup keeps, per candidate, its k BEST hits so far in LDS ([k][64] keys, slot-major: lanes that serve
+// different candidates touch different banks):
+//   * a hit is offered to its candidate's list by REPLACING THE LIST'S MAXIMUM: the lane reads the candidate's slots
+//     (empty slots hold 0xffffffff, slots beyond k hold 0), and if its key is below the maximum it swaps it in with one
+//     ds_cmpswap on that slot; a lane that loses the slot to another lane serving the same candidate reads again.  Only
+//     ever the maximum is replaced, by something smaller, and a key gives up only against a maximum it cannot beat: the
+//     slots end as the k smallest keys (unordered).  Two LDS round trips per attempt, whatever k (a sorted insert by a
+//     chain of k ds_min_rtn -- the first version -- measured 0.1 ms of S1's 0.72 ms scan).  No counter, no capacity, no
+//     overflow: a repeat family costs LDS operations, not a re-scan of the row;
+//   * the comparator bound of a candidate is the distance of its list's maximum (+ 1: ties go to the smaller id, decided
+//     on the key) -- exact at every level, not four counted ones;
+//   * no global store inside the scan loop: at the end every candidate's k keys go out as one 4 k-byte run into
+//     keys[list][row][KCAP] (the raw list format of gm_lookup.hip.h: key + 1, 0 = unused slot, 0xffffffff = empty),
+//     which k_merge_pg3 folds; the hit buffer, its headers and the capacity model of the kernel above are not needed;
+//   * the flush is DEALT: the queued (candidate, group, 64-bit hit word) entries are expanded through a prefix sum of
+//     their hit counts into a 64-slot window, every lane resolves ONE hit (a round is 64 hits whenever 64 entries are
+//     queued; an entry that is only partly taken stays at the ring's head with the rest of its bits) -- one record gather
+//     per 64 hits, all lanes busy.
+// A pair that several blocks find is offered to every one of their lists (each workgroup's bound then counts every hit
+// it sees) and taken once by the merge (insert_unique on equal keys).
+constexpr uint32_t PG3_EMPTY = 0xffffffffu;
+__host__ __device__ constexpr int pg3_slots(int k) { return (k + 4) / 5 * 5; }      // list slots per candidate (read five at a time)
+__host__ __device__ constexpr size_t pg3_lds_bytes(int L, int k) {
+    return sizeof(uint32_t) * (size_t)(2 * pg_pair_words(L) + PG_QCAP * 3 + WAVE / 2 + WAVE * pg3_slots(k));
+}
+
+// inclusive prefix sum over the 64 lanes (all lanes active): row_shr 1 / 2 / 4 / 8 inside rows of 16, then the gfx9 row
+// broadcasts 15 -> next row (rows 1, 3) and 31 -> upper half
+__device__ __forceinline__ int pg3_scan64(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
+struct Pg3Queue {
+    uint32_t* tag;      // [PG_QCAP]  group << 6 | candidate lane
+    uint2* mask;        // [PG_QCAP]  hit bits of the group's 64 targets not resolved yet
+    uint16_t* win;      // [WAVE]     the round's hits: entry (relative to the head) << 6 | bit
+    uint32_t* lists;    // [slots][WAVE]  per candidate the k smallest keys + 1 so far (unordered); PG3_EMPTY = free slot, 0 = not a slot
+    int head, tail;     // wave-uniform ring positions (monotonic)
+};
+
+// one round of the flush: the first <= 64 queued hits are resolved, one per lane, and offered to their candidates' lists
+#ifdef GM_PG_STATS
+#define GM_PG_STAT(i, v) do { if (lane == 0) st_[i] += (unsigned long long)(v); } while (0)
+#else
+#define GM_PG_STAT(i, v) do { } while (0)
+#endif
+// maximum of candidate cl's list slots (the first one among equals: a free slot while the list is not full)
+__device__ __forceinline__ void pg3_row_max(const uint32_t* lists, int slots, int cl, uint32_t& M, int& m) {
+    M = 0u;
+    m = 0;
+    for (int s0 = 0; s0 < slots; s0 += 5) {
+        uint32_t v[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) v[i] = lists[(s0 + i) * WAVE + cl];
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+            if (v[i] > M) {
+                M = v[i];
+                m = s0 + i;
+            }
+    }
+}
+
+// qv = this lane's own candidate planes, bit 31 of .x = the candidate takes the id cut-off (fetched from the owner lane
+// by ds_bpermute: no LDS copy of the planes)
+__device__ __forceinline__ void pg3_round(Pg3Queue& Q, int lane, const uint4* __restrict__ recs, int slots, int thr0, uint32_t cut_id,
+                                          uint2 qv
+#ifdef GM_PG_STATS
+                                          , unsigned long long (&st_)[8]
+#endif
+                                          ) {
+    const int avail = Q.tail - Q.head;
+    const int take = avail < WAVE ? avail : WAVE;
+    const int s = (Q.head + lane) & (PG_QCAP - 1);
+    uint2 m = make_uint2(0u, 0u);
+    if (lane < take) m = Q.mask[s];
+    const int hc = __popc(m.x) + __popc(m.y);
+    const int incl = pg3_scan64(hc);
+    const int excl = incl - hc;
+    const int total = __builtin_amdgcn_readlane(incl, WAVE - 1);
+    const int c = excl < WAVE ? (WAVE - excl < hc ? WAVE - excl : hc) : 0;      // this entry's share of the round's 64 slots
+    uint64_t hm = ((uint64_t)m.y << 32) | (uint64_t)m.x;
+    for (int i = 0; i < c; ++i) {
+        const int j = __builtin_ctzll(hm);
+        hm &= hm - 1ull;
+        Q.win[excl + i] = (uint16_t)((lane << 6) | j);
+    }
+    if (c > 0 && c < hc) Q.mask[s] = make_uint2((uint32_t)hm, (uint32_t)(hm >> 32));      // partly taken: stays at the head
+    // (the counts are positive, so the entries taken whole are a prefix of the ring)
+    const int whole = __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < take && incl <= WAVE));
+    const int head0 = Q.head;
+    Q.head += whole;
+    __syncthreads();      // single-wave workgroup: the window is written before it is read
+    const int nh = total < WAVE ? total : WAVE;
+    uint32_t x = PG3_EMPTY, w = 0u, tg = 0u;
+    if (lane < nh) {
+        w = Q.win[lane];
+        tg = Q.tag[(head0 + (int)(w >> 6)) & (PG_QCAP - 1)];
+    }
+    const int cl = (int)(tg & 63u);
+    // (every lane takes part in the two permutes; lanes without a hit read lane 0's planes and drop them)
+    const uint2 cq = make_uint2((uint32_t)__builtin_amdgcn_ds_bpermute(cl << 2, (int)qv.x),
+                                (uint32_t)__builtin_amdgcn_ds_bpermute(cl << 2, (int)qv.y));
+    if (lane < nh) {
+#if defined(GM_PG_TIMING) && (GM_PG_TIMING & 4)      // timing build only (results WRONG): no record gather
+        const uint4 t = make_uint4(w, tg, w * 977u & ID_MASK, 0u);
+#else
+        const uint4 t = recs[(int64_t)(tg >> 6) * LK_GROUP + (int64_t)(w & 63u)];
+#endif
+        const uint32_t mism = ((cq.x ^ t.x) | (cq.y ^ t.y)) & 0x7fffffffu;      // one bit per mismatching position
+        const int d = __popc(mism);
+        const uint32_t cut_c = (cq.x >> 31) != 0u ? cut_id : 0xffffffffu;      // id cut-off: at distance r only ids below it count
+        if (!(d == thr0 - 1 && t.z >= cut_c)) x = (((uint32_t)d << ID_BITS) | t.z) + 1u;
+    }
+#if defined(GM_PG_TIMING) && (GM_PG_TIMING & 1)      // timing build only (results WRONG): no list insertion
+    x = PG3_EMPTY;
+#endif
+    GM_PG_STAT(0, 1);
+    GM_PG_STAT(1, nh);
+    // replace-the-maximum insertion; a lane repeats only when another lane serving the same candidate took its slot
+    while (__builtin_amdgcn_ballot_w64(x != PG3_EMPTY) != 0ull) {
+        GM_PG_STAT(3, 1);
+        uint32_t M;
+        int m;
+        pg3_row_max(Q.lists, slots, cl, M, m);
+        if (x != PG3_EMPTY) {
+            if (x < M) {
+                if (atomicCAS(&Q.lists[m * WAVE + cl], M, x) == M) x = PG3_EMPTY;
+            } else {
+                x = PG3_EMPTY;      // cannot enter: k smaller keys are known
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// keys: [n_lists][n_q][kcap] raw lists (see above)
+template <int L, bool CUT>
+__global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg3(
+    gm_pg_blocks P, const gm_pg_chunk* __restrict__ chunks, const int* __restrict__ c_begin,
+    const int* __restrict__ c_end, const uint2* __restrict__ q, int64_t n_q, int k, int kcap, int thr0,
+    uint32_t* __restrict__ keys) {
+    extern __shared__ __align__(16) uint32_t smem[];
+    constexpr int GW = lk_group_words(L);
+    constexpr int PW = pg_pair_words(L);
+    const int first = *c_begin, n = *c_end - first;
+    const int wg = (int)blockIdx.x, xcd = wg & 7, slot = wg >> 3;
+    const int entry = (slot / P.run) * (8 * P.run) + xcd * P.run + (slot % P.run);
+    if (entry >= n) return;
+    const gm_pg_chunk ch = chunks[first + entry];
+    const uint32_t* __restrict__ table = P.table[ch.b];
+    const uint4* __restrict__ recs = P.recs[ch.b];
+    uint32_t* tiles = smem;                                     // [2][PW]
+    Pg3Queue Q;
+    Q.tag = smem + 2 * PW;
+    Q.mask = reinterpret_cast<uint2*>(Q.tag + PG_QCAP);
+    Q.win = reinterpret_cast<uint16_t*>(Q.mask + PG_QCAP);
+    Q.lists = reinterpret_cast<uint32_t*>(Q.win + WAVE);
+    Q.head = Q.tail = 0;
+    const int lane = threadIdx.x;
+    const bool valid = lane < ch.cn;
+    const int64_t qi = valid ? (int64_t)P.cperm[ch.b][ch.c0 + lane] : 0;
+    uint2 qv = valid ? q[qi] : make_uint2(0u, 0u);
+    const bool lane_cut = CUT && valid && P.cflag[qi] != 0;
+    const int slots = pg3_slots(k);
+    for (int s = 0; s < slots; ++s) Q.lists[s * WAVE + lane] = s < k ? PG3_EMPTY : 0u;
+
+    const int skip_start = P.skip[ch.b], skip_len = P.skiplen[ch.b];
+    const uint32_t* ptr[L];
+#pragma unroll
+    for (int p = 0; p < L; ++p) {
+        const int sp = p >= skip_start ? p + skip_len : p;
+        const uint32_t code = ((qv.x >> sp) & 1u) | (((qv.y >> sp) & 1u) << 1);
+        ptr[p] = tiles + p * 8 + (int)code * 2;
+    }
+#if defined(GM_PG_TIMING) && (GM_PG_TIMING & 2)      // timing build only (results WRONG): no hit is accepted
+    int thr = 0;
+#else
+    int thr = valid ? thr0 : 0;              // accept d < thr
+#endif
+    qv.x |= lane_cut ? 0x80000000u : 0u;      // (after the look-up addresses were formed from the planes)
+    uint32_t Tb[5];
+    PgIter it{ch.e_lo - 1, 0, 0, 0, 0, 0};
+    int gA = 0, ngA = 0, addA = 0, ucA = 2, gB = 0, ngB = 0, addB = 0, ucB = 2;
+    bool okA = pg_next<CUT>(P, ch, it, gA, ngA, addA, ucA), okB = false;
+    if (okA) pg_stage<L>(table, gA, tiles, lane);
+    const uint32_t cut_id = CUT ? P.cut_id : 0xffffffffu;
+    int cur = -1;      // (add << 1 | cut) the comparator words were formed for; -1 = stale
+#ifdef GM_PG_STATS
+    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define GM_PG_STARG , st_
+#else
+#define GM_PG_STARG
+#endif
+#define GM_PG_BOUND(ADD, CUTF)                                                              \
+    {                                                                                     \
+        const int want = ((ADD) << 1) | ((CUTF) ? 1 : 0);                                 \
+        if (want != cur) {                                                                \
+            cur = want;                                                                   \
+            const int t_ = (CUT && (CUTF) && lane_cut && thr > thr0 - 1) ? thr0 - 1 : thr; \
+            lk_set_bound(Tb, L, t_ - (ADD));                                              \
+        }                                                                                 \
+    }
+    // a round whenever 64 entries are queued (>= 64 hits: the round is dense); afterwards the bounds may have tightened
+#define GM_PG_AFTER_GROUP()                                                       \
+    if (Q.tail - Q.head >= WAVE) {                                                \
+        do pg3_round(Q, lane, recs, slots, thr0, cut_id, qv GM_PG_STARG);         \
+        while (Q.tail - Q.head >= WAVE);                                          \
+        uint32_t kth;                                                             \
+        int kth_at;                                                               \
+        pg3_row_max(Q.lists, slots, lane, kth, kth_at);                           \
+        const int nt = kth == PG3_EMPTY ? thr : (int)((kth - 1u) >> ID_BITS) + 1; \
+        if (nt < thr) thr = nt;                                                   \
+        cur = -1;                                                                 \
+    }
+    while (okA) {
+        okB = pg_next<CUT>(P, ch, it, gB, ngB, addB, ucB);
+        lk_stage_wait();                                        // unit A has landed in buffer 0
+        if (okB) pg_stage<L>(table, gB, tiles + PW, lane);
+        GM_PG_BOUND(addA, ucA < 1)
+        pg_group<L, 0>(ptr, Tb, gA, lane, Q);
+        GM_PG_AFTER_GROUP()
+        if (ngA > 1) {
+            GM_PG_BOUND(addA, ucA < 2)
+            pg_group<L, GW>(ptr, Tb, gA + 1, lane, Q);
+            GM_PG_AFTER_GROUP()
+        }
+        if (!okB) break;
+        okA = pg_next<CUT>(P, ch, it, gA, ngA, addA, ucA);
+        lk_stage_wait();                                        // unit B has landed in buffer 1
+        if (okA) pg_stage<L>(table, gA, tiles, lane);
+        GM_PG_BOUND(addB, ucB < 1)
+        pg_group<L, PW>(ptr, Tb, gB, lane, Q);
+        GM_PG_AFTER_GROUP()
+        if (ngB > 1) {
+            GM_PG_BOUND(addB, ucB < 2)
+            pg_group<L, PW + GW>(ptr, Tb, gB + 1, lane, Q);
+            GM_PG_AFTER_GROUP()
+        }
+    }
+#undef GM_PG_AFTER_GROUP
+#undef GM_PG_BOUND
+    while (Q.tail - Q.head > 0) {
+        GM_PG_STAT(4, 1);
+        pg3_round(Q, lane, recs, slots, thr0, cut_id, qv GM_PG_STARG);
+    }
+#ifdef GM_PG_STATS
+    if (lane == 0) {
+        st_[5] = 1;
+        for (int i = 0; i < 8; ++i) atomicAdd(reinterpret_cast<unsigned long long*>(P.hdr) + i, st_[i]);
+    }
+#endif
+    // every (list, candidate) pair has exactly one writer (the row number is fetched again: a 64-bit index kept in
+    // registers across the scan loop is two VGPRs the loop does not have)
+    if (lane < ch.cn) {
+        const int64_t row = (int64_t)P.cperm[ch.b][ch.c0 + lane];
+        uint32_t* __restrict__ out = keys + ((int64_t)ch.lst * n_q + row) * kcap;
+        for (int s = 0; s < kcap; ++s) out[s] = s < k ? Q.lists[s * WAVE + lane] : 0u;
+    }
+}
+
 // Appends `value` of the threads with take == true to out[] (order irrelevant): the workgroup's threads are ranked by
 // wave ballots + an LDS scan of the wave totals, ONE atomicAdd per workgroup on *counter hands out the range.  Every
 // thread of the workgroup calls it (it contains barriers); blockDim.x = a multiple of 64, at most 1024.
@@ -456,6 +730,69 @@ __global__ void k_merge_hits(gm_pg_blocks P, const uint32_t* __restrict__ lists,
     int32_t entry = 0;
     bool take = false;
     if (owner && overflow) {      // hits were lost: nothing about this row is known
+        list.init(k, nullptr, 0);
+        entry = (int32_t)((uint32_t)qi | PG_INC_OVERFLOW);
+        take = true;
+        atomicAdd(&s_over, 1);
+    } else if (owner && !full) {      // every target within r is in the list (there are fewer than k): kept for the re-scan
+        entry = (int32_t)qi;
+        take = true;
+        int c = 0;
+#pragma unroll
+        for (int s = 0; s < KCAP; ++s) c += (list.v[s] != 0u && list.v[s] != RegList<KCAP>::EMPTY) ? 1 : 0;
+        atomicAdd(&s_hist[c < 23 ? c : 23], 1);      // (the host sizes the prefix re-scan from this)
+    }
+    gm_block_append(take, entry, inc, inc_count);      // (contains the barrier that orders the LDS counters)
+    if (threadIdx.x < 24 && s_hist[threadIdx.x] != 0) atomicAdd(&chist[threadIdx.x], s_hist[threadIdx.x]);
+    if (threadIdx.x == 24 && s_over != 0) atomicAdd(over_count, s_over);
+    if (!owner) return;
+    list.store(k, qi, ids, dists, counts, nearest != 0);
+}
+
+// K1P merge for the LDS-list scan (k_hamming_scan_pg3): folds the n_lists raw lists keys[list][row][KCAP] of a row --
+// a pair that several blocks found sits in several of them with the same key: insert_unique -- into the top k.  SPLIT
+// adjacent lanes per row, as k_merge_hits; a row whose merged list is not full (or that took the id cut-off and is
+// short) is listed in `inc`.  There is no overflow: the lists are exact top-k lists of what their workgroups saw.
+template <int KCAP, int SPLIT>
+__global__ void k_merge_pg3(const uint32_t* __restrict__ keys, int n_lists, int64_t n_q, int k,
+                            int32_t* __restrict__ ids, int32_t* __restrict__ dists, int32_t* __restrict__ counts,
+                            int nearest, int32_t* __restrict__ inc, int* __restrict__ inc_count,
+                            int* __restrict__ over_count, int* __restrict__ chist, const uint8_t* __restrict__ cflag) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int sub = (int)(t % SPLIT);
+    const int64_t qi_raw = t / SPLIT;
+    const bool valid = qi_raw < n_q;
+    const int64_t qi = valid ? qi_raw : n_q - 1;      // (whole groups stay in the shuffles)
+    RegList<KCAP> list;
+    list.init(k, nullptr, 0);
+    for (int l = sub; l < n_lists; l += SPLIT) {
+        const uint32_t* __restrict__ in = keys + ((int64_t)l * n_q + qi) * KCAP;
+        uint32_t v[KCAP];
+#pragma unroll
+        for (int i = 0; i < KCAP; ++i) v[i] = in[i];
+#pragma unroll
+        for (int i = 0; i < KCAP; ++i)
+            if (v[i] != 0u && v[i] < list.v[KCAP - 1]) list.insert_unique(v[i] - 1u);
+    }
+#pragma unroll
+    for (int off = SPLIT / 2; off >= 1; off >>= 1) {
+#pragma unroll
+        for (int i = 0; i < KCAP; ++i) {
+            const uint32_t v = __shfl_down(list.v[i], off, SPLIT);
+            if (sub < off && v != 0u && v < list.v[KCAP - 1]) list.insert_unique(v - 1u);
+        }
+    }
+    __shared__ int s_hist[24], s_over;
+    if (threadIdx.x < 24) s_hist[threadIdx.x] = 0;
+    if (threadIdx.x == 24) s_over = 0;
+    __syncthreads();
+    const bool owner = sub == 0 && valid;
+    const bool full = list.v[KCAP - 1] != RegList<KCAP>::EMPTY;
+    // (a short row that took the id cut-off does not know all its neighbours at r: nothing about it is known)
+    const bool unknown = owner && !full && cflag != nullptr && cflag[qi] != 0;
+    int32_t entry = 0;
+    bool take = false;
+    if (unknown) {
         list.init(k, nullptr, 0);
         entry = (int32_t)((uint32_t)qi | PG_INC_OVERFLOW);
         take = true;
