@@ -134,6 +134,8 @@ def lib():
     L.gm_multi_create.restype = i32
     L.gm_multi_knn_query.argtypes = [vp, vp, i64, i32, vp, vp, vp]
     L.gm_multi_knn_query.restype = i32
+    L.gm_multi_nearest_dist.argtypes = [vp, vp, i64, vp]
+    L.gm_multi_nearest_dist.restype = i32
     L.gm_multi_devices.argtypes = [vp]
     L.gm_multi_devices.restype = i32
     L.gm_multi_has_comm.argtypes = [vp]
@@ -178,7 +180,7 @@ EXPORTS = [
     "gm_set_variant", "gm_timing_reserve", "gm_timing_read", "gm_pam_count", "gm_pam_emit", "gm_pam_free",
     "gm_pack_keys_dev", "gm_unpack_keys_dev", "gm_site_flags", "gm_seed_duplicated",
     "gm_last_kernel_evaluated", "gm_last_incomplete", "gm_pigeon_blocks", "gm_pigeon_plan", "gm_pigeon_plan_dist", "gm_pigeon_plan_sample", "gm_levpart_layout", "gm_levpart_info", "gm_pigeon_cascade_info", "gm_pigeon_block_info", "gm_set_param",
-    "gm_multi_create", "gm_multi_knn_query", "gm_multi_devices", "gm_multi_has_comm", "gm_multi_index", "gm_multi_free",
+    "gm_multi_create", "gm_multi_knn_query", "gm_multi_nearest_dist", "gm_multi_devices", "gm_multi_has_comm", "gm_multi_index", "gm_multi_free",
 ]
 
 
@@ -425,6 +427,20 @@ class MultiIndex:
         if nq:
             _check(lib().gm_multi_knn_query(self._h, _ptr(q), nq, k, _ptr(ids), _ptr(dists), _ptr(counts)))
         return ids, dists, counts
+
+    def set_param(self, name, value):
+        """gm_set_param on every device's handle (experiments, tests: e.g. a forced K1P layout)."""
+        for i in range(self.devices()):
+            _check(lib().gm_set_param(ctypes.c_void_p(lib().gm_multi_index(self._h, i)), name.encode(), int(value)))
+
+    def nearest(self, q_packed):
+        """Nearest-target distance of every candidate (get_control_seqs' query), sharded over the devices."""
+        q = np.ascontiguousarray(q_packed, dtype=np.uint64)
+        nq = int(q.shape[0])
+        d1 = np.full((nq,), -1, np.int32)
+        if nq:
+            _check(lib().gm_multi_nearest_dist(self._h, _ptr(q), nq, _ptr(d1)))
+        return d1
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

@@ -576,6 +576,21 @@ class TargetProcessor:
         idx = cdf.searchsorted(u, side='right')               # index into ["G", "C", "A", "T"]
         return np.array([2, 1, 0, 3], dtype=np.uint8)[idx]
 
+    def _control_match_probability(self, gc: float) -> float:
+        """P(a random control carries the same base as a pool target at a position) = sum_b f_pool(b) f_control(b), the
+        pool's composition measured on (a sample of) its packed targets, the controls' from the GC fraction they are
+        drawn with.  0.25 for uniform bases; larger on a GC-skewed genome, where mismatches are rarer."""
+        packed = getattr(self, "_db_packed", None)
+        if packed is None or len(packed) == 0:
+            return 0.25
+        sample = np.asarray(packed[:: max(1, len(packed) // 200_000)], dtype=np.uint64)
+        shifts = (2 * np.arange(self._guidelen, dtype=np.uint64))[None, :]
+        codes = ((sample[:, None] >> shifts) & np.uint64(3)).astype(np.uint8)      # A0 C1 G2 T3
+        f_pool = np.bincount(codes.reshape(-1), minlength=4).astype(np.float64)
+        f_pool /= f_pool.sum()
+        f_ctrl = np.array([(1 - gc) / 2, gc / 2, gc / 2, (1 - gc) / 2])
+        return float((f_pool * f_ctrl).sum())
+
     @staticmethod
     def _draw_control_seqs(count: int, length: int, gc: float) -> List[str]:
         """The same draw as strings."""
@@ -589,6 +604,13 @@ class TargetProcessor:
         wanted_dist = control_cfg["MINIMUM_HMDIST"]
         multiples = list(control_cfg["CONTROL_SEARCH_MULTIPLE"])
         largest_multiple = max(multiples)
+        # Opt-in (GPU: CONTROL_FAIL_FAST: true in the config; the reference has no such key): give up with the reference's
+        # IndexError as soon as TWO consecutive draws' exact nearest-distance histograms rule the largest draw out, instead
+        # of drawing every multiple first.  Off by default: the mirror then walks CONTROL_SEARCH_MULTIPLE exactly as the
+        # reference does (core.py:586-620) and leaves the global RNG in the state the reference would.
+        with open(configpath) as fh:
+            fail_fast = bool((yaml.safe_load(fh).get("GPU") or {}).get("CONTROL_FAIL_FAST", False))
+        ruled_out = 0
 
         # genome-wide GC fraction, length-weighted over the records; per record Bio.SeqUtils.gc_fraction's default:
         # (G+C+S) / (G+C+S+A+T+W+U), other letters ignored (reference core.py:570-578)
@@ -629,7 +651,17 @@ class TargetProcessor:
             # candidates stay numeric (codes -> packed words) until the n winners are known: at the
             # largest multiple this is 10^4 * n sequences
             codes = self._draw_control_codes(n * search_mult, length, gc)
-            d1 = self.nmslib_index.nearest(pack_codes(codes))
+            cpacked = pack_codes(codes)
+            sharded = False
+            if self.shard_candidates:
+                from . import distributed
+                sharded = distributed.is_distributed()
+            if sharded:
+                # one process per GPU: every rank has drawn the same sequences (same seed, same stream of the
+                # global RNGs -- checked by fingerprint), scans its shard of them, one all-gather of int32 distances
+                d1 = distributed.sharded_nearest_index(self.nmslib_index, cpacked, self.device)
+            else:
+                d1 = self.nmslib_index.nearest(cpacked)
             # sorted(..., reverse=True, key=dist) is stable: ties stay in draw order
             order = np.argsort(-d1.astype(np.int64), kind="stable")[0:n]
             sort_seq = codes_to_strings(codes[order])
@@ -640,19 +672,23 @@ class TargetProcessor:
             minimum_hmdist = int(min(sort_dist))
             sm_count += 1
             n_searched += n * search_mult
-            if minimum_hmdist < wanted_dist and sm_count < len(multiples):
-                # Fail fast.  The search is exact, so the nearest-distance histogram of this draw says whether the
-                # LARGEST multiple could ever yield n sequences at >= MINIMUM_HMDIST (the reference's HNSW misses
-                # neighbours and reports too-large distances, which is how its loop ends; an exact search on a large
-                # genome would draw 1.1 10^4 n more sequences and then walk off the list all the same).
-                expect = _controls_expected_at(d1, wanted_dist, length, n * largest_multiple, len(self._db_targets))
-                if expect < 0.1 * n:
+            if fail_fast and minimum_hmdist < wanted_dist and sm_count < len(multiples):
+                # The search is exact, so the nearest-distance histogram of a draw says whether the LARGEST multiple could
+                # yield n sequences at >= MINIMUM_HMDIST (the reference's HNSW misses neighbours and reports too-large
+                # distances, which is how its loop ends; an exact search on a large genome draws 1.1 10^4 n more
+                # sequences and then walks off the list all the same).  The extrapolation is a model (independent
+                # positions with the MEASURED match probability of controls against the pool): two draws in a row must
+                # agree, with a factor of a hundred to spare, before the search is abandoned.
+                p_match = self._control_match_probability(gc)
+                expect = _controls_expected_at(d1, wanted_dist, length, n * largest_multiple, len(self._db_targets), p_match=p_match)
+                ruled_out = ruled_out + 1 if expect < 0.01 * n else 0
+                if ruled_out >= 2:
                     raise IndexError(
                         "list index out of range: no %d control sequences at distance >= CONTROL.MINIMUM_HMDIST=%s "
                         "from every target can be expected within CONTROL.CONTROL_SEARCH_MULTIPLE=%s x n draws: the "
-                        "exact nearest-distance histogram of the first %d draws (best minimum %d over %d targets) puts "
+                        "exact nearest-distance histograms of the first %d draws (best minimum %d over %d targets) put "
                         "%.3g such sequences into the largest draw (the search is exact, so on large genomes lower "
-                        "MINIMUM_HMDIST in the config)"
+                        "MINIMUM_HMDIST in the config; GPU.CONTROL_FAIL_FAST asked for this early answer)"
                         % (n, wanted_dist, multiples, n_searched, minimum_hmdist, len(self._db_targets), expect))
         dt = time.perf_counter() - t0
         logger.info("get_control_seqs: %d random %d-mers x N_db=%d targets in %.3f s (%.3e guide pairs/s), minimum "
@@ -668,13 +704,17 @@ class TargetProcessor:
         return (min(sort_dist), statistics.median(sort_dist), table)
 
 
-def _controls_expected_at(d1, wanted, L, draws, n_db, min_count=30) -> float:
+def _controls_expected_at(d1, wanted, L, draws, n_db, min_count=30, p_match=0.25) -> float:
     """Expected number of random controls at nearest distance >= `wanted` among `draws` draws, from the exact nearest
-    distances d1 of a first draw.  P(nearest >= s) = exp(-lambda(s - 1)), lambda(r) = expected targets within r of a random
+    distances d1 of one draw.  P(nearest >= s) = exp(-lambda(s - 1)), lambda(r) = expected targets within r of a random
     sequence; it is read off the draw at the largest s <= wanted that still has `min_count` sequences, and carried to
-    `wanted` with the growth of lambda under uniform bases, lambda(r) / lambda(r - 1) = P(Bin(L, 3/4) <= r) / P(... <= r - 1)
-    -- a LOWER bound of the true growth for Levenshtein (lev <= hamming) and for skewed pools alike, so the figure
-    errs on the side of too many expected controls (the caller gives up only when even that is far too few)."""
+    `wanted` with the growth of lambda under independent positions that mismatch with probability q = 1 - p_match,
+    lambda(r) / lambda(r - 1) = P(Bin(L, q) <= r) / P(Bin(L, q) <= r - 1); p_match is the MEASURED match probability of
+    controls against the pool (TargetProcessor._control_match_probability; 0.25 = uniform bases).  With uniform bases on a
+    GC-rich pool the growth -- it scales with q / (1 - q): 3 at q = 0.75, 2.45 at 70 % GC -- would be overestimated and
+    the expected controls come out more than ten times too low; clustered pools (repeats) grow slower still
+    than independent positions, so this remains a MODEL, not a bound: the caller asks two draws to agree with a factor
+    of a hundred to spare, and only when the config opts in."""
     d1 = np.asarray(d1, dtype=np.int64)
     m = int(d1.shape[0])
     if m == 0:
@@ -687,10 +727,11 @@ def _controls_expected_at(d1, wanted, L, draws, n_db, min_count=30) -> float:
     if s_star == 0:                       # (every control hits a target exactly: nothing to extrapolate from)
         return 0.0 if n_db > 0 else float(draws)
     lam = -np.log(min(float(tail[s_star]) / m, 1.0 - 0.5 / m))
+    q = min(max(1.0 - float(p_match), 1e-6), 1.0 - 1e-6)
 
-    def within(r):                        # P(Bin(L, 3/4) <= r)
+    def within(r):                        # P(Bin(L, q) <= r)
         from math import comb
-        return sum(comb(L, i) * 0.75 ** i * 0.25 ** (L - i) for i in range(0, min(r, L) + 1))
+        return sum(comb(L, i) * q ** i * (1.0 - q) ** (L - i) for i in range(0, min(r, L) + 1))
 
     for s in range(s_star + 1, wanted + 1):
         lam *= within(s - 1) / max(within(s - 2), 1e-300)

@@ -175,8 +175,8 @@ int gm_pg_layout_radius(const gm_pg_layout& lay);
 bool gm_pg_layout_forced(const gm_index* idx, gm_pg_layout* out);
 int gm_pg_pool_stats(gm_index* idx, hipStream_t st, double* p_match);
 int gm_pg_prepare(gm_index* idx, const gm_pg_layout* lay, hipStream_t st);
-int gm_pg_candidates(gm_index* idx, int64_t n_q, hipStream_t st);
-int gm_pg_scan(gm_index* idx, int64_t n_q, int k, hipStream_t st);
+int gm_pg_candidates(gm_index* idx, int64_t n_q, int k, hipStream_t st);
+int gm_pg_scan(gm_index* idx, int64_t n_q, int k, int kcap, hipStream_t st);
 int gm_pg_merge(gm_index* idx, int kcap, int64_t n_q, int k, int32_t* ids, int32_t* dists, int32_t* counts,
                 bool nearest, hipStream_t st);
 int gm_pg_incomplete(gm_index* idx, int64_t* n_inc, int64_t* pairs_evaluated, hipStream_t st);
@@ -198,7 +198,7 @@ int gm_pg_read_bad(gm_index* idx, int64_t* n_bad, hipStream_t st);
 // rows i of [0, n) with counts[i] < need -> pg->inc (compact; their number arrives with gm_pg_read_bad); the list itself
 int gm_pg_collect_short(gm_index* idx, int64_t n, int need, const int32_t* counts, hipStream_t st);
 const int32_t* gm_pg_inc_list(const gm_index* idx);
-int gm_pg_debug_flags(const gm_index* idx);      // gm_set_param "pg_debug" (timing experiments)
+int gm_pg_debug_flags(const gm_index* idx);      // non-zero in a -DGM_PG_TIMING build (its answers are wrong on purpose)
 int gm_pg_blocks_of(const gm_index* idx);
 int gm_pg_block_info(const gm_index* idx, int b, int* positions, int64_t* pairs);
 int gm_pg_radius(const gm_index* idx);      // r of the layout in use: every pair within r is enumerated

@@ -70,18 +70,30 @@ int launch_pg_cfg(gm_index* idx, const gm_pg_blocks* blocks, const gm_pg_chunk* 
     return GM_OK;
 }
 
+template <int L, int KCAP>
+int launch_pg4_kc(gm_index* idx, const gm_pg_blocks* blocks, const gm_pg_chunk* chunks, const int* c_begin,
+                  const int* c_end, int64_t grid, int64_t n_q, int k, int thr0, uint32_t* keys, hipStream_t st) {
+    const size_t lds = gm::pg4_lds_bytes(L);
+    if (blocks->cut_id != 0xffffffffu)
+        hipLaunchKernelGGL((gm::k_hamming_scan_pg4<L, true, KCAP>), dim3((unsigned)grid), dim3(gm::WAVE), lds, st, *blocks, chunks,
+                           c_begin, c_end, idx->d_q, n_q, k, thr0, keys);
+    else
+        hipLaunchKernelGGL((gm::k_hamming_scan_pg4<L, false, KCAP>), dim3((unsigned)grid), dim3(gm::WAVE), lds, st, *blocks, chunks,
+                           c_begin, c_end, idx->d_q, n_q, k, thr0, keys);
+    HIP_TRY(hipGetLastError());
+    return GM_OK;
+}
+
 template <int L>
 int launch_pg3_cfg(gm_index* idx, const gm_pg_blocks* blocks, const gm_pg_chunk* chunks, const int* c_begin,
                    const int* c_end, int64_t grid, int64_t n_q, int k, int kcap, int thr0, uint32_t* keys, hipStream_t st) {
-    const size_t lds = gm::pg3_lds_bytes(L, k);
-    if (blocks->cut_id != 0xffffffffu)
-        hipLaunchKernelGGL((gm::k_hamming_scan_pg3<L, true>), dim3((unsigned)grid), dim3(gm::WAVE), lds, st, *blocks, chunks,
-                           c_begin, c_end, idx->d_q, n_q, k, kcap, thr0, keys);
-    else
-        hipLaunchKernelGGL((gm::k_hamming_scan_pg3<L, false>), dim3((unsigned)grid), dim3(gm::WAVE), lds, st, *blocks, chunks,
-                           c_begin, c_end, idx->d_q, n_q, k, kcap, thr0, keys);
-    HIP_TRY(hipGetLastError());
-    return GM_OK;
+    switch (kcap) {
+        case 1: return launch_pg4_kc<L, 1>(idx, blocks, chunks, c_begin, c_end, grid, n_q, k, thr0, keys, st);
+        case 5: return launch_pg4_kc<L, 5>(idx, blocks, chunks, c_begin, c_end, grid, n_q, k, thr0, keys, st);
+        case 10: return launch_pg4_kc<L, 10>(idx, blocks, chunks, c_begin, c_end, grid, n_q, k, thr0, keys, st);
+        case 20: return launch_pg4_kc<L, 20>(idx, blocks, chunks, c_begin, c_end, grid, n_q, k, thr0, keys, st);
+        default: return gm_fail(GM_ERR_ARG, "pigeonhole kernel: unsupported list capacity");
+    }
 }
 
 }  // namespace

@@ -96,6 +96,15 @@ struct RegList {
             v[s] = lo;
         }
     }
+    // x = key + 1 as the list stores it; EMPTY (no key) falls through
+    __device__ __forceinline__ void insert_raw(uint32_t x) {
+#pragma unroll
+        for (int s = 0; s < KCAP; ++s) {
+            uint32_t lo = v[s] < x ? v[s] : x;
+            x = v[s] < x ? x : v[s];
+            v[s] = lo;
+        }
+    }
     // insert unless the key is already in the list (merging lists that may share entries)
     __device__ __forceinline__ void insert_unique(uint32_t key) {
         bool dup = false;

@@ -11,6 +11,12 @@
 // scan is driven by its own std::thread ("one host thread per handle" in the header); the collective is enqueued from
 // the calling thread inside ncclGroupStart / ncclGroupEnd.
 //
+// Test mode (GMHIP_TEST_VIRTUAL_DEVICES=1 in the environment): the device list may name one ordinal several times --
+// n LOGICAL shards with their own index, stream, host thread, padding and offsets on one physical GPU -- and the
+// all-gather is n^2 device-to-device copies in place of ncclAllGather (a communicator cannot hold one device twice).
+// Everything else of the n > 1 path -- the fan-out, the shard arithmetic, the key packing, the unpack on device 0 --
+// is the code a real node runs; it lets a one-GPU box execute it (tests/test_gpu_parity.py).
+//
 // (The Python package drives multi-GPU as one process per GPU over torch.distributed instead --
 // guidemaker_amd/distributed.py; this entry serves hosts without torch.  Do not drive RCCL through both in one
 // process: PyTorch ships its own copy of librccl.so.)
@@ -18,6 +24,7 @@
 
 #include <dlfcn.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -73,6 +80,7 @@ struct gm_multi {
     std::vector<hipStream_t> streams;
     std::vector<ncclComm_t> comms;
     bool have_comm = false;
+    bool virtual_devices = false;      // test mode: an ordinal occurs more than once (no communicator; copies instead)
     // per-device workspaces (grow-only): packed shard, shard results, shard keys, gathered keys
     std::vector<void*> d_q, d_ids, d_dists, d_counts, d_keys, d_all;
     int64_t cap_per = 0, cap_k = 0;
@@ -126,6 +134,54 @@ int multi_ensure(gm_multi* m, int64_t per, int k) {
     return GM_OK;
 }
 
+// Every device's `send` block (count 32-bit words) to every device's `recv` buffer, block g at offset g * count:
+// one grouped ncclAllGather over the devices' communicators -- or, for logical shards on one GPU (test mode), plain
+// device-to-device copies on the receiving shard's stream.  The senders' streams have been synchronised by the caller.
+int multi_all_gather(gm_multi* m, const std::vector<void*>& send, const std::vector<void*>& recv, size_t count) {
+    const int n = m->n;
+    if (m->have_comm) {
+        Rccl& r = rccl();
+        ncclResult_t e = r.GroupStart();
+        for (int g = 0; g < n && e == ncclSuccess; ++g)
+            e = r.AllGather(send[(size_t)g], recv[(size_t)g], count, ncclUint32, m->comms[(size_t)g], m->streams[(size_t)g]);
+        const ncclResult_t e2 = r.GroupEnd();
+        if (e == ncclSuccess) e = e2;
+        if (e != ncclSuccess) return gm_fail(GM_ERR_DEVICE, std::string("ncclAllGather: ") + r.GetErrorString(e));
+        return GM_OK;
+    }
+    for (int g = 0; g < n; ++g) {
+        HIP_TRY(hipSetDevice(m->devices[(size_t)g]));
+        for (int h = 0; h < n; ++h)
+            HIP_TRY(hipMemcpyAsync(static_cast<uint32_t*>(recv[(size_t)g]) + (size_t)h * count, send[(size_t)h], sizeof(uint32_t) * count,
+                                   hipMemcpyDeviceToDevice, m->streams[(size_t)g]));
+    }
+    return GM_OK;
+}
+
+// run work(g) for every shard, each on a host thread of its own (the scans wait for their streams inside the call)
+template <class F>
+int multi_fan_out(gm_multi* m, F&& work) {
+    const int n = m->n;
+    std::vector<int> rcs((size_t)n, GM_OK);
+    std::vector<std::string> msgs((size_t)n);
+    auto run = [&](int g) {
+        const int r = work(g);
+        rcs[(size_t)g] = r;
+        if (r != GM_OK) msgs[(size_t)g] = gm_last_error();      // (thread-local in the worker)
+    };
+    if (n == 1) {
+        run(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int g = 0; g < n; ++g) th.emplace_back(run, g);
+        for (auto& t : th) t.join();
+    }
+    for (int g = 0; g < n; ++g)
+        if (rcs[(size_t)g] != GM_OK)
+            return gm_fail(rcs[(size_t)g], "device " + std::to_string(m->devices[(size_t)g]) + " (shard " + std::to_string(g) + "): " + msgs[(size_t)g]);
+    return GM_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -136,10 +192,15 @@ int gm_multi_create(const uint64_t* packed, int64_t n_db, int guidelen, int metr
     if (!out) return gm_fail(GM_ERR_ARG, "gm_multi_create: null out");
     *out = nullptr;
     if (!devices || n_devices < 1 || n_devices > 64) return gm_fail(GM_ERR_ARG, "gm_multi_create: need 1..64 devices");
+    bool dup = false;
     for (int a = 0; a < n_devices; ++a)
-        for (int b = a + 1; b < n_devices; ++b)
-            if (devices[a] == devices[b]) return gm_fail(GM_ERR_ARG, "gm_multi_create: duplicate device ordinal");
+        for (int b = a + 1; b < n_devices; ++b) dup = dup || devices[a] == devices[b];
+    {
+        const char* e = std::getenv("GMHIP_TEST_VIRTUAL_DEVICES");
+        if (dup && !(e && e[0] == '1')) return gm_fail(GM_ERR_ARG, "gm_multi_create: duplicate device ordinal");
+    }
     gm_multi* m = new gm_multi();
+    m->virtual_devices = dup;
     m->n = n_devices;
     m->devices.assign(devices, devices + n_devices);
     m->idx.assign(n_devices, nullptr);
@@ -152,7 +213,7 @@ int gm_multi_create(const uint64_t* packed, int64_t n_db, int guidelen, int metr
         if (rc == GM_OK && (hipSetDevice(devices[g]) != hipSuccess || hipStreamCreate(&m->streams[g]) != hipSuccess))
             rc = gm_fail(GM_ERR_DEVICE, "gm_multi_create: hipStreamCreate failed");
     }
-    if (rc == GM_OK) {
+    if (rc == GM_OK && !m->virtual_devices) {
         Rccl& r = rccl();
         if (r.ok) {
             const ncclResult_t e = r.CommInitAll(m->comms.data(), n_devices, devices);
@@ -201,45 +262,28 @@ int gm_multi_knn_query(gm_multi* m, const uint64_t* q, int64_t n_q, int k, int32
     int rc = multi_ensure(m, per, k);
     if (rc) return rc;
     // phase 1: every device scans its shard (own host thread per device), packs its lists into keys
-    std::vector<int> rcs((size_t)n, GM_OK);
-    std::vector<std::string> msgs((size_t)n);
-    auto work = [&](int g) {
+    rc = multi_fan_out(m, [&](int g) -> int {
         const int64_t lo = per * g < n_q ? per * g : n_q, hi = lo + per < n_q ? lo + per : n_q, cnt = hi - lo;
-        hipStream_t st = m->streams[g];
-        int r = GM_OK;
-        if (hipSetDevice(m->devices[g]) != hipSuccess) r = gm_fail(GM_ERR_DEVICE, "hipSetDevice failed");
+        hipStream_t st = m->streams[(size_t)g];
+        if (hipSetDevice(m->devices[(size_t)g]) != hipSuccess) return gm_fail(GM_ERR_DEVICE, "hipSetDevice failed");
         // rows past the end of the candidate list: "no neighbour" keys
-        if (r == GM_OK && hipMemsetAsync(m->d_keys[g], 0xff, sizeof(uint32_t) * per * k, st) != hipSuccess)
-            r = gm_fail(GM_ERR_DEVICE, "hipMemsetAsync(keys) failed");
-        if (r == GM_OK && cnt > 0) {
-            if (hipMemcpyAsync(m->d_q[g], q + lo, sizeof(uint64_t) * cnt, hipMemcpyHostToDevice, st) != hipSuccess)
-                r = gm_fail(GM_ERR_DEVICE, "hipMemcpyAsync(shard) failed");
-            if (r == GM_OK) r = gm_knn_query_dev(m->idx[g], m->d_q[g], cnt, k, m->d_ids[g], m->d_dists[g], m->d_counts[g], st);
-            if (r == GM_OK) r = gm_pack_keys_dev(m->d_ids[g], m->d_dists[g], cnt, k, m->d_keys[g], st);
+        if (hipMemsetAsync(m->d_keys[(size_t)g], 0xff, sizeof(uint32_t) * per * k, st) != hipSuccess)
+            return gm_fail(GM_ERR_DEVICE, "hipMemsetAsync(keys) failed");
+        if (cnt > 0) {
+            int r;
+            if (hipMemcpyAsync(m->d_q[(size_t)g], q + lo, sizeof(uint64_t) * cnt, hipMemcpyHostToDevice, st) != hipSuccess)
+                return gm_fail(GM_ERR_DEVICE, "hipMemcpyAsync(shard) failed");
+            if ((r = gm_knn_query_dev(m->idx[(size_t)g], m->d_q[(size_t)g], cnt, k, m->d_ids[(size_t)g], m->d_dists[(size_t)g], m->d_counts[(size_t)g], st))) return r;
+            if ((r = gm_pack_keys_dev(m->d_ids[(size_t)g], m->d_dists[(size_t)g], cnt, k, m->d_keys[(size_t)g], st))) return r;
         }
-        if (r == GM_OK && hipStreamSynchronize(st) != hipSuccess) r = gm_fail(GM_ERR_DEVICE, "shard scan failed");
-        rcs[(size_t)g] = r;
-        if (r != GM_OK) msgs[(size_t)g] = gm_last_error();      // (thread-local in the worker)
-    };
-    if (n == 1) {
-        work(0);
-    } else {
-        std::vector<std::thread> th;
-        for (int g = 0; g < n; ++g) th.emplace_back(work, g);
-        for (auto& t : th) t.join();
-    }
-    for (int g = 0; g < n; ++g)
-        if (rcs[(size_t)g] != GM_OK) return gm_fail(rcs[(size_t)g], "device " + std::to_string(m->devices[g]) + ": " + msgs[(size_t)g]);
+        if (hipStreamSynchronize(st) != hipSuccess) return gm_fail(GM_ERR_DEVICE, "shard scan failed");
+        return GM_OK;
+    });
+    if (rc) return rc;
     // phase 2: ONE all-gather of the keys over RCCL / xGMI
     const void* gathered = m->d_keys[0];
-    if (m->have_comm) {
-        Rccl& r = rccl();
-        ncclResult_t e = r.GroupStart();
-        for (int g = 0; g < n && e == ncclSuccess; ++g)
-            e = r.AllGather(m->d_keys[g], m->d_all[g], (size_t)(per * k), ncclUint32, m->comms[g], m->streams[g]);
-        const ncclResult_t e2 = r.GroupEnd();
-        if (e == ncclSuccess) e = e2;
-        if (e != ncclSuccess) return gm_fail(GM_ERR_DEVICE, std::string("ncclAllGather: ") + r.GetErrorString(e));
+    if (m->have_comm || n > 1) {
+        if ((rc = multi_all_gather(m, m->d_keys, m->d_all, (size_t)(per * k)))) return rc;
         gathered = m->d_all[0];
     }
     // phase 3: device 0 unpacks the gathered table; back to the caller
@@ -252,6 +296,49 @@ int gm_multi_knn_query(gm_multi* m, const uint64_t* q, int64_t n_q, int k, int32
     for (int g = 0; g < n; ++g) {      // every device's part of the collective has finished before the buffers are reused
         HIP_TRY(hipSetDevice(m->devices[g]));
         HIP_TRY(hipStreamSynchronize(m->streams[g]));
+    }
+    return GM_OK;
+}
+
+// Nearest-target distance of every candidate (get_control_seqs' k = 2 batch, /root/reference/guidemaker/core.py:603: the
+// path's largest query set), sharded like gm_multi_knn_query: device g scans shard g (gm_nearest_dist_dev), ONE
+// all-gather of the int32 distances, device 0's copy goes back.  d1[i] = -1 only for an empty pool.
+int gm_multi_nearest_dist(gm_multi* m, const uint64_t* q, int64_t n_q, int32_t* d1) {
+    GM_ENTER();
+    if (!m) return gm_fail(GM_ERR_ARG, "gm_multi_nearest_dist: null handle");
+    if (n_q < 0) return gm_fail(GM_ERR_ARG, "gm_multi_nearest_dist: need n_q >= 0");
+    if (n_q == 0) return GM_OK;
+    if (!q || !d1) return gm_fail(GM_ERR_ARG, "gm_multi_nearest_dist: null buffer");
+    const int n = m->n;
+    const int64_t per = (n_q + n - 1) / n;
+    int rc = multi_ensure(m, per, 1);      // (d_keys: the shard's distances, d_all: the gathered ones)
+    if (rc) return rc;
+    rc = multi_fan_out(m, [&](int g) -> int {
+        const int64_t lo = per * g < n_q ? per * g : n_q, hi = lo + per < n_q ? lo + per : n_q, cnt = hi - lo;
+        hipStream_t st = m->streams[(size_t)g];
+        if (hipSetDevice(m->devices[(size_t)g]) != hipSuccess) return gm_fail(GM_ERR_DEVICE, "hipSetDevice failed");
+        if (hipMemsetAsync(m->d_keys[(size_t)g], 0xff, sizeof(uint32_t) * per, st) != hipSuccess)      // padding rows: -1
+            return gm_fail(GM_ERR_DEVICE, "hipMemsetAsync(distances) failed");
+        if (cnt > 0) {
+            int r;
+            if (hipMemcpyAsync(m->d_q[(size_t)g], q + lo, sizeof(uint64_t) * cnt, hipMemcpyHostToDevice, st) != hipSuccess)
+                return gm_fail(GM_ERR_DEVICE, "hipMemcpyAsync(shard) failed");
+            if ((r = gm_nearest_dist_dev(m->idx[(size_t)g], m->d_q[(size_t)g], cnt, m->d_keys[(size_t)g], st))) return r;
+        }
+        if (hipStreamSynchronize(st) != hipSuccess) return gm_fail(GM_ERR_DEVICE, "shard scan failed");
+        return GM_OK;
+    });
+    if (rc) return rc;
+    const void* gathered = m->d_keys[0];
+    if (m->have_comm || n > 1) {
+        if ((rc = multi_all_gather(m, m->d_keys, m->d_all, (size_t)per))) return rc;
+        gathered = m->d_all[0];
+    }
+    HIP_TRY(hipSetDevice(m->devices[0]));
+    HIP_TRY(hipMemcpyAsync(d1, gathered, sizeof(int32_t) * n_q, hipMemcpyDeviceToHost, m->streams[0]));
+    for (int g = 0; g < n; ++g) {
+        HIP_TRY(hipSetDevice(m->devices[(size_t)g]));
+        HIP_TRY(hipStreamSynchronize(m->streams[(size_t)g]));
     }
     return GM_OK;
 }

@@ -26,7 +26,6 @@ struct gm_pg_blocks {
     int trad[GM_PG_MAXB];                // search radius of block b (a pair is REPORTED by the first block that finds it)
     int n_lists;
     int run;                             // consecutive chunk-table entries executed on the same XCD
-    int debug;                           // timing experiments only (gm_set_param "pg_debug"): bit 0 = skip the list stores
     int row_words;                       // words of one candidate's row of the hit buffer: [keys 0..3 of every list][keys 4.. of list 0] ...
     int lcap[GM_PG_MAXLISTS];            // key capacity of list l (a multiple of 4, at least 4)
     int loff[GM_PG_MAXLISTS];            // keys 0..3 of list l of candidate q: word q * row_words + 4 l; keys 4..: q * row_words + loff[l]

@@ -418,8 +418,9 @@ struct gm_pigeon {
     int64_t last_bpairs[GM_PG_MAXB]{}; // pairs block b's part of the last launch evaluated
     int tune_sub = 2;                  // workgroups per expansion chunk (gm_set_param "pg_sub")
     int tune_per = 0;                  // target buckets per workgroup, 0 = 16 / pg_sub (gm_set_param "pg_per")
-    int tune_hit = 1;                  // 1 = hit lists in LDS (k_hamming_scan_pg3), 0 = hit buffer in HBM (gm_set_param "pg_hit")
-    int tune_debug = 0;                // timing experiments (gm_set_param "pg_debug")
+    int tune_hit = 1;                  // hit path (gm_set_param "pg_hit"): 0 = hit buffer in HBM (k_hamming_scan_pg), 2 = register lists
+                                       // (k_hamming_scan_pg4), 1 = chosen per level (pg_use_reglists)
+    bool hit_reg = false;              // the hit path of the launch being prepared / merged
     int tune_layout = 0;               // experiments: forced layout, decimal digit pairs (len, radius) per block
     int tune_gap = 0;                  // table gaps: 0 = choose, 1 = common gap (one launch), 2 = per-block gaps
     int tune_run = 128;                // chunk-table entries per XCD run (gm_set_param "pg_run")
@@ -940,7 +941,6 @@ void gm_pg_inherit(gm_index* idx, const gm_pigeon* parent) {
     pg->tune_run = parent->tune_run;
     pg->tune_msplit = parent->tune_msplit;
     pg->tune_prefix = parent->tune_prefix;
-    pg->tune_debug = parent->tune_debug;
     pg->tune_layout = idx->pg_layout_deeper;
 }
 const gm_pigeon* gm_pg_state(const gm_index* idx) { return idx->pg; }
@@ -977,7 +977,7 @@ int gm_pg_set_param(gm_index* idx, const char* name, int value) {
         return GM_OK;
     }
     if (std::strcmp(name, "pg_hit") == 0) {
-        if (value != 0 && value != 1) return gm_fail(GM_ERR_ARG, "pg_hit: 0 (hit buffer), 1 (lists in LDS)");
+        if (value < 0 || value > 2) return gm_fail(GM_ERR_ARG, "pg_hit: 0 (hit buffer), 1 (chosen per level), 2 (register lists)");
         idx->pg->tune_hit = value;
         idx->pg->cap_nq = -1;
         return GM_OK;
@@ -991,10 +991,8 @@ int gm_pg_set_param(gm_index* idx, const char* name, int value) {
         idx->pg->B = 0;
         return GM_OK;
     }
-    if (std::strcmp(name, "pg_debug") == 0) {
-        idx->pg->tune_debug = value;
-        return GM_OK;
-    }
+    if (std::strcmp(name, "pg_debug") == 0)      // (timing experiments are separate builds: make CXXFLAGS+=-DGM_PG_TIMING=...)
+        return gm_fail(GM_ERR_ARG, "pg_debug: not in this build (timing experiments are compile-time: -DGM_PG_TIMING)");
     if (std::strcmp(name, "pg_cut") == 0) {
         if (value < 0 || value > 100) return gm_fail(GM_ERR_ARG, "pg_cut: 0 (choose), 1..99 (percent of the ids), 100 (off)");
         idx->pg->tune_cut = value;
@@ -1205,8 +1203,19 @@ int gm_pg_prepare(gm_index* idx, const gm_pg_layout* lay, hipStream_t st) {
 // per block: target buckets of a candidate bucket, the workgroups they are split over (about 16 / pg_sub = 8 buckets
 // per workgroup, at most 6 workgroups per chunk -- every workgroup means one more hit list per candidate), and the
 // hit-list numbering
+// The hit path of a level.  Register lists (k_hamming_scan_pg4): exact bound, no hit buffer, a merge that reads 40 dense
+// bytes per list -- at 6 instead of 8 waves per SIMD (10 more VGPRs) and with a serial sorted insert per delivered key.
+// Measured (profiles/r04/NOTES.md): faster where hits are dense and chunks plentiful (PAO1 level 0: scan 1.82 -> 1.56 ms,
+// merge 0.40 -> 0.11), equal on S1, slower on the deeper levels' few short-handed chunks and with 20-key lists.
+static bool pg_use_reglists(const gm_pigeon* pg, int64_t n_q, int k) {
+    if (pg->tune_hit != 1) return pg->tune_hit == 2;
+    return k <= 10 && n_q >= 400000;
+}
+
 static void pg_geometry(gm_pigeon* pg) {
-    const int per_target = pg->tune_per > 0 ? pg->tune_per : (16 + pg->tune_sub - 1) / pg->tune_sub;
+    // (register lists: every chunk's target buckets in ONE workgroup -- a list sees all the block's hits of its candidates,
+    // its bound tightens three times sooner, and the merge has a third of the lists to fold)
+    const int per_target = pg->tune_per > 0 ? pg->tune_per : (pg->hit_reg ? 4096 : (16 + pg->tune_sub - 1) / pg->tune_sub);
     int cap_sub = 6;
     for (;;) {
         int lists = 0;
@@ -1231,9 +1240,10 @@ static void pg_geometry(gm_pigeon* pg) {
 }
 
 // group the candidates in idx->d_q by every block's value and build the chunk table
-int gm_pg_candidates(gm_index* idx, int64_t n_q, hipStream_t st) {
+int gm_pg_candidates(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
     gm_pigeon* pg = idx->pg;
     if (!pg || pg->B < 2) return gm_fail(GM_ERR_ARG, "gm_pg_candidates: no layout prepared");
+    pg->hit_reg = pg_use_reglists(pg, n_q, k);
     if (n_q >= (int64_t)1 << 31) return gm_fail(GM_ERR_ARG, "gm_pg_candidates: too many candidates");
     int rc;
     const int n_entries = pg->ebase[pg->B];      // (block, bucket) entries = histogram bins
@@ -1353,7 +1363,7 @@ static void pg_list_capacity(const gm_index* idx, gm_pigeon* pg, int64_t n_q) {
 
 int64_t gm_pg_list_words(const gm_pigeon* pg) { return pg->blocks.row_words; }
 
-int gm_pg_scan(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
+int gm_pg_scan(gm_index* idx, int64_t n_q, int k, int kcap, hipStream_t st) {
     gm_pigeon* pg = idx->pg;
     int rc;
     uint64_t lkey = 0;      // the radii of the layout in use (the block lengths are fixed while the copies live)
@@ -1404,8 +1414,9 @@ int gm_pg_scan(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
         }
     }
     const int sub_key = pg->tune_sub * 8192 + pg->tune_per;
-    const int kcap3 = k <= 1 ? 1 : (k <= 5 ? 5 : (k <= 10 ? 10 : 20));
-    if (pg->tune_hit) {
+    if (pg->hit_reg != pg_use_reglists(pg, n_q, k)) return gm_fail(GM_ERR_ARG, "gm_pg_scan: candidates were grouped for another k");
+    const int kcap3 = kcap;      // (the merge reads the raw lists with the same stride)
+    if (pg->hit_reg) {
         pg_geometry(pg);
         if ((rc = ensure(&pg->keys3, &pg->keys3_cap, (int64_t)pg->blocks.n_lists * n_q * kcap3, "K1P raw lists"))) return rc;
 #ifdef GM_PG_STATS      // instrumented build (tools only): eight 64-bit event counters per launch, printed to stderr
@@ -1441,7 +1452,6 @@ int gm_pg_scan(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
     blocks.cflag = pg->cflag;
     const int thr0 = gm_pg_radius(idx) + 1;      // accept d < thr0, i.e. d <= r
     blocks.run = pg->tune_run;
-    blocks.debug = pg->tune_debug;
     const int64_t unit = 8 * (int64_t)blocks.run;      // the kernel's entry mapping permutes whole units
     // one launch per run of consecutive blocks whose copies keep the same number of positions
     for (int b0 = 0; b0 < pg->B;) {
@@ -1455,7 +1465,7 @@ int gm_pg_scan(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
         switch (pg->Lp[b0]) {            // the kernel instantiated for the positions actually evaluated
 #define GM_CASE(LEN)                                                                                                     \
     case LEN:                                                                                                            \
-        rc2 = pg->tune_hit ? gm_launch_pg3_L##LEN(idx, &blocks, pg->chunks, c_begin, c_end, grid, n_q, k, kcap3, thr0, pg->keys3, st) \
+        rc2 = pg->hit_reg ? gm_launch_pg3_L##LEN(idx, &blocks, pg->chunks, c_begin, c_end, grid, n_q, k, kcap3, thr0, pg->keys3, st) \
                            : gm_launch_pg_L##LEN(idx, &blocks, pg->chunks, c_begin, c_end, grid, n_q, k, thr0, pg->lists, st);       \
         break;
             GM_FOR_EACH_LEN(GM_CASE)
@@ -1466,12 +1476,12 @@ int gm_pg_scan(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
         b0 = b1;
     }
 #ifdef GM_PG_STATS
-    if (pg->tune_hit) {
+    if (pg->hit_reg) {
         unsigned long long h[8];
         HIP_TRY(hipMemcpyAsync(h, pg->hdr, sizeof(h), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        fprintf(stderr, "[gm stats] n_q %lld: workgroups %llu, rounds %llu (%llu at the end), hits dealt %llu, keys offered %llu, chain steps %llu\n",
-                (long long)n_q, h[5], h[0], h[4], h[1], h[2], h[3]);
+        fprintf(stderr, "[gm stats] n_q %lld: workgroups %llu, rounds %llu (%llu at the end), hits %llu, delivered %llu, sub-rounds %llu, inserts %llu\n",
+                (long long)n_q, h[5], h[0], h[4], h[1], h[2], h[3], h[6]);
     }
 #endif
     return GM_OK;
@@ -1490,7 +1500,7 @@ int gm_pg_merge(gm_index* idx, int kcap, int64_t n_q, int k, int32_t* ids, int32
     const dim3 grid = grid_for(n_q * split), block(256);
 #define GM_MERGE(KC, SP)                                                                                                          \
     do {                                                                                                                          \
-        if (pg->tune_hit)                                                                                                         \
+        if (pg->hit_reg)                                                                                                          \
             hipLaunchKernelGGL((gm::k_merge_pg3<KC, SP>), grid, block, 0, st, pg->keys3, pg->blocks.n_lists, n_q, k, ids, dists,   \
                                counts, nr, pg->inc, n_inc, &pg->ctr->n_over, pg->ctr->chist,                                      \
                                pg->cut_id != 0xffffffffu ? pg->cflag : nullptr);                                                  \
@@ -1769,7 +1779,14 @@ void gm_pg_expect_hits(gm_index* idx, double hits) {
 }
 
 const int32_t* gm_pg_inc_list(const gm_index* idx) { return idx->pg ? idx->pg->inc : nullptr; }
-int gm_pg_debug_flags(const gm_index* idx) { return idx->pg ? idx->pg->tune_debug : 0; }
+int gm_pg_debug_flags(const gm_index* idx) {
+    (void)idx;
+#ifdef GM_PG_TIMING
+    return GM_PG_TIMING;      // a timing build's answers are wrong on purpose: the handle must not learn from them
+#else
+    return 0;
+#endif
+}
 
 int gm_pg_scatter(gm_index* idx, int64_t n_inc, int k, bool nearest, int32_t* ids, int32_t* dists, int32_t* counts,
                   hipStream_t st) {

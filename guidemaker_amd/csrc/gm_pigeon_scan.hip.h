@@ -155,7 +155,7 @@ struct PgQueue {
 // FLUSH: n (<= 64, wave-uniform) queued hit words are turned into list entries, one per lane.
 __device__ __forceinline__ void pg_flush(PgQueue& Q, int n, int lane, const uint4* __restrict__ recs,
                                          uint32_t* __restrict__ lists, int off_a, int off_b, int lcap, int row_words, int k, int thr0,
-                                         int debug = 0, uint32_t cut_id = 0xffffffffu, int n_before = 0,
+                                         uint32_t cut_id = 0xffffffffu, int n_before = 0,
                                          const uint32_t* bmask = nullptr, const int* brad = nullptr) {
     uint32_t tg = 0;
     uint2 m = make_uint2(0u, 0u);
@@ -190,7 +190,11 @@ __device__ __forceinline__ void pg_flush(PgQueue& Q, int n, int lane, const uint
         if (!owned) continue;
         const int slot = atomicAdd(&Q.cnt[cl], 1);
         // (the first four keys of every list of a row sit together at the row's start, the rest list by list)
-        if (slot < lcap && !(debug & 1)) lists[row * row_words + (slot < 4 ? off_a : off_b) + slot] = ((uint32_t)d << ID_BITS) | t.z;
+#if defined(GM_PG_TIMING) && (GM_PG_TIMING & 1)      // timing build only (results WRONG): no list stores
+        (void)lists;
+#else
+        if (slot < lcap) lists[row * row_words + (slot < 4 ? off_a : off_b) + slot] = ((uint32_t)d << ID_BITS) | t.z;
+#endif
     }
     if (k == 1) {
         if (best < 64) atomicMin(&Q.c12[cl], (uint32_t)best);
@@ -296,7 +300,11 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
     // keys of candidate row: slots 0 .. 3 at lists + row * row_words + 4 lst, slot s >= 4 at ... + loff[lst] + (s - 4)
     uint32_t* __restrict__ mylists = lists;
     const int off_a = 4 * ch.lst, off_b = P.loff[ch.lst] - 4;
-    int thr = valid && !(P.debug & 2) ? thr0 : 0;              // accept d < thr  (debug bit 1: no hits at all, timing only)
+#if defined(GM_PG_TIMING) && (GM_PG_TIMING & 2)      // timing build only (results WRONG): no hit is accepted
+    int thr = 0;
+#else
+    int thr = valid ? thr0 : 0;              // accept d < thr
+#endif
     uint32_t Tb[5];
     // the blocks before this one (position masks, radii): a pair one of them finds is theirs to report
     uint32_t bmask[GM_PG_MAXB];
@@ -327,7 +335,7 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
     // flush when a full wave of entries is queued; afterwards the bounds may have tightened
 #define GM_PG_AFTER_GROUP()                                                       \
     if (Q.tail - Q.head >= WAVE) {                                                \
-        pg_flush(Q, WAVE, lane, recs, mylists, off_a, off_b, lcap, row_words, k, thr0, P.debug, cut_id, ch.b, bmask, brad); \
+        pg_flush(Q, WAVE, lane, recs, mylists, off_a, off_b, lcap, row_words, k, thr0, cut_id, ch.b, bmask, brad); \
         const int nt = pg_bound(Q, lane, k, thr0);                                \
         if (valid && nt < thr) thr = nt;                                          \
         cur = -1;                                                                 \
@@ -361,7 +369,7 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
 #undef GM_PG_BOUND
     while (Q.tail - Q.head > 0) {
         const int n_take = Q.tail - Q.head < WAVE ? Q.tail - Q.head : WAVE;
-        pg_flush(Q, n_take, lane, recs, mylists, off_a, off_b, lcap, row_words, k, thr0, P.debug, cut_id, ch.b, bmask, brad);
+        pg_flush(Q, n_take, lane, recs, mylists, off_a, off_b, lcap, row_words, k, thr0, cut_id, ch.b, bmask, brad);
     }
     // every (list, candidate) pair has exactly one writer (the row number comes back from LDS: a 64-bit index kept in
     // registers across the scan loop is two VGPRs the loop does not have)
@@ -369,159 +377,148 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg(
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// K1P with the hit lists in LDS (k_hamming_scan_pg3; gm_set_param "pg_hit" = 1).
+// K1P with the hit lists in REGISTERS (k_hamming_scan_pg4; gm_set_param "pg_hit" = 1).
 //
 // What the counters of the kernel above say on a real genome (profiles/r03: PAO1, ~72 targets within r per candidate):
-// the hit path is 57 % of the launch, and it is not instruction issue -- it is the vector-memory pipeline: every hit
-// is a scattered 4-byte store into a multi-GB hit buffer (one line per lane), every store stays in the wave's in-order
-// vmcnt queue in front of the next table unit, and the bound a workgroup works under (four counted levels) is loose.
-// Here a workgroup keeps, per candidate, its k BEST hits so far in LDS ([k][64] keys, slot-major: lanes that serve
-// different candidates touch different banks):
-//   * a hit is offered to its candidate's list by REPLACING THE LIST'S MAXIMUM: the lane reads the candidate's slots
-//     (empty slots hold 0xffffffff, slots beyond k hold 0), and if its key is below the maximum it swaps it in with one
-//     ds_cmpswap on that slot; a lane that loses the slot to another lane serving the same candidate reads again.  Only
-//     ever the maximum is replaced, by something smaller, and a key gives up only against a maximum it cannot beat: the
-//     slots end as the k smallest keys (unordered).  Two LDS round trips per attempt, whatever k (a sorted insert by a
-//     chain of k ds_min_rtn -- the first version -- measured 0.1 ms of S1's 0.72 ms scan).  No counter, no capacity, no
-//     overflow: a repeat family costs LDS operations, not a re-scan of the row;
-//   * the comparator bound of a candidate is the distance of its list's maximum (+ 1: ties go to the smaller id, decided
-//     on the key) -- exact at every level, not four counted ones;
-//   * no global store inside the scan loop: at the end every candidate's k keys go out as one 4 k-byte run into
-//     keys[list][row][KCAP] (the raw list format of gm_lookup.hip.h: key + 1, 0 = unused slot, 0xffffffff = empty),
-//     which k_merge_pg3 folds; the hit buffer, its headers and the capacity model of the kernel above are not needed;
-//   * the flush is DEALT: the queued (candidate, group, 64-bit hit word) entries are expanded through a prefix sum of
-//     their hit counts into a 64-slot window, every lane resolves ONE hit (a round is 64 hits whenever 64 entries are
-//     queued; an entry that is only partly taken stays at the ring's head with the rest of its bits) -- one record gather
-//     per 64 hits, all lanes busy.
+// the hit path is 57 % of the launch, and it is latency, not issue: every hit is a scattered 4-byte store into a
+// multi-GB hit buffer, every store stays in the wave's in-order vmcnt queue in front of the next table unit, the bound a
+// workgroup works under is four counted levels, and a flush walks the hit bits of its fullest entry round by round.
+// Here (measured steps: profiles/r04/NOTES.md):
+//   * ENQUEUE is per HIT: a lane with hits pushes (position in the copy, its lane) for its lowest hit bit -- ballot
+//     prefix as before -- and the few lanes with more bits go round again.  A ring entry is 5 bytes, and a flush
+//     round needs no expansion: lane t takes entry t.
+//   * every lane keeps ITS OWN candidate's k best keys in a sorted register list (RegList, as the plain scan K1L): the
+//     comparator bound is the list's k-th distance (+ 1; ties go to the smaller id, decided on the key) -- exact, in
+//     registers, no counters;
+//   * FLUSH ROUND (64 queued hits, one per lane): read the entry, fetch the candidate's planes from the owner lane
+//     (ds_bpermute), gather the target's record, distance by xor / or / popcount, drop what cannot beat the owner's
+//     published k-th key, and DELIVER the key to the owner through a four-deep mailbox per candidate in LDS (slot from
+//     a returning LDS add; a fifth key for one candidate waits a turn).  Every owner then drains its mailbox into its
+//     register list: <= 4 sorted inserts of 2 KCAP min / max each, all lanes busy (an empty slot inserts the "no key"
+//     sentinel, which falls through).  Two LDS round trips + one gather per round, whatever k; no atomics on list
+//     slots, no capacity, no overflow: a repeat family costs inserts, not a re-scan of the row;
+//   * no global store inside the scan loop: at the end every lane writes its list as one run into
+//     keys[list][row][KCAP] (the raw list format of gm_lookup.hip.h), which k_merge_pg3 folds; the hit buffer, its
+//     headers and the capacity model of the kernel above are not needed.  LDS per wave: 2 table units + 1.9 KB.
 // A pair that several blocks find is offered to every one of their lists (each workgroup's bound then counts every hit
 // it sees) and taken once by the merge (insert_unique on equal keys).
-constexpr uint32_t PG3_EMPTY = 0xffffffffu;
-__host__ __device__ constexpr int pg3_slots(int k) { return (k + 4) / 5 * 5; }      // list slots per candidate (read five at a time)
-__host__ __device__ constexpr size_t pg3_lds_bytes(int L, int k) {
-    return sizeof(uint32_t) * (size_t)(2 * pg_pair_words(L) + PG_QCAP * 3 + WAVE / 2 + WAVE * pg3_slots(k));
+constexpr uint32_t PG4_NONE = 0xffffffffu;      // "no key" (= RegList::EMPTY: inserting it changes nothing)
+constexpr int PG4_MAIL = 4;                     // mailbox slots per candidate and round
+__host__ __device__ constexpr size_t pg4_lds_bytes(int L) {
+    // tiles, ring (position u32 + lane u8), mailbox, mailbox counts, published k-th keys
+    return sizeof(uint32_t) * (size_t)(2 * pg_pair_words(L) + PG_QCAP + PG_QCAP / 4 + PG4_MAIL * WAVE + WAVE + WAVE);
 }
 
-// inclusive prefix sum over the 64 lanes (all lanes active): row_shr 1 / 2 / 4 / 8 inside rows of 16, then the gfx9 row
-// broadcasts 15 -> next row (rows 1, 3) and 31 -> upper half
-__device__ __forceinline__ int pg3_scan64(int v) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
-    return v;
-}
-
-struct Pg3Queue {
-    uint32_t* tag;      // [PG_QCAP]  group << 6 | candidate lane
-    uint2* mask;        // [PG_QCAP]  hit bits of the group's 64 targets not resolved yet
-    uint16_t* win;      // [WAVE]     the round's hits: entry (relative to the head) << 6 | bit
-    uint32_t* lists;    // [slots][WAVE]  per candidate the k smallest keys + 1 so far (unordered); PG3_EMPTY = free slot, 0 = not a slot
+struct Pg4Queue {
+    uint32_t* pos;      // [PG_QCAP]  position of the hit target in the block-sorted copy
+    uint8_t* ln;        // [PG_QCAP]  candidate lane
+    uint32_t* mail;     // [PG4_MAIL][WAVE]  keys + 1 delivered to candidate c this round
+    int* mc;            // [WAVE]     keys delivered to (or tried for) candidate c this round
+    uint32_t* kth;      // [WAVE]     candidate c's k-th key + 1 as of its last drain (PG4_NONE: list not full)
     int head, tail;     // wave-uniform ring positions (monotonic)
 };
 
-// one round of the flush: the first <= 64 queued hits are resolved, one per lane, and offered to their candidates' lists
 #ifdef GM_PG_STATS
 #define GM_PG_STAT(i, v) do { if (lane == 0) st_[i] += (unsigned long long)(v); } while (0)
 #else
 #define GM_PG_STAT(i, v) do { } while (0)
 #endif
-// maximum of candidate cl's list slots (the first one among equals: a free slot while the list is not full)
-__device__ __forceinline__ void pg3_row_max(const uint32_t* lists, int slots, int cl, uint32_t& M, int& m) {
-    M = 0u;
-    m = 0;
-    for (int s0 = 0; s0 < slots; s0 += 5) {
-        uint32_t v[5];
-#pragma unroll
-        for (int i = 0; i < 5; ++i) v[i] = lists[(s0 + i) * WAVE + cl];
-#pragma unroll
-        for (int i = 0; i < 5; ++i)
-            if (v[i] > M) {
-                M = v[i];
-                m = s0 + i;
-            }
-    }
-}
 
-// qv = this lane's own candidate planes, bit 31 of .x = the candidate takes the id cut-off (fetched from the owner lane
-// by ds_bpermute: no LDS copy of the planes)
-__device__ __forceinline__ void pg3_round(Pg3Queue& Q, int lane, const uint4* __restrict__ recs, int slots, int thr0, uint32_t cut_id,
-                                          uint2 qv
+// one round of the flush: the first <= 64 queued hits are resolved, one per lane, and delivered to their candidates'
+// owner lanes; qv = this lane's own candidate planes, bit 31 of .x = the candidate takes the id cut-off
+template <int KCAP>
+__device__ __forceinline__ void pg4_round(Pg4Queue& Q, int lane, const uint4* __restrict__ recs, int thr0, uint32_t cut_id,
+                                          uint2 qv, RegList<KCAP>& list
 #ifdef GM_PG_STATS
                                           , unsigned long long (&st_)[8]
 #endif
                                           ) {
     const int avail = Q.tail - Q.head;
-    const int take = avail < WAVE ? avail : WAVE;
+    const int n = avail < WAVE ? avail : WAVE;
     const int s = (Q.head + lane) & (PG_QCAP - 1);
-    uint2 m = make_uint2(0u, 0u);
-    if (lane < take) m = Q.mask[s];
-    const int hc = __popc(m.x) + __popc(m.y);
-    const int incl = pg3_scan64(hc);
-    const int excl = incl - hc;
-    const int total = __builtin_amdgcn_readlane(incl, WAVE - 1);
-    const int c = excl < WAVE ? (WAVE - excl < hc ? WAVE - excl : hc) : 0;      // this entry's share of the round's 64 slots
-    uint64_t hm = ((uint64_t)m.y << 32) | (uint64_t)m.x;
-    for (int i = 0; i < c; ++i) {
-        const int j = __builtin_ctzll(hm);
-        hm &= hm - 1ull;
-        Q.win[excl + i] = (uint16_t)((lane << 6) | j);
+    const bool mine = lane < n;
+    uint32_t pos = 0u;
+    int cl = 0;
+    if (mine) {
+        pos = Q.pos[s];
+        cl = (int)Q.ln[s];
     }
-    if (c > 0 && c < hc) Q.mask[s] = make_uint2((uint32_t)hm, (uint32_t)(hm >> 32));      // partly taken: stays at the head
-    // (the counts are positive, so the entries taken whole are a prefix of the ring)
-    const int whole = __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < take && incl <= WAVE));
-    const int head0 = Q.head;
-    Q.head += whole;
-    __syncthreads();      // single-wave workgroup: the window is written before it is read
-    const int nh = total < WAVE ? total : WAVE;
-    uint32_t x = PG3_EMPTY, w = 0u, tg = 0u;
-    if (lane < nh) {
-        w = Q.win[lane];
-        tg = Q.tag[(head0 + (int)(w >> 6)) & (PG_QCAP - 1)];
-    }
-    const int cl = (int)(tg & 63u);
-    // (every lane takes part in the two permutes; lanes without a hit read lane 0's planes and drop them)
+    Q.head += n;
+    // (every lane takes part in the two permutes; lanes without an entry read lane 0's planes and drop them)
     const uint2 cq = make_uint2((uint32_t)__builtin_amdgcn_ds_bpermute(cl << 2, (int)qv.x),
                                 (uint32_t)__builtin_amdgcn_ds_bpermute(cl << 2, (int)qv.y));
-    if (lane < nh) {
+    uint32_t x = PG4_NONE;
+    if (mine) {
 #if defined(GM_PG_TIMING) && (GM_PG_TIMING & 4)      // timing build only (results WRONG): no record gather
-        const uint4 t = make_uint4(w, tg, w * 977u & ID_MASK, 0u);
+        const uint4 t = make_uint4(pos, pos * 31u, pos * 977u & ID_MASK, 0u);
 #else
-        const uint4 t = recs[(int64_t)(tg >> 6) * LK_GROUP + (int64_t)(w & 63u)];
+        const uint4 t = recs[pos];
 #endif
         const uint32_t mism = ((cq.x ^ t.x) | (cq.y ^ t.y)) & 0x7fffffffu;      // one bit per mismatching position
         const int d = __popc(mism);
         const uint32_t cut_c = (cq.x >> 31) != 0u ? cut_id : 0xffffffffu;      // id cut-off: at distance r only ids below it count
-        if (!(d == thr0 - 1 && t.z >= cut_c)) x = (((uint32_t)d << ID_BITS) | t.z) + 1u;
+        const uint32_t key1 = (((uint32_t)d << ID_BITS) | t.z) + 1u;
+        if (!(d == thr0 - 1 && t.z >= cut_c) && key1 < Q.kth[cl]) x = key1;
     }
-#if defined(GM_PG_TIMING) && (GM_PG_TIMING & 1)      // timing build only (results WRONG): no list insertion
-    x = PG3_EMPTY;
+#if defined(GM_PG_TIMING) && (GM_PG_TIMING & 1)      // timing build only (results WRONG): nothing is delivered
+    x = PG4_NONE;
 #endif
     GM_PG_STAT(0, 1);
-    GM_PG_STAT(1, nh);
-    // replace-the-maximum insertion; a lane repeats only when another lane serving the same candidate took its slot
-    while (__builtin_amdgcn_ballot_w64(x != PG3_EMPTY) != 0ull) {
+    GM_PG_STAT(1, n);
+#ifdef GM_PG_STATS
+    { const int nd = __builtin_popcountll(__builtin_amdgcn_ballot_w64(x != PG4_NONE)); GM_PG_STAT(2, nd); }
+#endif
+    do {
         GM_PG_STAT(3, 1);
-        uint32_t M;
-        int m;
-        pg3_row_max(Q.lists, slots, cl, M, m);
-        if (x != PG3_EMPTY) {
-            if (x < M) {
-                if (atomicCAS(&Q.lists[m * WAVE + cl], M, x) == M) x = PG3_EMPTY;
-            } else {
-                x = PG3_EMPTY;      // cannot enter: k smaller keys are known
+        if (x != PG4_NONE) {
+            const int slot = atomicAdd(&Q.mc[cl], 1);
+            if (slot < PG4_MAIL) {
+                Q.mail[slot * WAVE + cl] = x;
+                x = PG4_NONE;
             }
         }
-    }
-    __syncthreads();
+        __syncthreads();      // single-wave workgroup: the deliveries are in LDS before the owners read
+        const int got = Q.mc[lane];
+        uint32_t kx[PG4_MAIL];
+#pragma unroll
+        for (int i = 0; i < PG4_MAIL; ++i) kx[i] = Q.mail[i * WAVE + lane];
+        Q.mc[lane] = 0;
+#pragma unroll
+        for (int i = 0; i < PG4_MAIL; ++i) {
+            const uint32_t v = i < got ? kx[i] : PG4_NONE;
+            if (__builtin_amdgcn_ballot_w64(i < got) != 0ull) {
+                GM_PG_STAT(6, 1);
+                list.insert_raw(v);
+            }
+        }
+        Q.kth[lane] = list.v[KCAP - 1];
+        __syncthreads();
+    } while (__builtin_amdgcn_ballot_w64(x != PG4_NONE) != 0ull);
 }
 
-// keys: [n_lists][n_q][kcap] raw lists (see above)
-template <int L, bool CUT>
-__global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg3(
+// the hit words of one 64-target group from LDS (word offset WOFF)
+template <int L, int WOFF>
+__device__ __forceinline__ uint64_t pg4_eval(const uint32_t* const (&ptr)[L], const uint32_t (&Tb)[5]) {
+    LkGroupRegs<L> r;
+    lk_read_group<L, WOFF>(r, ptr);
+    uint32_t c0[5], c1[5];
+    const uint32_t h0 = lk_eval_half<L>(r.m0, Tb, c0);
+    const uint32_t h1 = lk_eval_half<L>(r.m1, Tb, c1);
+    return ((uint64_t)h1 << 32) | (uint64_t)h0;
+}
+
+// keys: [n_lists][n_q][KCAP] raw lists (see above)
+#ifndef GM_PG4_W10
+#define GM_PG4_W10 6      /* waves per SIMD asked for with a 5 / 10-key register list */
+#endif
+#ifndef GM_PG4_W20
+#define GM_PG4_W20 4      /* ... with a 20-key list */
+#endif
+__host__ __device__ constexpr int pg4_min_waves(int L, int KCAP) { return L > 20 ? 1 : (KCAP <= 1 ? 8 : (KCAP <= 10 ? GM_PG4_W10 : GM_PG4_W20)); }
+template <int L, bool CUT, int KCAP>
+__global__ __launch_bounds__(WAVE, pg4_min_waves(L, KCAP)) void k_hamming_scan_pg4(
     gm_pg_blocks P, const gm_pg_chunk* __restrict__ chunks, const int* __restrict__ c_begin,
-    const int* __restrict__ c_end, const uint2* __restrict__ q, int64_t n_q, int k, int kcap, int thr0,
+    const int* __restrict__ c_end, const uint2* __restrict__ q, int64_t n_q, int k, int thr0,
     uint32_t* __restrict__ keys) {
     extern __shared__ __align__(16) uint32_t smem[];
     constexpr int GW = lk_group_words(L);
@@ -534,19 +531,22 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg3(
     const uint32_t* __restrict__ table = P.table[ch.b];
     const uint4* __restrict__ recs = P.recs[ch.b];
     uint32_t* tiles = smem;                                     // [2][PW]
-    Pg3Queue Q;
-    Q.tag = smem + 2 * PW;
-    Q.mask = reinterpret_cast<uint2*>(Q.tag + PG_QCAP);
-    Q.win = reinterpret_cast<uint16_t*>(Q.mask + PG_QCAP);
-    Q.lists = reinterpret_cast<uint32_t*>(Q.win + WAVE);
+    Pg4Queue Q;
+    Q.pos = smem + 2 * PW;
+    Q.ln = reinterpret_cast<uint8_t*>(Q.pos + PG_QCAP);
+    Q.mail = Q.pos + PG_QCAP + PG_QCAP / 4;
+    Q.mc = reinterpret_cast<int*>(Q.mail + PG4_MAIL * WAVE);
+    Q.kth = reinterpret_cast<uint32_t*>(Q.mc + WAVE);
     Q.head = Q.tail = 0;
     const int lane = threadIdx.x;
     const bool valid = lane < ch.cn;
     const int64_t qi = valid ? (int64_t)P.cperm[ch.b][ch.c0 + lane] : 0;
     uint2 qv = valid ? q[qi] : make_uint2(0u, 0u);
     const bool lane_cut = CUT && valid && P.cflag[qi] != 0;
-    const int slots = pg3_slots(k);
-    for (int s = 0; s < slots; ++s) Q.lists[s * WAVE + lane] = s < k ? PG3_EMPTY : 0u;
+    RegList<KCAP> list;
+    list.init(k, nullptr, 0);
+    Q.mc[lane] = 0;
+    Q.kth[lane] = list.v[KCAP - 1];
 
     const int skip_start = P.skip[ch.b], skip_len = P.skiplen[ch.b];
     const uint32_t* ptr[L];
@@ -584,48 +584,57 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg3(
             lk_set_bound(Tb, L, t_ - (ADD));                                              \
         }                                                                                 \
     }
-    // a round whenever 64 entries are queued (>= 64 hits: the round is dense); afterwards the bounds may have tightened
-#define GM_PG_AFTER_GROUP()                                                       \
-    if (Q.tail - Q.head >= WAVE) {                                                \
-        do pg3_round(Q, lane, recs, slots, thr0, cut_id, qv GM_PG_STARG);         \
-        while (Q.tail - Q.head >= WAVE);                                          \
-        uint32_t kth;                                                             \
-        int kth_at;                                                               \
-        pg3_row_max(Q.lists, slots, lane, kth, kth_at);                           \
-        const int nt = kth == PG3_EMPTY ? thr : (int)((kth - 1u) >> ID_BITS) + 1; \
-        if (nt < thr) thr = nt;                                                   \
-        cur = -1;                                                                 \
+    // push the group's hits, lowest bit of every lane first; a round whenever 64 hits are queued (afterwards the bounds may
+    // have tightened: the rest of this group's hit bits were formed under the old one and are dropped by the key test)
+#define GM_PG_GROUP(WOFF, G)                                                                                   \
+    {                                                                                                          \
+        uint64_t hm = pg4_eval<L, WOFF>(ptr, Tb);                                                              \
+        uint64_t bal = __builtin_amdgcn_ballot_w64(hm != 0ull);                                                \
+        while (bal != 0ull) {                                                                                  \
+            if (hm != 0ull) {                                                                                  \
+                const uint32_t before =                                                                        \
+                    __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u)); \
+                const int s_ = (Q.tail + (int)before) & (PG_QCAP - 1);                                         \
+                Q.pos[s_] = ((uint32_t)(G) << 6) + (uint32_t)__builtin_ctzll(hm);                              \
+                Q.ln[s_] = (uint8_t)lane;                                                                      \
+                hm &= hm - 1ull;                                                                               \
+            }                                                                                                  \
+            Q.tail += __builtin_popcountll(bal);                                                               \
+            if (Q.tail - Q.head >= WAVE) {                                                                     \
+                pg4_round<KCAP>(Q, lane, recs, thr0, cut_id, qv, list GM_PG_STARG);                            \
+                const int nt = list.v[KCAP - 1] == PG4_NONE ? thr : (int)((list.v[KCAP - 1] - 1u) >> ID_BITS) + 1; \
+                if (nt < thr) thr = nt;                                                                        \
+                cur = -1;                                                                                      \
+            }                                                                                                  \
+            bal = __builtin_amdgcn_ballot_w64(hm != 0ull);                                                     \
+        }                                                                                                      \
     }
     while (okA) {
         okB = pg_next<CUT>(P, ch, it, gB, ngB, addB, ucB);
         lk_stage_wait();                                        // unit A has landed in buffer 0
         if (okB) pg_stage<L>(table, gB, tiles + PW, lane);
         GM_PG_BOUND(addA, ucA < 1)
-        pg_group<L, 0>(ptr, Tb, gA, lane, Q);
-        GM_PG_AFTER_GROUP()
+        GM_PG_GROUP(0, gA)
         if (ngA > 1) {
             GM_PG_BOUND(addA, ucA < 2)
-            pg_group<L, GW>(ptr, Tb, gA + 1, lane, Q);
-            GM_PG_AFTER_GROUP()
+            GM_PG_GROUP(GW, gA + 1)
         }
         if (!okB) break;
         okA = pg_next<CUT>(P, ch, it, gA, ngA, addA, ucA);
         lk_stage_wait();                                        // unit B has landed in buffer 1
         if (okA) pg_stage<L>(table, gA, tiles, lane);
         GM_PG_BOUND(addB, ucB < 1)
-        pg_group<L, PW>(ptr, Tb, gB, lane, Q);
-        GM_PG_AFTER_GROUP()
+        GM_PG_GROUP(PW, gB)
         if (ngB > 1) {
             GM_PG_BOUND(addB, ucB < 2)
-            pg_group<L, PW + GW>(ptr, Tb, gB + 1, lane, Q);
-            GM_PG_AFTER_GROUP()
+            GM_PG_GROUP(PW + GW, gB + 1)
         }
     }
-#undef GM_PG_AFTER_GROUP
+#undef GM_PG_GROUP
 #undef GM_PG_BOUND
     while (Q.tail - Q.head > 0) {
         GM_PG_STAT(4, 1);
-        pg3_round(Q, lane, recs, slots, thr0, cut_id, qv GM_PG_STARG);
+        pg4_round<KCAP>(Q, lane, recs, thr0, cut_id, qv, list GM_PG_STARG);
     }
 #ifdef GM_PG_STATS
     if (lane == 0) {
@@ -637,8 +646,9 @@ __global__ __launch_bounds__(WAVE, (L <= 20 ? 8 : 1)) void k_hamming_scan_pg3(
     // registers across the scan loop is two VGPRs the loop does not have)
     if (lane < ch.cn) {
         const int64_t row = (int64_t)P.cperm[ch.b][ch.c0 + lane];
-        uint32_t* __restrict__ out = keys + ((int64_t)ch.lst * n_q + row) * kcap;
-        for (int s = 0; s < kcap; ++s) out[s] = s < k ? Q.lists[s * WAVE + lane] : 0u;
+        uint32_t* __restrict__ out = keys + ((int64_t)ch.lst * n_q + row) * KCAP;
+#pragma unroll
+        for (int s = 0; s < KCAP; ++s) out[s] = list.v[s];
     }
 }
 

@@ -864,11 +864,11 @@ static int run_pigeon_level(gm_index* idx, int level, bool nearest, int64_t n_q,
         if (forced && rc == GM_ERR_ARG) return GM_OK;      // forced layout not usable for this length
         return rc;
     }
-    if ((rc = gm_pg_candidates(idx, n_q, st))) return rc;
+    if ((rc = gm_pg_candidates(idx, n_q, keff, st))) return rc;
     const int kcap = nearest ? 1 : (k <= 5 ? 5 : (k <= 10 ? 10 : 20));
     if (timed && (rc = timing_begin(idx, st))) return rc;
     if (timed) idx->last_kernel = "k_hamming_scan_pg";
-    if ((rc = gm_pg_scan(idx, n_q, keff, st))) {
+    if ((rc = gm_pg_scan(idx, n_q, keff, kcap, st))) {
         if (rc == GM_ERR_ALLOC) return GM_OK;      // no room for the slot lists: the plain scan takes over
         return rc;
     }

@@ -141,6 +141,54 @@ def sharded_knn(local_knn, q_packed, k, device=None, group=None):
     return tuple(x.cpu().numpy() for x in g)
 
 
+def sharded_nearest(local_nearest, q_packed, device=None, group=None):
+    """Nearest-target distance of all candidates with the work split over the ranks (get_control_seqs' k = 2 batch,
+    reference core.py:603: every rank draws the SAME random sequences -- same seed, same stream -- scans its contiguous
+    shard, and ONE all-gather of int32 distances gives every rank the whole vector).
+
+    local_nearest(q_shard_uint64) -> [n] int32 numpy array (Index.nearest of this rank's GPU).  q_packed: the FULL
+    candidate array, identical on every rank.  Returns the full [n] int32 array on every rank."""
+    import torch
+    dist = _dist()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    q_packed = np.ascontiguousarray(q_packed, dtype=np.uint64)
+    n = int(q_packed.shape[0])
+    lo, hi, per = shard_range(n, world, rank)
+    d1 = np.full((per,), -1, np.int32)
+    if hi > lo:
+        d1[:hi - lo] = local_nearest(q_packed[lo:hi])
+    if device is None:
+        device = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    mine = torch.from_numpy(d1).to(device)
+    gathered = torch.empty((world * per,), dtype=torch.int32, device=mine.device)
+    dist.all_gather_into_tensor(gathered, mine, group=group)
+    return gathered[:n].cpu().numpy()
+
+
+def sharded_nearest_index(index, q_packed, device_ordinal=0, group=None):
+    """sharded_nearest on this rank's guidemaker_amd._lib.Index; on the RCCL backend the shard's query and its distances
+    stay on the GPU from the scan (Index.nearest_dev) through the all-gather."""
+    import torch
+    dist = _dist()
+    if dist.get_backend(group) != "nccl":
+        _check_same_candidates(q_packed, "cpu", group)
+        return sharded_nearest(index.nearest, q_packed, device="cpu", group=group)
+    dev = torch.device("cuda", device_ordinal)
+    _check_same_candidates(q_packed, dev, group)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    q_packed = np.ascontiguousarray(q_packed, dtype=np.uint64)
+    n = int(q_packed.shape[0])
+    lo, hi, per = shard_range(n, world, rank)
+    with torch.cuda.device(dev):
+        d1 = torch.full((per,), -1, dtype=torch.int32, device=dev)
+        if hi > lo:
+            d_q = torch.from_numpy(q_packed[lo:hi].view(np.int64)).to(dev)
+            index.nearest_dev(d_q.data_ptr(), hi - lo, d1.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        gathered = torch.empty((world * per,), dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(gathered, d1, group=group)
+        return gathered[:n].cpu().numpy()
+
+
 def _check_same_candidates(q_packed, device, group=None):
     """Every rank must hold the same candidate array: compare (n, xor, sum) fingerprints across the ranks BEFORE the
     shapes of the collective depend on them (ranks working on different frames would hang or mix results)."""

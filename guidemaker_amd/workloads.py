@@ -38,6 +38,11 @@ WORKLOADS = {
     "pao1_leven": dict(fixture="pao1_genome.2bit.gz", records=[6_264_404], gc=0.666, seed=0, pam="TTTV", orientation="5prime",
                        guidelen=23, metric="leven", k=5, editdist=3,
                        label="PAO1-leven: REAL genome P. aeruginosa PAO1 NC_002516 (6 264 404 bp, gc 0.666), TTTV 5prime, L=23, leven, k=5"),
+    # ... and its 1.16 M NGG targets cut at L = 23 under Levenshtein: ten times configs[2]'s pool, real repeats and codon bias
+    # (the displaced-block partition K2P with two levels; profiles/r03/y2_real_genome_leven_k2p_two_levels.txt)
+    "pao1_l23": dict(fixture="pao1_genome.2bit.gz", records=[6_264_404], gc=0.666, seed=0, pam="NGG", orientation="3prime",
+                     guidelen=23, metric="leven", k=5, editdist=3,
+                     label="PAO1-L23: REAL genome P. aeruginosa PAO1 NC_002516 (6 264 404 bp, gc 0.666), NGG 3prime, L=23, leven, k=5"),
     # small variant for tests / smoke
     "tiny": dict(records=[200_000], gc=0.45, seed=9, pam="NGG", orientation="3prime", guidelen=20,
                  metric="hamming", k=10, editdist=2, label="tiny: synthetic 200 kb, NGG 3prime, L=20"),

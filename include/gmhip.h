@@ -118,7 +118,9 @@ int gm_unpack_keys_dev(const void* d_keys, int64_t n_q, int k, void* d_ids, void
 /* Multi-GPU, ONE process, the devices of one node (replaces nmslib's num_threads fan-out of
  * knnQueryBatch, guidemaker/core.py:501-503, by a fan-out over GPUs).  gm_multi_create replicates the packed pool on
  * every listed device (ordinals must be distinct) and creates one RCCL communicator over them (ncclCommInitAll;
- * librccl.so is loaded on first use).  gm_multi_knn_query cuts the candidates into n contiguous, equally long shards,
+ * librccl.so is loaded on first use).  (Test mode, GMHIP_TEST_VIRTUAL_DEVICES=1 in the environment: an ordinal may
+ * occur several times -- n logical shards on one GPU, device-to-device copies in place of the collective -- so that a
+ * one-GPU box executes the fan-out, the shard offsets and the padding of the n > 1 path.)  gm_multi_knn_query cuts the candidates into n contiguous, equally long shards,
  * device g scans shard g (gm_knn_query_dev on its own stream, driven by its own host thread), ONE ncclAllGather
  * exchanges the neighbour lists as 32-bit keys, and the table gathered on the first device is returned: the result
  * is identical to gm_knn_query on one device.  Host pointers; blocking.  (One process per GPU over an existing
@@ -127,6 +129,11 @@ typedef struct gm_multi gm_multi;
 int gm_multi_create(const uint64_t* packed, int64_t n_db, int guidelen, int metric, const int* devices, int n_devices,
                     gm_multi** out);
 int gm_multi_knn_query(gm_multi* m, const uint64_t* q, int64_t n_q, int k, int32_t* ids, int32_t* dists, int32_t* counts);
+/* The nearest-target distance of every candidate, sharded the same way ("for get_control_seqs the random
+ * query batch is split the same way"; replaces the k = 2 knnQueryBatch of guidemaker/core.py:603, the path's largest
+ * query set -- up to 10^4 n random guides): device g scans shard g (gm_nearest_dist_dev), ONE all-gather of the int32
+ * distances.  d1: [n_q], identical to gm_nearest_dist on one device. */
+int gm_multi_nearest_dist(gm_multi* m, const uint64_t* q, int64_t n_q, int32_t* d1);
 int gm_multi_devices(const gm_multi* m);
 int gm_multi_has_comm(const gm_multi* m);          /* 1: an RCCL communicator exists and the all-gather goes through it */
 gm_index* gm_multi_index(gm_multi* m, int i);      /* the i-th device's handle (measurement hooks, gm_set_variant) */
@@ -253,8 +260,13 @@ int gm_set_variant(gm_index* idx, int variant);
  *   candidates (every (n_q / 2048)-th row against the whole pool, once per plan, for n_q >= 32768); 0 = it uses the
  *   independent-base model of the pool's composition alone (A/B, tests).  The result is exact either way;
  *   "pg_msplit": lanes per candidate in K1P's merge (0 = choose, 1, 2, 4);
- *   "pg_debug": timing experiments only (bit 0: the scan skips its list stores; bit 1: the scan accepts no hit at
- *   all -- results are then WRONG);
+ *   "pg_hit": K1P's hit path: 0 = every hit is stored to a hit buffer in HBM and the merge selects (k_hamming_scan_pg);
+ *   2 = every lane keeps its candidate's k best keys in registers, hits reach it through a mailbox in LDS and the scan
+ *   writes k keys per list (k_hamming_scan_pg4); 1 (default) = chosen per cascade level (register lists for k <= 10 on
+ *   >= 400 000 candidates);
+ *   "pg_per": target buckets per K1P workgroup (0 = choose: 16 / pg_sub, all of them with register lists);
+ *   ("pg_debug", a round-3 knob that made the scan skip work for timing and its results WRONG, is gone from the library:
+ *   it answers GM_ERR_ARG; such timings are separate builds, -DGM_PG_TIMING in guidemaker_amd/csrc/Makefile's CXXFLAGS);
  *   "pg_cascade": K1P levels for the rows a pass leaves short: 0 = never (they take the plain / prefix re-scan), 1 =
  *   when the planner's sample says a deeper level pays (default), 2 = whenever >= 64 rows are left (tests);
  *   "pg_layout2": forced layout of the deeper levels, digits as "pg_layout" (tests);

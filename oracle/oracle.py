@@ -58,6 +58,10 @@ def lib():
                                     ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         L.orc_cfd_batch.restype = None
         L.orc_max_threads.restype = ctypes.c_int
+        L.orc_knn_hamming_tuned.argtypes = [ctypes.c_char_p, i64, ctypes.c_char_p, i64, ctypes.c_int, ctypes.c_int,
+                                            i32p, i32p, i32p, ctypes.c_int, ctypes.c_int]
+        L.orc_knn_hamming_tuned.restype = ctypes.c_int
+        L.orc_tuned_isa.restype = ctypes.c_int
         _LIB = L
     return _LIB
 
@@ -123,6 +127,27 @@ def knn(db, q, L, metric, k, threads=0):
     if rc != 0:
         raise ValueError("oracle: bad input (non-ACGT base or bad argument)")
     return ids, dists, counts
+
+
+def knn_tuned(db, q, L, k, threads=0, isa=-1):
+    """The same answer as knn(..., 'hamming', ...) -- exact, (distance, db index) order, RAW nmslib units -- from
+    gm_oracle_tuned.c (bit planes, 16 targets per AVX-512 VPOPCNTDQ instruction / AVX2 / scalar, chosen at run time;
+    isa forces a slower path: 0 scalar, 1 AVX2).  Pinned against knn() by tests/test_oracle.py; used where a WHOLE
+    genome-sized pool is checked (tests/test_gpu_fullsize.py) and as bench.py's cpu_baseline kind "tuned"."""
+    dbb, ndb = _rows(db, L)
+    qb, nq = _rows(q, L)
+    ids = np.empty((nq, k), np.int32)
+    dists = np.empty((nq, k), np.int32)
+    counts = np.empty((nq,), np.int32)
+    p = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+    rc = lib().orc_knn_hamming_tuned(dbb, ndb, qb, nq, L, k, p(ids), p(dists), p(counts), threads, isa)
+    if rc != 0:
+        raise ValueError("oracle: bad input (non-ACGT base or bad argument)")
+    return ids, dists, counts
+
+
+def tuned_isa():
+    return {0: "scalar popcnt", 1: "AVX2", 2: "AVX-512 VPOPCNTDQ"}[lib().orc_tuned_isa()]
 
 
 def dist_matrix(db, q, L, metric):

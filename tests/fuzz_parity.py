@@ -46,6 +46,10 @@ def run(seconds, seed, max_cases=None):
             variant = rng.choice([0, 8, 100 + B, 200 + B, 300 + B, 400 + B, 600 + B, 700 + B, 800 + B, 900 + B])
         idx = _lib.Index(_lib.pack(db, L), L, _lib.METRIC_HAMMING if metric == "hamming" else _lib.METRIC_LEVEN)
         idx.set_variant(variant)
+        hit = -1
+        if metric == "hamming":
+            hit = rng.choice([0, 1, 2])      # K1P's hit path: hit buffer / per level / register lists
+            idx.set_param("pg_hit", hit)
         qp = _lib.pack(q, L)
         ids, dists, counts = idx.knn(qp, k)
         d1 = idx.nearest(qp)
@@ -56,8 +60,14 @@ def run(seconds, seed, max_cases=None):
             od = np.where(od >= 0, od // 2, -1)
         ok = (ids == oi).all() and (dists == od).all() and (counts == oc).all() and (d1 == od[:, 0]).all()
         if not ok:
-            return n_cases, ("MISMATCH: L=%d metric=%s n_db=%d n_q=%d k=%d variant=%d kernel=%s seed=%d case=%d"
-                             % (L, metric, len(db), n_q, k, variant, kern, seed, n_cases))
+            what = [name for name, a, b in (("ids", ids, oi), ("dists", dists, od), ("counts", counts, oc), ("nearest", d1, od[:, 0]))
+                    if not (a == b).all()]
+            rows = np.flatnonzero((ids != oi).any(axis=1) | (dists != od).any(axis=1) | (d1 != od[:, 0]))[:4].tolist()
+            return n_cases, ("MISMATCH: L=%d metric=%s n_db=%d n_q=%d k=%d variant=%d pg_hit=%d kernel=%s seed=%d case=%d: %s differ, rows %s; "
+                             "row %s: got ids %s dists %s nearest %s, want ids %s dists %s"
+                             % (L, metric, len(db), n_q, k, variant, hit, kern, seed, n_cases, what, rows, rows[:1],
+                                ids[rows[:1]].tolist(), dists[rows[:1]].tolist(), d1[rows[:1]].tolist(), oi[rows[:1]].tolist(),
+                                od[rows[:1]].tolist()))
         n_cases += 1
     return n_cases, None
 

@@ -110,6 +110,12 @@ class _OracleIndex:
         ids, dists, counts = orc.knn(self.db, _lib.unpack(q_shard, self.L), self.L, "hamming", kk)
         return ids, np.where(dists >= 0, dists // 2, -1), counts
 
+    def nearest(self, q_shard):
+        self.nearest_calls = getattr(self, "nearest_calls", []) + [int(len(q_shard))]
+        if len(q_shard) == 0:
+            return np.empty((0,), np.int32)
+        return self.knn(q_shard, 1)[1][:, 0].astype(np.int32)
+
 
 def _worker_index(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -149,6 +155,61 @@ def test_sharded_knn_index_and_strong_scaling_world2(tmp_path):
     orc.build()
     world = 2
     mp.spawn(_worker_index, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / ("ok_%d.npy" % r)) for r in range(world))
+
+
+def _worker_controls(rank, world, port, out_dir):
+    """get_control_seqs' random query batch is split over the ranks like the candidates of get_neighbors."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from helpers import targets_frame
+        from guidemaker_amd import core
+        L = 20
+        db = list(dict.fromkeys(random_pool(400, L, seed=21)))
+        index = _OracleIndex(db, L)
+        # (1) the building block: one all-gather of int32 distances, any length (odd, 1, 0)
+        for n in (301, 1, 0, 64):
+            q = _lib.pack((db + random_pool(100, L, seed=22))[:n], L) if n else np.empty((0,), np.uint64)
+            got = distributed.sharded_nearest_index(index, q)
+            want = index.nearest(q)
+            assert got.dtype == np.int32 and got.shape == want.shape and (got == want).all(), n
+        other = _lib.pack(db[:50] if rank == 0 else db[:49], L)
+        with pytest.raises(RuntimeError, match="different candidate sets"):
+            distributed.sharded_nearest_index(index, other)
+        # (2) TargetProcessor.get_control_seqs with shard_candidates: every rank draws the same stream (same seed),
+        # scans only its shard of each draw, and ends with the table the unsharded search gives
+        import types
+        import yaml
+        cfg = {"CONTROL": {"MINIMUM_HMDIST": 6, "CONTROL_SEARCH_MULTIPLE": [10, 100, 1000]}, "NMSLIB": {"ef": 9}}
+        cfg_path = os.path.join(out_dir, "cfg_%d.yaml" % rank)
+        with open(cfg_path, "w") as fh:
+            yaml.safe_dump(cfg, fh)
+        rec = [types.SimpleNamespace(seq="ACGT" * 500 + "GGCC" * 100)]
+        tables = []
+        for shard in (True, False):
+            tp = core.TargetProcessor(targets_frame(db), lsr=0, shard_candidates=shard)
+            tp.nmslib_index = _OracleIndex(db, L)
+            tp._db_targets, tp._guidelen = db, L
+            np.random.seed(7)
+            mn, med, table = tp.get_control_seqs(rec, cfg_path, length=L, n=10)
+            tables.append((mn, med, table, tp.nmslib_index.nearest_calls, tp.ncontrolsearched))
+        (mn_s, med_s, t_s, calls_s, searched_s), (mn_u, med_u, t_u, calls_u, searched_u) = tables
+        assert mn_s == mn_u and med_s == med_u and searched_s == searched_u
+        assert t_s.equals(t_u)
+        # the sharded run scanned half of every draw on this rank, the unsharded one all of it
+        assert calls_s == [c // world for c in calls_u], (calls_s, calls_u)
+        np.save(os.path.join(out_dir, "ok_%d.npy" % rank), np.array([1]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_controls_world2(tmp_path):
+    from oracle import oracle as orc
+    orc.build()
+    world = 2
+    mp.spawn(_worker_controls, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / ("ok_%d.npy" % r)) for r in range(world))
 
 

@@ -7,7 +7,10 @@ is searched against the FULL pool through the C-ABI and
   * the production kernel is asserted (pigeonhole-partitioned scan, 4 blocks, for the Hamming workloads),
   * the whole result is compared with an independent kernel of the library (plain two-phase scan,
     gm_set_variant(8); per-pair Myers kernel, variant 2, for Levenshtein),
-  * >= 512 random rows are compared with the CPU oracle over the full pool (bit-exact ids / distances / counts),
+  * 4 096 random rows are compared with the literal CPU oracle (gm_oracle.c: nmslib's brute_force restated) over the full pool,
+  * EVERY candidate row of S1 (configs[1], the pool the headline metric is quoted on) and of S3, and every fourth row of
+    S4, is compared -- ids, distances, counts, bit for bit -- with the fast exact CPU scan gm_oracle_tuned.c, which
+    tests/test_oracle.py pins to the literal one ("bit-exact k-NN vs reference on an E. coli genome-wide pool"),
   * size-independent properties hold (self is nearest, sortedness, canonical tie order, idempotence).
 
 The pools are built once per session (the 100 Mb genome of S4 takes the longest)."""
@@ -40,6 +43,24 @@ def _oracle_rows(orc, pool, rows):
     if metric == "hamming":
         dists = np.where(dists >= 0, dists // 2, -1)
     return ids, dists, counts
+
+
+def _whole_pool_oracle(orc, pool, ids, dists, counts, stride=1):
+    """Every stride-th candidate row against the fast exact CPU scan over the full pool, in slices of 150 000 rows."""
+    L, k = pool["guidelen"], pool["k"]
+    asc = np.frombuffer(b"ACGT", np.uint8)
+    shifts = (2 * np.arange(L, dtype=np.uint64))[None, :]
+    db = np.ascontiguousarray(asc[((pool["packed_db"][:, None] >> shifts) & np.uint64(3)).astype(np.uint8)])
+    rows_all = np.arange(0, pool["packed_all"].shape[0], stride)
+    checked = 0
+    for lo in range(0, rows_all.size, 150_000):
+        rows = rows_all[lo:lo + 150_000]
+        q = np.ascontiguousarray(asc[((pool["packed_all"][rows][:, None] >> shifts) & np.uint64(3)).astype(np.uint8)])
+        oi, od, oc = orc.knn_tuned(db, q, L, k)
+        od = np.where(od >= 0, od // 2, -1)
+        assert (oc == counts[rows]).all() and (od == dists[rows]).all() and (oi == ids[rows]).all(), (lo, stride)
+        checked += rows.size
+    return checked
 
 
 def _check_properties(pool, ids, dists, counts):
@@ -104,6 +125,9 @@ def test_hamming_workload_full_size(oracle, name):
         rows = np.sort(rng.choice(q.shape[0], size=ORACLE_ROWS, replace=False))
         oi, od, oc = _oracle_rows(oracle, pool, rows)
         assert (oc == counts[rows]).all() and (od == dists[rows]).all() and (oi == ids[rows]).all()
+        # ... and the WHOLE candidate set (S1, S3; every fourth row of S4's 3.1 M) against the fast exact CPU scan
+        n_checked = _whole_pool_oracle(oracle, pool, ids, dists, counts, stride=4 if name == "s4" else 1)
+        assert n_checked == (q.shape[0] + 3) // 4 if name == "s4" else n_checked == q.shape[0]
     finally:
         idx.close()
     if name == "s3":

@@ -297,6 +297,21 @@ def test_controls_fail_fast_estimate():
     # Carsonella sized pool: the nearest target is 6 .. 9 away, nothing to give up on
     d1 = rng.choice([6, 7, 8, 9], p=[0.1, 0.5, 0.35, 0.05], size=100)
     assert core._controls_expected_at(d1, 7, 20, 100_000, 3_814) > 50_000
+    # a GC-rich pool (66 % GC, as PAO1) with controls of the same composition: positions match with
+    # probability ~0.28, not 0.25, lambda grows 2.6 x per step instead of 3 x, and the uniform-base extrapolation over two
+    # steps puts the expected controls an order of magnitude too low -- enough to give up on a reachable minimum
+    L, q = 20, 1.0 - (2 * 0.33 ** 2 + 2 * 0.17 ** 2)
+    from math import comb
+    cdf = [sum(comb(L, i) * q ** i * (1 - q) ** (L - i) for i in range(r + 1)) for r in range(L + 1)]
+    n_db = 1_160_000
+    p_ge = [1.0] + [float(np.exp(-n_db * cdf[s - 1])) for s in range(1, L + 1)]      # P(nearest >= s) under the skewed model
+    pmf = np.array([p_ge[s] - p_ge[s + 1] for s in range(L)] + [p_ge[L]])
+    d1 = np.random.default_rng(5).choice(L + 1, p=pmf / pmf.sum(), size=100_000)
+    true_expect = 1e7 * p_ge[7]
+    uniform = core._controls_expected_at(d1, 7, L, 10_000_000, n_db)
+    measured = core._controls_expected_at(d1, 7, L, 10_000_000, n_db, p_match=1.0 - q)
+    assert abs(np.log(measured / true_expect)) < np.log(3.0), (measured, true_expect)
+    assert uniform < measured / 5.0, (uniform, measured)
     # no data at all / every control an exact hit
     assert core._controls_expected_at(np.zeros(0, int), 7, 20, 1000, 10) == 1000.0
     assert core._controls_expected_at(np.zeros(50, int), 7, 20, 1000, 10) == 0.0
@@ -527,3 +542,23 @@ def test_native_neighbor_columns_equal_the_numpy_path():
         tp.neighbors = core.NeighborMap(q, np.arange(n), ids, dists, counts, db)
         want = core.format_neighbor_columns(tp, q)
         assert got[0] == want[0] and got[1] == want[1]
+
+
+def test_release_library_has_no_wrong_result_knob():
+    """gm_set_param("pg_debug") made the scan skip work (results WRONG) in the shipped library.  It is
+    now a compile-time option of separate timing builds (-DGM_PG_TIMING); the release .so answers GM_ERR_ARG -- checked
+    on the exported function without a GPU (the parameter is rejected before any device call)."""
+    import ctypes
+    from guidemaker_amd import _lib
+    lib = _lib.lib()
+    lib.gm_set_param.restype = ctypes.c_int
+    lib.gm_set_param.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
+    # a null handle is rejected first; with a handle the name is: build one without touching a device is not possible, so
+    # the source is checked as well
+    assert lib.gm_set_param(None, b"pg_debug", 1) != 0
+    import os
+    src = open(os.path.join(os.path.dirname(_lib.LIB_PATH), "csrc", "gm_pigeon.hip")).read()
+    assert 'std::strcmp(name, "pg_debug") == 0)' in src and "return gm_fail(GM_ERR_ARG, \"pg_debug: not in this build" in src
+    assert "tune_debug" not in src
+    hdr = open(os.path.join(os.path.dirname(_lib.LIB_PATH), "csrc", "gm_pg_types.h")).read()
+    assert "debug" not in hdr

@@ -205,3 +205,34 @@ def test_hnsw_baseline_against_the_notebook(oracle):
     _, d = h.query(packed, 3, ef=13, threads=4)
     h.close()
     assert oracle.top2_distance_recall(d, od) < min(got[(16, 13, 13)])
+
+
+@pytest.mark.parametrize("isa", [-1, 1, 0])
+def test_tuned_oracle_equals_the_port(oracle, isa):
+    """gm_oracle_tuned.c (bit planes + AVX-512 VPOPCNTDQ / AVX2 / scalar, chosen at run time) is what the GPU suite checks
+    WHOLE genome-sized pools against; here it is pinned to the literal restatement gm_oracle.c (which the reference's known
+    answers and golden vectors pin): ids, raw distances, counts, every guide length 4 .. 27 (+ 32), k from 1 to beyond the
+    pool size, ragged sizes (not multiples of the 8-query / 16-target blocks), skewed bases, duplicate-rich pools."""
+    orc = oracle
+    rng = np.random.default_rng(40 + isa)
+    asc = np.frombuffer(b"ACGT", np.uint8)
+    cases = [(L, int(rng.integers(1, 1500)), int(rng.integers(1, 300)), int(rng.choice([1, 2, 3, 5, 10, 20, 33, 64])))
+             for L in list(range(4, 28)) + [32]]
+    cases += [(20, 7, 30, 10), (20, 16, 8, 16), (20, 17, 9, 1), (23, 4099, 517, 5)]
+    for L, n_db, n_q, k in cases:
+        p = rng.dirichlet([0.6] * 4) if rng.random() < 0.5 else [0.25] * 4
+        db = asc[rng.choice(4, size=(n_db, L), p=p)]
+        if rng.random() < 0.5 and n_db > 10:      # near-duplicates and exact duplicates: ties by pool index
+            src = rng.integers(0, n_db, size=n_db // 3)
+            db[rng.integers(0, n_db, size=n_db // 3)] = db[src]
+        q = np.concatenate([db[rng.integers(0, n_db, size=n_q // 2 + 1)], asc[rng.choice(4, size=(n_q // 2 + 1, L), p=p)]])
+        want = orc.knn(np.ascontiguousarray(db), np.ascontiguousarray(q), L, "hamming", k)
+        got = orc.knn_tuned(np.ascontiguousarray(db), np.ascontiguousarray(q), L, k, isa=isa)
+        assert all((a == b).all() for a, b in zip(got, want)), (L, n_db, n_q, k, isa)
+    # the golden genome: Carsonella's NGG targets against themselves
+    tg = list(dict.fromkeys(load_carsonella("NGG3p")["target"]))
+    assert len(tg) > 3000
+    want = orc.knn(tg, tg, 20, "hamming", 10)
+    got = orc.knn_tuned(tg, tg, 20, 10, isa=isa)
+    assert all((a == b).all() for a, b in zip(got, want))
+    assert orc.tuned_isa() in ("scalar popcnt", "AVX2", "AVX-512 VPOPCNTDQ")

@@ -130,6 +130,13 @@ def test_pao1_flow_gpu(oracle):
     q_b = np.ascontiguousarray(asc[((q[rows][:, None] >> shifts) & np.uint64(3)).astype(np.uint8)])
     oi, od, oc = oracle.knn(db_b, q_b, L, "hamming", 10)
     assert (oc == counts[rows]).all() and (od // 2 == dists[rows]).all() and (oi == ids[rows]).all()
+    # ... and EVERY row (1.36 10^12 pairs) against the fast exact CPU scan (gm_oracle_tuned.c, pinned to the literal oracle
+    # by tests/test_oracle.py): the real genome is where the cascade, the repeats and the id ties are
+    for lo in range(0, n_q, 150_000):
+        q_s = np.ascontiguousarray(asc[((q[lo:lo + 150_000][:, None] >> shifts) & np.uint64(3)).astype(np.uint8)])
+        ti, td, tc = oracle.knn_tuned(db_b, q_s, L, 10)
+        hi = lo + q_s.shape[0]
+        assert (tc == counts[lo:hi]).all() and (td // 2 == dists[lo:hi]).all() and (ti == ids[lo:hi]).all(), lo
     # reference-level contract: retained = candidates whose 2nd hit is at least editdist away (core.py:512), and the
     # neighbour sequences are the pool's
     keep = np.flatnonzero(dists[:, 1] >= 2)

@@ -110,6 +110,8 @@ def main():
         idx = _lib.Index(db, L, _lib.METRIC_HAMMING)
         try:
             idx.set_param("pg_cut", cut)
+            hit = int(rng.choice([0, 1, 2, 2]))      # hit buffer / chosen per level / register lists on every level
+            idx.set_param("pg_hit", hit)
             if rng.random() < 0.2:      # (default: the planner scans a sample of the candidates when there are >= 32768)
                 idx.set_param("pg_sample", 0)
             casc = ""
@@ -139,7 +141,7 @@ def main():
             idx.close()
         used[name] = used.get(name, 0) + 1
         ok = all((x == y).all() for x, y in zip(got, want))
-        print("case %3d n_db=%d n_q=%d L=%d k=%d skew=%.1f planted=%.2f cut=%d %s%s %s" % (case, len(db), len(q), L, k, skew, planted, cut, name, casc, "ok" if ok else "MISMATCH"), flush=True)
+        print("case %3d n_db=%d n_q=%d L=%d k=%d skew=%.1f planted=%.2f cut=%d hit=%d %s%s %s" % (case, len(db), len(q), L, k, skew, planted, cut, hit, name, casc, "ok" if ok else "MISMATCH"), flush=True)
         if not ok:
             sys.exit(1)
     print("cases", case, used)
