@@ -112,8 +112,8 @@ def roofline_block(workload, pool, kname, kern_s, n_timed, query_ms, launch_pair
     if os.path.exists(COUNTERS_JSON):
         with open(COUNTERS_JSON) as fh:
             reg = json.load(fh).get(workload, {})
-    if reg and not reg.get("kernel", "").startswith(kname.split("(")[0]):
-        reg = {}      # counters of another kernel: do not mix
+    if reg and reg.get("kernel", "").split("<")[0].strip() != kname.split("(")[0]:
+        reg = {}      # counters of another kernel (e.g. the other K1P hit path): do not mix
     # The registered counters describe ONE launch shape: the layout the planner picked on the profiled box (the pairs it
     # evaluated, the positions per block).  A live launch of another shape (another layout, cut-off or cascade split)
     # must not be priced with them: then the line says "stale" and carries the modelled figure only.

@@ -130,6 +130,8 @@ def lib():
     L.gm_set_variant.argtypes = [vp, i32]
     L.gm_set_param.argtypes = [vp, c.c_char_p, i32]
     L.gm_set_param.restype = i32
+    L.gm_last_speculation.argtypes = [vp]
+    L.gm_last_speculation.restype = i32
     L.gm_multi_create.argtypes = [vp, i64, i32, i32, c.POINTER(i32), i32, c.POINTER(vp)]
     L.gm_multi_create.restype = i32
     L.gm_multi_knn_query.argtypes = [vp, vp, i64, i32, vp, vp, vp]
@@ -179,7 +181,7 @@ EXPORTS = [
     "gm_cfd_batch_dev", "gm_last_kernel_ms", "gm_last_query_ms", "gm_last_kernel_name", "gm_last_kernel_pairs",
     "gm_set_variant", "gm_timing_reserve", "gm_timing_read", "gm_pam_count", "gm_pam_emit", "gm_pam_free",
     "gm_pack_keys_dev", "gm_unpack_keys_dev", "gm_site_flags", "gm_seed_duplicated",
-    "gm_last_kernel_evaluated", "gm_last_incomplete", "gm_pigeon_blocks", "gm_pigeon_plan", "gm_pigeon_plan_dist", "gm_pigeon_plan_sample", "gm_levpart_layout", "gm_levpart_info", "gm_pigeon_cascade_info", "gm_pigeon_block_info", "gm_set_param",
+    "gm_last_kernel_evaluated", "gm_last_incomplete", "gm_pigeon_blocks", "gm_pigeon_plan", "gm_pigeon_plan_dist", "gm_pigeon_plan_sample", "gm_levpart_layout", "gm_levpart_info", "gm_pigeon_cascade_info", "gm_pigeon_block_info", "gm_set_param", "gm_last_speculation",
     "gm_multi_create", "gm_multi_knn_query", "gm_multi_nearest_dist", "gm_multi_devices", "gm_multi_has_comm", "gm_multi_index", "gm_multi_free",
 ]
 
@@ -322,6 +324,11 @@ class Index:
         if nq:
             _check(lib().gm_nearest_dist(self._h, _ptr(q), nq, _ptr(d1)))
         return d1
+
+    def last_speculation(self):
+        """0 = the last K1P query waited for the device's row counts, 1 = it ran on the previous query's (validated at the
+        end), 2 = it did and had to run again (gm_last_speculation)."""
+        return int(lib().gm_last_speculation(self._h))
 
     def nearest_dev(self, q_ptr, nq, d1_ptr, stream=None):
         _check(lib().gm_nearest_dist_dev(self._h, ctypes.c_void_p(q_ptr), nq, ctypes.c_void_p(d1_ptr),

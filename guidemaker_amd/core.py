@@ -836,7 +836,7 @@ def neighbor_table(targetprocessor_object) -> pd.DataFrame:
 
 
 def _packed_side_car_put(packed) -> str:
-    token = "gm-packed-%d-%x" % (len(_PACKED_SIDE_CARS), id(packed))
+    token = "gm-packed-%d" % next(_SIDE_CAR_SERIAL)      # (a monotonic serial: an evicted token can never name a later entry)
     while len(_PACKED_SIDE_CARS) >= _SIDE_CAR_LIMIT:
         _PACKED_SIDE_CARS.pop(next(iter(_PACKED_SIDE_CARS)))
     _PACKED_SIDE_CARS[token] = packed
@@ -853,6 +853,7 @@ def packed_side_car(frame):
 _PACKED_SIDE_CARS = {}   # token -> packed 'target' column of a find_targets frame
 _SIDE_CARS = {}          # token -> (packed guides, packed similar guides, L, hash of the guide column, of the similar-guides column)
 _SIDE_CAR_LIMIT = 4      # frames whose side-car is kept (oldest dropped first)
+_SIDE_CAR_SERIAL = itertools.count(1)
 
 
 def _column_hash(col) -> int:
@@ -862,7 +863,7 @@ def _column_hash(col) -> int:
 
 def _side_car_put(side, guides, sim_col) -> str:
     gpk, spk, L = side
-    token = "gm-cfd-%d-%x" % (len(_SIDE_CARS), id(gpk))
+    token = "gm-cfd-%d" % next(_SIDE_CAR_SERIAL)
     while len(_SIDE_CARS) >= _SIDE_CAR_LIMIT:
         _SIDE_CARS.pop(next(iter(_SIDE_CARS)))
     _SIDE_CARS[token] = (gpk, spk, L, _column_hash(guides), _column_hash(sim_col))

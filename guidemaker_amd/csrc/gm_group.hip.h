@@ -27,8 +27,10 @@ __device__ __forceinline__ int pg_key(const uint2 e, int start, int len) {
 // buckets of a 6-base block) -- T = 4 cuts those atomics by a third and the launch from 19 to 13 us on S1 (the scatter: 53 to 34).
 template <int T>
 __global__ __launch_bounds__(1024) void k_cand_hist(const uint2* __restrict__ planes, int64_t n, PgKeyArg K,
-                                                    int* __restrict__ hist, int use_lds, int b_lo, int b_hi) {
+                                                    int* __restrict__ hist, int use_lds, int b_lo, int b_hi,
+                                                    const int* __restrict__ n_dev) {
     extern __shared__ int s_hist[];      // the (block, bucket) entries of blocks [b_lo, b_hi)
+    if (n_dev != nullptr && *n_dev < n) n = *n_dev;      // (speculative follow-ups: the launch was sized for an upper bound)
     const int e_lo = K.ebase[b_lo], n_ent = K.ebase[b_hi] - e_lo;
     if (use_lds) {
         for (int e = threadIdx.x; e < n_ent; e += blockDim.x) s_hist[e] = 0;
@@ -162,8 +164,10 @@ __global__ __launch_bounds__(64) void k_chunk_starts(const int* __restrict__ bto
 // candidates per workgroup (see k_cand_hist); blocks [b_lo, b_hi) per launch (their entries fit the LDS table)
 template <int T>
 __global__ __launch_bounds__(1024) void k_cand_scatter(const uint2* __restrict__ planes, int64_t n, PgKeyArg K,
-                                                       int* __restrict__ cursor, int use_lds, int b_lo, int b_hi) {
+                                                       int* __restrict__ cursor, int use_lds, int b_lo, int b_hi,
+                                                       const int* __restrict__ n_dev) {
     extern __shared__ int s_cnt[];      // [entries of the blocks] counts, then reused as bases
+    if (n_dev != nullptr && *n_dev < n) n = *n_dev;
     const int e_lo = K.ebase[b_lo], n_ent = K.ebase[b_hi] - e_lo;
     int ent[T][GM_PG_MAXB], rank[T][GM_PG_MAXB];
     if (use_lds) {
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(1024) void k_cand_scatter(const uint2* __restrict__
 // chunk ranges of the blocks (also clears the caller's counter words) -> scatter.  K.coff[b] (4^len + 1 ints), K.cperm[b]
 // (n_q), hist / cursor / cbase (K.ebase[B] ints; hist zeroed on entry and left zeroed), btot (GM_PG_MAXB ints).
 inline int gm_group_launch(const uint2* q, int64_t n_q, const PgKeyArg& K, const PgSubArg& nsub, int* hist, int* cursor, int* cbase,
-                           int* btot, int* ctr_words, int ctr_n_words, int* cstart, int* n_chunks, int device, hipStream_t st) {
+                           int* btot, int* ctr_words, int ctr_n_words, int* cstart, int* n_chunks, int device, hipStream_t st, const int* n_dev = nullptr) {
     // tiles of 1024 candidates per workgroup: as many as leave ~128 workgroups
     const int tiles = n_q >= (int64_t)1024 * 128 * 4 ? 4 : (n_q >= (int64_t)1024 * 128 * 2 ? 2 : 1);
     const dim3 cgrid((unsigned)((n_q + 1024 * tiles - 1) / (1024 * tiles)));
@@ -268,13 +272,13 @@ inline int gm_group_launch(const uint2* q, int64_t n_q, const PgKeyArg& K, const
     } while (0)
     for (int i = 0; i < n_runs; ++i) {
         const size_t lds = runs[i].lds ? sizeof(int) * (size_t)(K.ebase[runs[i].hi] - K.ebase[runs[i].lo]) : 0;
-        GM_LAUNCH_T(k_cand_hist, q, n_q, K, hist, runs[i].lds, runs[i].lo, runs[i].hi);
+        GM_LAUNCH_T(k_cand_hist, q, n_q, K, hist, runs[i].lds, runs[i].lo, runs[i].hi, n_dev);
     }
     hipLaunchKernelGGL(k_cand_offsets, dim3(K.B), dim3(1024), 0, st, K, nsub, hist, cursor, cbase, btot);
     hipLaunchKernelGGL(k_chunk_starts, dim3(1), dim3(64), 0, st, btot, K.B, ctr_words, ctr_n_words, cstart, n_chunks);
     for (int i = 0; i < n_runs; ++i) {
         const size_t lds = runs[i].lds ? sizeof(int) * (size_t)(K.ebase[runs[i].hi] - K.ebase[runs[i].lo]) : 0;
-        GM_LAUNCH_T(k_cand_scatter, q, n_q, K, cursor, runs[i].lds, runs[i].lo, runs[i].hi);
+        GM_LAUNCH_T(k_cand_scatter, q, n_q, K, cursor, runs[i].lds, runs[i].lo, runs[i].hi, n_dev);
     }
 #undef GM_LAUNCH_T
     HIP_TRY(hipGetLastError());

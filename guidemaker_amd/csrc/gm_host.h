@@ -31,6 +31,7 @@ struct gm_pg_level_state {
     gm_pigeon* pg = nullptr;
     int64_t plan_nq = -1;
     int plan_k = -1, plan_found = 0, plan_cascade = 0;
+    int plan_parent_radius = -2;      // the parent level's radius the plan was made for
     int pg_flooded_k1 = 0;
     double plan_cost = 1.0;
     gm_pg_layout plan_lay{};
@@ -44,7 +45,6 @@ struct gm_index {
     int64_t n_db = 0;
     int64_t n_db_pad = 0;
     uint2* d_db = nullptr;        // bit planes, padded to a multiple of gm::TILE
-    uint32_t* d_vert = nullptr;   // bit-sliced groups of 32 entries (Hamming, 10 <= L <= 27)
     uint32_t* d_onehot = nullptr; // one-hot bit-sliced table, groups of 64 entries (K1L)
     int64_t n_lk_tiles = 0;
     uint4* d_peq = nullptr;       // Levenshtein: match masks {A,C,G,T} per target (K2L), padded to LV_TILE
@@ -86,6 +86,7 @@ struct gm_index {
     int64_t plan_nq = -1;
     int plan_k = -1, plan_found = 0;
     int plan_cascade = 0;         // the plan sends the rows it leaves short to a deeper K1P level
+    int plan_parent_radius = -2;  // (deeper levels) the parent's radius the plan was made for: another radius, another plan
     double plan_cost = 1.0;       // the planner's cost of the plan (pool scans per candidate, re-scans included)
     std::vector<double> plan_p_short;      // measured share of the candidates whose k-th neighbour lies beyond r (empty: no sample)
     std::vector<uint32_t> plan_cum;        // level 0's sample: targets within d = 0 .. 8 of every sampled candidate (gm_pg_sample)
@@ -96,12 +97,32 @@ struct gm_index {
     int pg_layout_deeper = 0;     // gm_set_param "pg_layout2": forced layout of the deeper levels (tests; digits as "pg_layout")
     // per level of the last query: candidates, radius, pairs evaluated, rows left short (gm_pigeon_cascade_info)
     int64_t casc_nq[GM_PG_LEVELS]{}, casc_pairs[GM_PG_LEVELS]{}, casc_left[GM_PG_LEVELS]{};
+    int64_t casc_pairs_last[GM_PG_LEVELS]{};      // pairs per level of the last query that waited for its counts
     int casc_radius[GM_PG_LEVELS]{};
     int casc_levels = 0;
     // k (+ 1) for which the planner's layout left more than a third of the candidates incomplete on this pool (repeat
     // families flood the hit lists): later queries with that k go straight to the plain scan
     int pg_flooded_k1 = 0;
     gm_pg_layout plan_lay{};
+    // Speculative follow-ups (gmhip.hip run_hamming_pigeon): what the last query of this shape left per cascade level --
+    // rows after the merge, after the prefix re-scan, after the plain re-scan under the guessed bound (-1: that step did
+    // not run) and the prefix fraction it used.  A query of the same shape sizes its follow-up launches from these
+    // instead of waiting for the device's counts, and checks them once at the end.
+    struct {
+        bool valid = false;
+        int64_t n_q = -1;
+        int k = -1;
+        bool nearest = false;
+        int64_t ninc[GM_PG_LEVELS]{}, nleft[GM_PG_LEVELS]{}, nbad[GM_PG_LEVELS]{};
+        double frac[GM_PG_LEVELS]{};
+        int cooldown = 0;      // queries that stay synchronous after a misprediction
+    } spec;
+    int pg_spec = 1;              // gm_set_param "pg_spec": 0 = always wait for the counts (A/B, tests)
+    int spec_last = 0;            // the last K1P query: 0 = waited for its counts, 1 = speculative, 2 = speculative, then run again
+    // speculative run: device counts the kernels launched for an upper bound clamp to (nullptr: the host's n is exact) --
+    // dev_nq: the candidates of the K1P level being run (grouping, merge); dev_rows: the rows of the re-scan being run
+    const int* dev_nq = nullptr;
+    const int* dev_rows = nullptr;
 };
 
 int gm_fail(int code, const std::string& msg);   // records the thread-local error message, returns code
@@ -135,6 +156,7 @@ struct gm_lk_args {
     int32_t *ids = nullptr, *dists = nullptr, *counts = nullptr;
     const uint2* q = nullptr;     // candidate planes (nullptr: idx->d_q)
     int n_tiles = 0;              // scan only the first n_tiles tiles of the pool (0: all) -- K1P's prefix re-scan
+    const int* n_dev = nullptr;   // device count n_q is an upper bound of (speculative follow-ups); nullptr: exact
 };
 #define GM_DECL_LK(LEN) int gm_launch_lk_L##LEN(gm_index* idx, const gm_lk_args* a, hipStream_t st);
 GM_FOR_EACH_LEN(GM_DECL_LK)
@@ -206,6 +228,18 @@ int gm_pg_count_incomplete(gm_index* idx, int64_t n, int need, const int32_t* co
                            int64_t* n_bad, hipStream_t st);      // rows that are not full; synchronises
 int gm_pg_set_param(gm_index* idx, const char* name, int value);
 void gm_pg_free(gm_index* idx);
+// speculative follow-ups (see gm_pigeon.hip): publish the counters to a mailbox without waiting; wait for one later;
+// device address of a row count (which = 0: rows the merge left short, 1: rows the last collect left)
+struct gm_pg_pending {
+    gm_pigeon* pg = nullptr;
+    int slot = 0;
+    unsigned seq = 0;
+};
+bool gm_pg_mailbox_usable(const gm_index* idx);
+int gm_pg_publish_async(gm_index* idx, int slot, hipStream_t st, gm_pg_pending* out);
+int gm_pg_pending_wait(const gm_pg_pending* p, bool after_merge, hipStream_t st, int64_t* n_inc, int64_t* n_bad, int64_t* pairs);
+const int* gm_pg_count_ptr(const gm_index* idx, int which);
+bool gm_pg_hit_path_is_registers(const gm_index* idx);      // the launch being prepared runs k_hamming_scan_pg4
 
 // K2L launchers, one per guide length (gm_inst_lv.hip)
 // options of a Levenshtein scan launch: candidate planes other than idx->d_q; narrow-band first pass (K2B): bounds
@@ -244,8 +278,3 @@ int gm_lp_candidates(gm_index* idx, const uint2* q, int64_t n_q, hipStream_t st)
 int gm_lp_merge(gm_index* idx, int kcap, int64_t n_q, int k, int32_t* ids, int32_t* dists, int32_t* counts, hipStream_t st);
 int gm_lp_scan(gm_index* idx, const uint2* q, int64_t n_q, int k, int kcap, const int32_t* seed_d, const int32_t* seed_c, int seed_k,
                hipStream_t st, const uint32_t** keys_out, int* n_lists);
-
-// K1v (scalar-load bit-sliced kernel), kept for L = 20 as an A/B baseline (gm_inst_bs20.hip)
-int gm_launch_bs20(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t* ids, int32_t* dists,
-                   int32_t* counts, hipStream_t st);
-int gm_build_vertical(gm_index* idx, hipStream_t st);

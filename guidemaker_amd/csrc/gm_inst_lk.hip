@@ -15,10 +15,6 @@ int launch_lk_cfg(gm_index* idx, const gm_lk_args& a, hipStream_t st) {
     size_t lds = 2 * (size_t)gm::lk_tile_bytes(L) + (KCAP == 0 ? sizeof(uint32_t) * (size_t)a.k * gm::WAVE : 0);
     // (Capping the occupancy to make the number of workgroup rounds integral was measured and does not
     // pay: throughput rises with resident waves up to the VGPR/LDS limit -- profiles/r01/NOTES.md.)
-    if (idx->variant >= 40 && idx->variant < 50) {     // A/B knob: cap resident waves per SIMD via LDS padding
-        const size_t pad = (size_t)160 * 1024 / (4 * (size_t)(idx->variant - 40 > 0 ? idx->variant - 40 : 1)) / 512 * 512;
-        if (pad > lds) lds = pad;
-    }
     auto kern = gm::k_hamming_knn_lk<L, KCAP, NEAREST, SEEDED>;
     // (once per instantiation, device and size: the call costs ~5 us of host time, and the re-scan launches sit on the
     // critical path right after a read-back)
@@ -31,7 +27,7 @@ int launch_lk_cfg(gm_index* idx, const gm_lk_args& a, hipStream_t st) {
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)chunks, (unsigned)a.n_seg), dim3(gm::WAVE), lds, st, idx->d_onehot,
                        (int)idx->n_db, a.n_tiles > 0 ? a.n_tiles : (int)idx->n_lk_tiles, a.tiles_per_seg, a.seg_base, a.q ? a.q : idx->d_q, a.n_q, a.k,
-                       a.seed_keys, a.out_keys, a.ids, a.dists, a.counts);
+                       a.seed_keys, a.out_keys, a.ids, a.dists, a.counts, a.n_dev);
     HIP_TRY(hipGetLastError());
     return GM_OK;
 }

@@ -260,8 +260,14 @@ __global__ __launch_bounds__(WAVE, lk_min_waves(L, KCAP)) void k_hamming_knn_lk(
     const uint32_t* __restrict__ table, int n_db, int n_tiles, int tiles_per_seg, int seg_base,
     const uint2* __restrict__ q, int64_t n_q, int k, const uint32_t* __restrict__ seed_keys,
     uint32_t* __restrict__ out_keys, int32_t* __restrict__ ids, int32_t* __restrict__ dists,
-    int32_t* __restrict__ counts) {
+    int32_t* __restrict__ counts, const int* __restrict__ n_dev) {
     extern __shared__ __align__(16) uint32_t smem[];
+    // (speculative follow-ups of K1P: the grid was sized for an upper bound of the rows; the count is on the device)
+    const int64_t n_out = n_q;      // row stride of the segment lists: the host's number
+    if (n_dev != nullptr) {
+        if (*n_dev < n_q) n_q = *n_dev;
+        if ((int64_t)blockIdx.x * WAVE >= n_q) return;
+    }
     constexpr int TILE_W = lk_tile_bytes(L) / 4;         // words per tile
     constexpr int GW = lk_group_words(L);
     uint32_t* tiles = smem;                              // [2][TILE_W]
@@ -328,7 +334,7 @@ __global__ __launch_bounds__(WAVE, lk_min_waves(L, KCAP)) void k_hamming_knn_lk(
     if (valid) {
         if constexpr (KCAP > 0) {
             if (out_keys != nullptr) {
-                uint32_t* out = out_keys + ((int64_t)seg * n_q + qi) * KCAP;
+                uint32_t* out = out_keys + ((int64_t)seg * n_out + qi) * KCAP;
 #pragma unroll
                 for (int s = 0; s < KCAP; ++s) out[s] = list.v[s];
                 return;
@@ -342,9 +348,9 @@ __global__ __launch_bounds__(WAVE, lk_min_waves(L, KCAP)) void k_hamming_knn_lk(
 template <int KCAP>
 __global__ void k_merge_lists(const uint32_t* __restrict__ keys, int n_seg, int64_t n_q, int k,
                               int32_t* __restrict__ ids, int32_t* __restrict__ dists,
-                              int32_t* __restrict__ counts, int nearest) {
+                              int32_t* __restrict__ counts, int nearest, const int* __restrict__ n_dev = nullptr) {
     const int64_t qi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (qi >= n_q) return;
+    if (qi >= n_q || (n_dev != nullptr && qi >= *n_dev)) return;      // (n_q stays the row stride of the lists)
     RegList<KCAP> list;
     list.init(k, nullptr, 0);
     for (int s = 0; s < n_seg; ++s) {
@@ -364,12 +370,12 @@ __global__ void k_merge_lists(const uint32_t* __restrict__ keys, int n_seg, int6
 template <int KCAP, int SPLIT>
 __global__ void k_merge_lists_split(const uint32_t* __restrict__ keys, int n_seg, int64_t n_q, int k,
                                     int32_t* __restrict__ ids, int32_t* __restrict__ dists,
-                                    int32_t* __restrict__ counts, int nearest) {
+                                    int32_t* __restrict__ counts, int nearest, const int* __restrict__ n_dev = nullptr) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int sub = (int)(t % SPLIT);
     const int64_t qi_raw = t / SPLIT;
-    const bool valid = qi_raw < n_q;
-    const int64_t qi = valid ? qi_raw : n_q - 1;
+    const bool valid = qi_raw < n_q && (n_dev == nullptr || qi_raw < *n_dev);      // (n_q stays the row stride of the lists)
+    const int64_t qi = valid ? qi_raw : 0;
     RegList<KCAP> list;
     list.init(k, nullptr, 0);
     for (int s = sub; s < n_seg; s += SPLIT) {

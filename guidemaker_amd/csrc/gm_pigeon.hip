@@ -69,6 +69,7 @@ struct PgMailbox {
     volatile unsigned seq;
     unsigned pad[3];
 };
+constexpr int PG_BOXES = 4;
 
 __global__ __launch_bounds__(64) void k_publish(PgCounters* __restrict__ src, PgMailbox* __restrict__ box, unsigned seq) {
     constexpr int W = (int)(sizeof(PgCounters) / sizeof(int));
@@ -229,7 +230,8 @@ __global__ __launch_bounds__(256) void k_stride_rows(int32_t* __restrict__ inc, 
 }
 
 __global__ __launch_bounds__(256) void k_gather_rows(const uint2* __restrict__ q, const int32_t* __restrict__ inc, int64_t n,
-                                                     uint2* __restrict__ q2) {
+                                                     uint2* __restrict__ q2, const int* __restrict__ n_dev) {
+    if (n_dev != nullptr && *n_dev < n) n = *n_dev;      // (speculative follow-ups: the launch was sized for an upper bound)
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j < n) q2[j] = q[(uint32_t)inc[j] & ~gm::PG_INC_OVERFLOW];
 }
@@ -237,7 +239,9 @@ __global__ __launch_bounds__(256) void k_gather_rows(const uint2* __restrict__ q
 __global__ __launch_bounds__(256) void k_scatter_rows(const int32_t* __restrict__ inc, int64_t n, int k,
                                                       const int32_t* __restrict__ ids2, const int32_t* __restrict__ dists2,
                                                       const int32_t* __restrict__ counts2, int32_t* __restrict__ ids,
-                                                      int32_t* __restrict__ dists, int32_t* __restrict__ counts) {
+                                                      int32_t* __restrict__ dists, int32_t* __restrict__ counts,
+                                                      const int* __restrict__ n_dev) {
+    if (n_dev != nullptr && *n_dev < n) n = *n_dev;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * k) return;
     const int64_t j = t / k;
@@ -253,7 +257,9 @@ __global__ __launch_bounds__(256) void k_scatter_rows(const int32_t* __restrict_
 // segment lists: KCAP slots, keys + 1 ascending, unused leading slots 0, empty slots 0xffffffff
 __global__ __launch_bounds__(256) void k_partial_keys(const int32_t* __restrict__ inc, int64_t n, int kcap, int k, int nearest,
                                                       const int32_t* __restrict__ ids, const int32_t* __restrict__ dists,
-                                                      const int32_t* __restrict__ counts, uint32_t* __restrict__ out) {
+                                                      const int32_t* __restrict__ counts, uint32_t* __restrict__ out,
+                                                      const int* __restrict__ n_dev) {
+    if (n_dev != nullptr && *n_dev < n) n = *n_dev;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * kcap) return;
     const int64_t j = t / kcap;
@@ -275,7 +281,9 @@ __global__ __launch_bounds__(256) void k_partial_keys(const int32_t* __restrict_
 // compacted into out (order irrelevant), counted in *n_out
 __global__ __launch_bounds__(256) void k_collect_bad(const int32_t* __restrict__ inc, int64_t n, int need,
                                                      const int32_t* __restrict__ counts2, const int32_t* __restrict__ d1,
-                                                     int32_t* __restrict__ out, int* __restrict__ n_out) {
+                                                     int32_t* __restrict__ out, int* __restrict__ n_out,
+                                                     const int* __restrict__ n_dev) {
+    if (n_dev != nullptr && *n_dev < n) n = *n_dev;
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool take = j < n && (counts2 != nullptr ? counts2[j] < need : d1[j] < 0);
     gm::gm_block_append(take, take ? (int32_t)((uint32_t)inc[j] & ~gm::PG_INC_OVERFLOW) : 0, out, n_out);
@@ -462,9 +470,11 @@ struct gm_pigeon {
     gm_pg_chunk* chunks = nullptr;
     int64_t chunks_cap = 0;
     PgCounters* ctr = nullptr;
-    PgMailbox* box = nullptr;         // pinned, host-coherent mailbox of the per-query read-backs (k_publish)
-    PgMailbox* box_dev = nullptr;     // ... its device address
+    PgMailbox* box = nullptr;         // pinned, host-coherent mailboxes of the per-query read-backs (k_publish): [PG_BOXES];
+                                      // slot 0 = the synchronous read-backs, 1 .. = the speculative run's (one per kind)
+    PgMailbox* box_dev = nullptr;     // ... their device address
     unsigned box_seq = 0;
+    PgCounters last_c{};              // host copy of the counters as of the last completed after-merge read-back
     bool box_off = false;             // the mailbox word once failed to arrive while the stream ran: plain copies from then on
     int64_t grid = 0;
     uint32_t* lists = nullptr;    // hit lists (gm_pg_blocks::loff / lcap)
@@ -499,9 +509,9 @@ int pg_ensure_counters(gm_pigeon* pg) {
         if (hipMemset(pg->ctr, 0, sizeof(PgCounters)) != hipSuccess) return gm_fail(GM_ERR_DEVICE, "hipMemset(K1P counters) failed");
     }
     if (!pg->box) {
-        if (hipHostMalloc(reinterpret_cast<void**>(&pg->box), sizeof(PgMailbox), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
+        if (hipHostMalloc(reinterpret_cast<void**>(&pg->box), sizeof(PgMailbox) * PG_BOXES, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
             return gm_fail(GM_ERR_ALLOC, "hipHostMalloc(K1P mailbox) failed");
-        std::memset(pg->box, 0, sizeof(PgMailbox));
+        std::memset(pg->box, 0, sizeof(PgMailbox) * PG_BOXES);
         if (hipHostGetDevicePointer(reinterpret_cast<void**>(&pg->box_dev), pg->box, 0) != hipSuccess)
             return gm_fail(GM_ERR_ALLOC, "hipHostGetDevicePointer(K1P mailbox) failed");
     }
@@ -753,7 +763,10 @@ int gm_pg_plan(int64_t n_db, int64_t n_q, int L, int k, double p_match, gm_pg_la
         double beyond[GM_PG_SAMPLE_BINS + 1] = {0}, hsum[GM_PG_SAMPLE_BINS] = {0};
         for (int i = 0; i < smp->n; ++i) {
             const uint32_t* c = smp->cum + (size_t)i * GM_PG_SAMPLE_BINS;
-            int kth = GM_PG_SAMPLE_BINS;      // (beyond the histogram)
+            // (beyond the histogram: such a row counts as short at EVERY radius the histogram does not reach -- beyond[BINS] is
+            // the share carried, as an upper bound, for r >= BINS; with kth = BINS it stayed 0 and a radius >= 9 was priced as
+            // leaving no row short: ADVICE r03)
+            int kth = GM_PG_SAMPLE_BINS + 1;
             for (int d = 0; d < GM_PG_SAMPLE_BINS; ++d)
                 if (c[d] >= (uint32_t)smp->k) {
                     kth = d;
@@ -1294,7 +1307,7 @@ int gm_pg_candidates(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
     PgSubArg nsub{};
     for (int b = 0; b < pg->B; ++b) nsub.n[b] = pg->nsub[b];
     if ((rc = gm_group_launch(idx->d_q, n_q, K, nsub, pg->hist, pg->cursor, pg->cbase, pg->nch, reinterpret_cast<int*>(pg->ctr),
-                              (int)(sizeof(PgCounters) / sizeof(int)), pg->ctr->cstart, &pg->ctr->n_chunks, idx->device, st)))
+                              (int)(sizeof(PgCounters) / sizeof(int)), pg->ctr->cstart, &pg->ctr->n_chunks, idx->device, st, idx->dev_nq)))
         return rc;
     hipLaunchKernelGGL(k_fill_chunks, grid_for((int64_t)A.n_entries * A.smax), dim3(256), 0, st, A, pg->cbase, pg->chunks, pg->ctr);
     HIP_TRY(hipGetLastError());
@@ -1503,11 +1516,11 @@ int gm_pg_merge(gm_index* idx, int kcap, int64_t n_q, int k, int32_t* ids, int32
         if (pg->hit_reg)                                                                                                          \
             hipLaunchKernelGGL((gm::k_merge_pg3<KC, SP>), grid, block, 0, st, pg->keys3, pg->blocks.n_lists, n_q, k, ids, dists,   \
                                counts, nr, pg->inc, n_inc, &pg->ctr->n_over, pg->ctr->chist,                                      \
-                               pg->cut_id != 0xffffffffu ? pg->cflag : nullptr);                                                  \
+                               pg->cut_id != 0xffffffffu ? pg->cflag : nullptr, idx->dev_nq);                                     \
         else                                                                                                                      \
             hipLaunchKernelGGL((gm::k_merge_hits<KC, SP>), grid, block, 0, st, pg->blocks, pg->lists, n_q, k, ids, dists, counts,  \
                                nr, pg->inc, n_inc, &pg->ctr->n_over, pg->ctr->chist,                                              \
-                               pg->cut_id != 0xffffffffu ? pg->cflag : nullptr);                                                  \
+                               pg->cut_id != 0xffffffffu ? pg->cflag : nullptr, idx->dev_nq);                                     \
     } while (0)
 #define GM_MERGE_KC(KC) do { if (split == 1) GM_MERGE(KC, 1); else if (split == 2) GM_MERGE(KC, 2); else GM_MERGE(KC, 4); } while (0)
     switch (kcap) {
@@ -1572,6 +1585,7 @@ int gm_pg_incomplete(gm_index* idx, int64_t* n_inc, int64_t* pairs_evaluated, hi
     int rc;
     if ((rc = pg_read_counters(pg, st))) return rc;
     const PgCounters h = pg->box->c;
+    pg->last_c = h;
     *n_inc = h.n_inc;
     if (pg->cut_id != 0xffffffffu && pg->tune_cut == 0 && pg->cap_nq > 0 &&
         (double)h.n_inc > (0.01 + pg->expect_short) * (double)pg->cap_nq)
@@ -1580,6 +1594,80 @@ int gm_pg_incomplete(gm_index* idx, int64_t* n_inc, int64_t* pairs_evaluated, hi
     for (int b = 0; b < GM_PG_MAXB; ++b) {
         pg->last_bpairs[b] = (int64_t)h.bpairs[b];
         *pairs_evaluated += (int64_t)h.bpairs[b];
+    }
+    return GM_OK;
+}
+
+// ---- speculative follow-ups (gmhip.hip run_hamming_pigeon): no host round trip inside a steady-state query ----
+// The rows a level leaves short are counted on the device; the host used to wait for that count (mailbox) to size
+// the follow-up launches.  A query of the same shape as the handle's last one instead runs every follow-up on a
+// PREDICTED upper bound `cap` of the number of rows (the last actual count + an eighth + 1024): grids and buffers are
+// sized for cap, and every row-indexed kernel behind it clamps n to the device's count (gm_index::dev_rows / dev_nq: a
+// workgroup beyond the count exits at once; measured: padding the list with duplicate rows instead cost more than the
+// read-backs it saved -- +9 % pairs on PAO1's second level).
+// The counters still go to a mailbox (one per read-back kind, k_publish); the host looks at them ONCE, after the whole
+// query is enqueued: a level that left more rows than its cap makes the query run again the synchronous way.
+// device address of a row count the follow-up kernels clamp their launch to: 0 = rows the merge left short (n_inc),
+// 1 = rows the last collect left (n_bad as of the last publish, which re-zeroes the live counter)
+const int* gm_pg_count_ptr(const gm_index* idx, int which) {
+    const gm_pigeon* pg = idx->pg;
+    return which == 0 ? &pg->ctr->n_inc : &pg->ctr->n_bad_pub;
+}
+
+bool gm_pg_hit_path_is_registers(const gm_index* idx) { return idx->pg && idx->pg->hit_reg; }
+
+bool gm_pg_mailbox_usable(const gm_index* idx) {
+    static const bool polled = [] {
+        const char* e = std::getenv("GM_PG_MAILBOX");
+        return !(e && e[0] == '0');
+    }();
+    return polled && idx->pg && !idx->pg->box_off && idx->pg->box != nullptr;
+}
+
+// the counters as of this point of the stream go to mailbox `slot` (1 .. PG_BOXES - 1); no wait
+int gm_pg_publish_async(gm_index* idx, int slot, hipStream_t st, gm_pg_pending* out) {
+    gm_pigeon* pg = idx->pg;
+    if (slot < 1 || slot >= PG_BOXES) return gm_fail(GM_ERR_ARG, "gm_pg_publish_async: bad slot");
+    const unsigned seq = ++pg->box_seq;
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, pg->ctr, pg->box_dev + slot, seq);
+    HIP_TRY(hipGetLastError());
+    out->pg = pg;
+    out->slot = slot;
+    out->seq = seq;
+    return GM_OK;
+}
+
+// waits for a publish; n_inc / n_bad / pairs as of its point of the stream.  after_merge: the counters become the
+// handle's "last read-back" (prefix fraction, per-block pairs, cut-off bookkeeping), as gm_pg_incomplete does
+int gm_pg_pending_wait(const gm_pg_pending* p, bool after_merge, hipStream_t st, int64_t* n_inc, int64_t* n_bad, int64_t* pairs) {
+    gm_pigeon* pg = p->pg;
+    PgMailbox* box = pg->box + p->slot;
+    for (unsigned spins = 0; box->seq != p->seq; ++spins) {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+        if ((spins & 0x3fff) == 0x3fff) {
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipErrorNotReady) continue;
+            if (q != hipSuccess) return gm_fail(GM_ERR_DEVICE, std::string("K1P read-back: ") + hipGetErrorString(q));
+            std::atomic_thread_fence(std::memory_order_acquire);
+            if (box->seq == p->seq) break;
+            pg->box_off = true;      // the stream has drained and the word has not arrived: no mailbox on this platform
+            return gm_fail(GM_ERR_DEVICE, "K1P mailbox word did not arrive");
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    const PgCounters h = box->c;
+    *n_inc = h.n_inc;
+    *n_bad = h.n_bad;
+    *pairs = 0;
+    for (int b = 0; b < GM_PG_MAXB; ++b) *pairs += (int64_t)h.bpairs[b];
+    if (after_merge) {
+        pg->last_c = h;
+        for (int b = 0; b < GM_PG_MAXB; ++b) pg->last_bpairs[b] = (int64_t)h.bpairs[b];
+        if (pg->cut_id != 0xffffffffu && pg->tune_cut == 0 && pg->cap_nq > 0 &&
+            (double)h.n_inc > (0.01 + pg->expect_short) * (double)pg->cap_nq)
+            pg->cut_dropped = true;
     }
     return GM_OK;
 }
@@ -1612,7 +1700,7 @@ int gm_pg_gather(gm_index* idx, int64_t n_inc, int k, bool nearest, const uint2*
     if ((rc = ensure(&pg->ids2, &pg->ids2_cap, n_inc * k, "compact ids"))) return rc;
     if ((rc = ensure(&pg->dists2, &pg->dists2_cap, n_inc * k, "compact distances"))) return rc;
     if ((rc = ensure(&pg->counts2, &pg->counts2_cap, n_inc, "compact counts"))) return rc;
-    hipLaunchKernelGGL(k_gather_rows, grid_for(n_inc), dim3(256), 0, st, idx->d_q, pg->inc, n_inc, pg->q2);
+    hipLaunchKernelGGL(k_gather_rows, grid_for(n_inc), dim3(256), 0, st, idx->d_q, pg->inc, n_inc, pg->q2, idx->dev_rows);
     HIP_TRY(hipGetLastError());
     *q2 = pg->q2;
     *ids2 = nearest ? nullptr : pg->ids2;
@@ -1632,7 +1720,7 @@ double gm_pg_prefix_fraction(const gm_index* idx, int k) {
     if (!pg || pg->B < 2 || !pg->tune_prefix || !pg->box) return 1.0;
     // (under the id cut-off a short row that took it does NOT know all its neighbours at distance r: the merge files it
     // with the overflowed rows -- n_over -- and only the others, which kept all their hits, count here)
-    const PgCounters& h = pg->box->c;      // as read back by gm_pg_incomplete
+    const PgCounters& h = pg->last_c;      // as read back by gm_pg_incomplete (or by the last validated speculative run)
     const double pm = pg->p_match >= 0.25 ? pg->p_match : 0.25;
     const int r = gm_pg_radius(idx);
     const double within = (double)idx->n_db * tail_within(idx->L, r, pm);
@@ -1675,7 +1763,7 @@ int gm_pg_partial_keys(gm_index* idx, int64_t n_inc, int kcap, int k, bool neare
                        const int32_t* counts, uint32_t* out_keys, hipStream_t st) {
     gm_pigeon* pg = idx->pg;
     hipLaunchKernelGGL(k_partial_keys, grid_for(n_inc * kcap), dim3(256), 0, st, pg->inc, n_inc, kcap, k, nearest ? 1 : 0, ids,
-                       dists, counts, out_keys);
+                       dists, counts, out_keys, idx->dev_rows);
     HIP_TRY(hipGetLastError());
     return GM_OK;
 }
@@ -1689,10 +1777,10 @@ int gm_pg_merge_prefix(gm_index* idx, int kcap, const uint32_t* keys, int n_list
     int32_t* ids2 = nearest ? nullptr : pg->ids2;
     int32_t* counts2 = nearest ? nullptr : pg->counts2;
     switch (kcap) {
-        case 1: hipLaunchKernelGGL((gm::k_merge_prefix<1, SP>), grid, block, 0, st, keys, n_lists, pg->inc, n_inc, k, ids2, pg->dists2, counts2, nr); break;
-        case 5: hipLaunchKernelGGL((gm::k_merge_prefix<5, SP>), grid, block, 0, st, keys, n_lists, pg->inc, n_inc, k, ids2, pg->dists2, counts2, nr); break;
-        case 10: hipLaunchKernelGGL((gm::k_merge_prefix<10, SP>), grid, block, 0, st, keys, n_lists, pg->inc, n_inc, k, ids2, pg->dists2, counts2, nr); break;
-        default: hipLaunchKernelGGL((gm::k_merge_prefix<20, SP>), grid, block, 0, st, keys, n_lists, pg->inc, n_inc, k, ids2, pg->dists2, counts2, nr); break;
+        case 1: hipLaunchKernelGGL((gm::k_merge_prefix<1, SP>), grid, block, 0, st, keys, n_lists, pg->inc, n_inc, k, ids2, pg->dists2, counts2, nr, idx->dev_rows); break;
+        case 5: hipLaunchKernelGGL((gm::k_merge_prefix<5, SP>), grid, block, 0, st, keys, n_lists, pg->inc, n_inc, k, ids2, pg->dists2, counts2, nr, idx->dev_rows); break;
+        case 10: hipLaunchKernelGGL((gm::k_merge_prefix<10, SP>), grid, block, 0, st, keys, n_lists, pg->inc, n_inc, k, ids2, pg->dists2, counts2, nr, idx->dev_rows); break;
+        default: hipLaunchKernelGGL((gm::k_merge_prefix<20, SP>), grid, block, 0, st, keys, n_lists, pg->inc, n_inc, k, ids2, pg->dists2, counts2, nr, idx->dev_rows); break;
     }
     HIP_TRY(hipGetLastError());
     return GM_OK;
@@ -1706,7 +1794,7 @@ int gm_pg_collect_bad(gm_index* idx, int64_t n_inc, int need, bool nearest, hipS
     if ((rc = ensure(&pg->inc_b, &pg->inc_b_cap, pg->inc_cap > n_inc ? pg->inc_cap : n_inc, "incomplete rows (second list)")))
         return rc;
     hipLaunchKernelGGL(k_collect_bad, grid_for(n_inc), dim3(256), 0, st, pg->inc, n_inc, need, nearest ? nullptr : pg->counts2,
-                       nearest ? pg->dists2 : nullptr, pg->inc_b, &pg->ctr->n_bad);
+                       nearest ? pg->dists2 : nullptr, pg->inc_b, &pg->ctr->n_bad, idx->dev_rows);
     HIP_TRY(hipGetLastError());
     std::swap(pg->inc, pg->inc_b);
     std::swap(pg->inc_cap, pg->inc_b_cap);
@@ -1793,7 +1881,7 @@ int gm_pg_scatter(gm_index* idx, int64_t n_inc, int k, bool nearest, int32_t* id
     gm_pigeon* pg = idx->pg;
     hipLaunchKernelGGL(k_scatter_rows, grid_for(n_inc * k), dim3(256), 0, st, pg->inc, n_inc, k,
                        nearest ? nullptr : pg->ids2, pg->dists2, nearest ? nullptr : pg->counts2, nearest ? nullptr : ids,
-                       dists, nearest ? nullptr : counts);
+                       dists, nearest ? nullptr : counts, idx->dev_rows);
     HIP_TRY(hipGetLastError());
     return GM_OK;
 }

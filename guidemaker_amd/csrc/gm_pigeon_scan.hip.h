@@ -686,12 +686,13 @@ template <int KCAP, int SPLIT>
 __global__ void k_merge_hits(gm_pg_blocks P, const uint32_t* __restrict__ lists, int64_t n_q, int k,
                              int32_t* __restrict__ ids, int32_t* __restrict__ dists, int32_t* __restrict__ counts,
                              int nearest, int32_t* __restrict__ inc, int* __restrict__ inc_count,
-                             int* __restrict__ over_count, int* __restrict__ chist, const uint8_t* __restrict__ cflag) {
+                             int* __restrict__ over_count, int* __restrict__ chist, const uint8_t* __restrict__ cflag, const int* __restrict__ n_dev) {
+    if (n_dev != nullptr && *n_dev < n_q) n_q = *n_dev;      // (speculative follow-ups: launched for an upper bound)
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int sub = (int)(t % SPLIT);
     const int64_t qi_raw = t / SPLIT;
     const bool valid = qi_raw < n_q;
-    const int64_t qi = valid ? qi_raw : n_q - 1;      // (whole groups stay in the shuffles)
+    const int64_t qi = valid ? qi_raw : 0;      // (whole groups stay in the shuffles)
     RegList<KCAP> list;
     list.init(k, nullptr, 0);
     int overflow = 0;
@@ -767,29 +768,45 @@ template <int KCAP, int SPLIT>
 __global__ void k_merge_pg3(const uint32_t* __restrict__ keys, int n_lists, int64_t n_q, int k,
                             int32_t* __restrict__ ids, int32_t* __restrict__ dists, int32_t* __restrict__ counts,
                             int nearest, int32_t* __restrict__ inc, int* __restrict__ inc_count,
-                            int* __restrict__ over_count, int* __restrict__ chist, const uint8_t* __restrict__ cflag) {
+                            int* __restrict__ over_count, int* __restrict__ chist, const uint8_t* __restrict__ cflag, const int* __restrict__ n_dev) {
+    const int64_t n_stride = n_q;      // row stride of the raw lists: the host's number
+    if (n_dev != nullptr && *n_dev < n_q) n_q = *n_dev;      // (speculative follow-ups: launched for an upper bound)
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int sub = (int)(t % SPLIT);
     const int64_t qi_raw = t / SPLIT;
     const bool valid = qi_raw < n_q;
-    const int64_t qi = valid ? qi_raw : n_q - 1;      // (whole groups stay in the shuffles)
+    const int64_t qi = valid ? qi_raw : 0;      // (whole groups stay in the shuffles)
+    // A raw list IS the image of a sorted register list (unused leading slots 0, keys + 1 ascending, empty slots
+    // 0xffffffff): a lane takes its first list over as it stands and inserts only the others' keys -- ascending, so a
+    // list is done at its first key that cannot beat the current k-th (with one list per block and SPLIT >= the number of
+    // blocks no insert happens before the shuffle tree: PAO1's first-level merge 255 -> see profiles/r04/NOTES.md).
     RegList<KCAP> list;
     list.init(k, nullptr, 0);
-    for (int l = sub; l < n_lists; l += SPLIT) {
-        const uint32_t* __restrict__ in = keys + ((int64_t)l * n_q + qi) * KCAP;
+    if (sub < n_lists) {
+        const uint32_t* __restrict__ in = keys + ((int64_t)sub * n_stride + qi) * KCAP;
+#pragma unroll
+        for (int i = 0; i < KCAP; ++i) list.v[i] = in[i];
+    }
+    for (int l = sub + SPLIT; l < n_lists; l += SPLIT) {
+        const uint32_t* __restrict__ in = keys + ((int64_t)l * n_stride + qi) * KCAP;
         uint32_t v[KCAP];
 #pragma unroll
         for (int i = 0; i < KCAP; ++i) v[i] = in[i];
+        bool more = true;
 #pragma unroll
-        for (int i = 0; i < KCAP; ++i)
-            if (v[i] != 0u && v[i] < list.v[KCAP - 1]) list.insert_unique(v[i] - 1u);
+        for (int i = 0; i < KCAP; ++i) {
+            more = more && (v[i] == 0u || v[i] < list.v[KCAP - 1]);
+            if (more && v[i] != 0u) list.insert_unique(v[i] - 1u);
+        }
     }
 #pragma unroll
     for (int off = SPLIT / 2; off >= 1; off >>= 1) {
+        bool more = true;      // (the partner's keys ascend: it is done at its first key that cannot beat the k-th)
 #pragma unroll
         for (int i = 0; i < KCAP; ++i) {
             const uint32_t v = __shfl_down(list.v[i], off, SPLIT);
-            if (sub < off && v != 0u && v < list.v[KCAP - 1]) list.insert_unique(v - 1u);
+            more = more && (v == 0u || v < list.v[KCAP - 1]);
+            if (sub < off && more && v != 0u) list.insert_unique(v - 1u);
         }
     }
     __shared__ int s_hist[24], s_over;
@@ -829,16 +846,18 @@ __global__ void k_merge_pg3(const uint32_t* __restrict__ keys, int n_lists, int6
 template <int KCAP, int SPLIT>
 __global__ void k_merge_prefix(const uint32_t* __restrict__ keys, int n_lists, const int32_t* __restrict__ inc, int64_t n,
                                int k, int32_t* __restrict__ ids, int32_t* __restrict__ dists, int32_t* __restrict__ counts,
-                               int nearest) {
+                               int nearest, const int* __restrict__ n_dev) {
+    const int64_t n_stride = n;      // row stride of the raw lists: the host's number
+    if (n_dev != nullptr && *n_dev < n) n = *n_dev;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int sub = (int)(t % SPLIT);
     const int64_t row_raw = t / SPLIT;
     const bool valid = row_raw < n;
-    const int64_t row = valid ? row_raw : n - 1;
+    const int64_t row = valid ? row_raw : 0;
     RegList<KCAP> list;
     list.init(k, nullptr, 0);
     for (int s = sub; s < n_lists; s += SPLIT) {
-        const uint32_t* in = keys + ((int64_t)s * n + row) * KCAP;
+        const uint32_t* in = keys + ((int64_t)s * n_stride + row) * KCAP;
 #pragma unroll
         for (int i = 0; i < KCAP; ++i) {
             const uint32_t v = in[i];

@@ -115,16 +115,16 @@ int ensure_u32(uint32_t** buf, int64_t* cap, int64_t need) {
 }
 
 int launch_merge(int kcap, const uint32_t* keys, int n_seg, int64_t n_q, int k, int32_t* ids, int32_t* dists,
-                 int32_t* counts, bool nearest, hipStream_t st) {
+                 int32_t* counts, bool nearest, hipStream_t st, const int* n_dev = nullptr) {
     const int nr = nearest ? 1 : 0;
     if (n_seg >= 128 && n_q <= 2048) {      // a handful of candidates, hundreds of lists: a whole wave per candidate
         constexpr int SP = 64;
         const dim3 grid((unsigned)((n_q * SP + 255) / 256)), block(256);
         switch (kcap) {
-            case 1: hipLaunchKernelGGL((gm::k_merge_lists_split<1, SP>), grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
-            case 5: hipLaunchKernelGGL((gm::k_merge_lists_split<5, SP>), grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
-            case 10: hipLaunchKernelGGL((gm::k_merge_lists_split<10, SP>), grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
-            default: hipLaunchKernelGGL((gm::k_merge_lists_split<20, SP>), grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
+            case 1: hipLaunchKernelGGL((gm::k_merge_lists_split<1, SP>), grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr, n_dev); break;
+            case 5: hipLaunchKernelGGL((gm::k_merge_lists_split<5, SP>), grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr, n_dev); break;
+            case 10: hipLaunchKernelGGL((gm::k_merge_lists_split<10, SP>), grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr, n_dev); break;
+            default: hipLaunchKernelGGL((gm::k_merge_lists_split<20, SP>), grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr, n_dev); break;
         }
         HIP_TRY(hipGetLastError());
         return GM_OK;
@@ -133,20 +133,20 @@ int launch_merge(int kcap, const uint32_t* keys, int n_seg, int64_t n_q, int k, 
         constexpr int SP = 16;
         const dim3 grid((unsigned)((n_q * SP + 255) / 256)), block(256);
         switch (kcap) {
-            case 1: hipLaunchKernelGGL((gm::k_merge_lists_split<1, SP>), grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
-            case 5: hipLaunchKernelGGL((gm::k_merge_lists_split<5, SP>), grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
-            case 10: hipLaunchKernelGGL((gm::k_merge_lists_split<10, SP>), grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
-            default: hipLaunchKernelGGL((gm::k_merge_lists_split<20, SP>), grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
+            case 1: hipLaunchKernelGGL((gm::k_merge_lists_split<1, SP>), grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr, n_dev); break;
+            case 5: hipLaunchKernelGGL((gm::k_merge_lists_split<5, SP>), grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr, n_dev); break;
+            case 10: hipLaunchKernelGGL((gm::k_merge_lists_split<10, SP>), grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr, n_dev); break;
+            default: hipLaunchKernelGGL((gm::k_merge_lists_split<20, SP>), grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr, n_dev); break;
         }
         HIP_TRY(hipGetLastError());
         return GM_OK;
     }
     const dim3 grid((unsigned)((n_q + 255) / 256)), block(256);
     switch (kcap) {
-        case 1: hipLaunchKernelGGL(gm::k_merge_lists<1>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
-        case 5: hipLaunchKernelGGL(gm::k_merge_lists<5>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
-        case 10: hipLaunchKernelGGL(gm::k_merge_lists<10>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
-        default: hipLaunchKernelGGL(gm::k_merge_lists<20>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr); break;
+        case 1: hipLaunchKernelGGL(gm::k_merge_lists<1>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr, n_dev); break;
+        case 5: hipLaunchKernelGGL(gm::k_merge_lists<5>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr, n_dev); break;
+        case 10: hipLaunchKernelGGL(gm::k_merge_lists<10>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr, n_dev); break;
+        default: hipLaunchKernelGGL(gm::k_merge_lists<20>, grid, block, 0, st, keys, n_seg, n_q, k, ids, dists, counts, nr, n_dev); break;
     }
     HIP_TRY(hipGetLastError());
     return GM_OK;
@@ -168,6 +168,7 @@ int run_hamming_lookup(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
                        int guess_thr = 0) {
     gm_lk_args a;
     a.q = qplanes;
+    a.n_dev = qplanes != nullptr ? idx->dev_rows : nullptr;      // (K1P's re-scan of compact rows in a speculative run)
     a.kcap = nearest ? 1 : (idx->variant == 7 || k > 20 ? 0 : (k <= 5 ? 5 : (k <= 10 ? 10 : 20)));
     a.n_q = n_q;
     a.k = nearest ? 1 : k;
@@ -192,10 +193,9 @@ int run_hamming_lookup(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
     const int64_t fill = (int64_t)idx->n_simd * 8 / (chunks > 0 ? chunks : 1);
     if (fill > seg_cap) seg_cap = fill < 512 ? fill : 512;
     if (n_seg > seg_cap) n_seg = seg_cap;
-    if (idx->variant >= 50 && idx->variant < 100) n_seg = idx->variant - 50;     // A/B knob: force the segment count
     if (guess_thr > 0 && idx->lk_seg > 0) n_seg = idx->lk_seg < n_tiles / 2 ? idx->lk_seg : n_tiles / 2;
     int rc;
-    if (a.kcap == 0 || n_seg < 2 || idx->variant == 9) {           // single pass over the whole pool
+    if (a.kcap == 0 || n_seg < 2) {           // single pass over the whole pool
         a.n_seg = 1;
         a.tiles_per_seg = (int)n_tiles;
         if (timed && (rc = timing_begin(idx, st))) return rc;
@@ -219,7 +219,7 @@ int run_hamming_lookup(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
         a.seg_base = 0;
         a.seed_keys = seeds;
         if ((rc = launch_lk_len(idx, a, st))) return rc;
-        return launch_merge(a.kcap, idx->d_keys, (int)n_seg, n_q, a.k, ids, dists, counts, nearest, st);
+        return launch_merge(a.kcap, idx->d_keys, (int)n_seg, n_q, a.k, ids, dists, counts, nearest, st, a.n_dev);
     }
     a.n_seg = 1;
     a.seg_base = 0;
@@ -233,7 +233,7 @@ int run_hamming_lookup(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
     const int64_t seg0 = tps * gm::LK_TG * gm::LK_GROUP;          // pool targets covered by segment 0
     const int64_t in_b = idx->n_db > seg0 ? idx->n_db - seg0 : 0;
     if (timed && (rc = timing_end(idx, st, n_q * in_b))) return rc;
-    return launch_merge(a.kcap, idx->d_keys, (int)n_seg, n_q, a.k, ids, dists, counts, nearest, st);
+    return launch_merge(a.kcap, idx->d_keys, (int)n_seg, n_q, a.k, ids, dists, counts, nearest, st, a.n_dev);
 }
 
 int launch_lv_by_len(gm_index* idx, int algo, int kcap, int64_t n_q, int k, int n_seg, int tiles_per_seg,
@@ -625,6 +625,7 @@ int run_hamming_prefix(gm_index* idx, bool nearest, int64_t n, int k, int kcap, 
                        const int32_t* ids, const int32_t* dists, const int32_t* counts, hipStream_t st) {
     gm_lk_args a;
     a.q = q2;
+    a.n_dev = idx->dev_rows;
     a.kcap = kcap;
     a.n_q = n;
     a.k = nearest ? 1 : k;
@@ -675,6 +676,7 @@ struct PgLevelScope {
         std::swap(idx->plan_k, lv->plan_k);
         std::swap(idx->plan_found, lv->plan_found);
         std::swap(idx->plan_cascade, lv->plan_cascade);
+        std::swap(idx->plan_parent_radius, lv->plan_parent_radius);
         std::swap(idx->plan_cost, lv->plan_cost);
         std::swap(idx->pg_flooded_k1, lv->pg_flooded_k1);
         std::swap(idx->plan_lay, lv->plan_lay);
@@ -696,10 +698,38 @@ struct PgLevelScope {
 static const std::vector<uint32_t>& idx_cum(const gm_index* idx) { return idx->plan_cum; }      // (level 0's sample: not swapped)
 static int idx_cum_k(const gm_index* idx) { return idx->plan_cum_k; }
 
+// A speculative run (SpecRun != nullptr): the counts the host used to wait for are taken from the handle's last query of
+// this shape (+ a margin), the device's counts go to mailboxes, and run_hamming_pigeon checks them once at the end.
+namespace {
+struct SpecCheck {
+    gm_pg_pending pend;
+    int level, kind;      // kind 0: rows left by the merge, 1: by the prefix re-scan, 2: by the plain re-scan under the guess
+    int64_t cap;
+};
+struct SpecRun {
+    std::vector<SpecCheck> checks;
+};
+int64_t spec_cap(int64_t last) { return last <= 0 ? 0 : last + last / 4 + 2048; }
+int64_t spec_cap_small(int64_t last) { return last <= 0 ? 0 : last + last / 4 + 64; }
+}  // namespace
+
 static int run_pigeon_level(gm_index* idx, int level, bool nearest, int64_t n_q, int k, int32_t* ids, int32_t* dists,
                             int32_t* counts, hipStream_t st, bool* used, bool timed, const double* p_short_in,
-                            int parent_radius) {
+                            int parent_radius, SpecRun* sp, int64_t n_q_dec, const int* n_q_dev) {
+    // (n_q_dec: the row count DECISIONS are taken on -- n_q itself, or, in a speculative run on an upper bound of the row
+    // count, the actual count of the run it learnt from, so that both take the same path; n_q_dev: in such a run the device
+    // address of the level's actual candidate count, which its grouping and merge kernels clamp to)
     *used = false;
+    struct DevCountScope {      // the device counts this level's launches clamp to; the caller's come back on every exit
+        gm_index* i;
+        const int *nq, *rows;
+        ~DevCountScope() {
+            i->dev_nq = nq;
+            i->dev_rows = rows;
+        }
+    } dev_scope{idx, idx->dev_nq, idx->dev_rows};
+    idx->dev_nq = n_q_dev;
+    idx->dev_rows = nullptr;
     const int keff = nearest ? 1 : k;
     if (keff > 20 || idx->n_db < keff || n_q < 1) return GM_OK;
     // variants 100 + B force the plain layout of B blocks; 200 + B one expansion block (even lengths), 300 + B
@@ -733,8 +763,10 @@ static int run_pigeon_level(gm_index* idx, int level, bool nearest, int64_t n_q,
     } else {
         // (the pool and its composition belong to the handle; a deeper level's candidate count varies a little from query
         // to query: its plan stands while the count stays within an eighth of the planned one)
+        // (a speculative run hands a deeper level its PREDICTED row count + margin: the plan of the run it learnt from stands)
         const bool stale = level == 0 ? idx->plan_nq != n_q
-                                      : (idx->plan_nq < 0 || std::llabs((long long)(n_q - idx->plan_nq)) * 8 > (long long)idx->plan_nq);
+                                      : (idx->plan_nq < 0 || idx->plan_parent_radius != parent_radius ||      // (the parent re-planned)
+                                         (!sp && std::llabs((long long)(n_q - idx->plan_nq)) * 8 > (long long)idx->plan_nq));
         if (stale || idx->plan_k != keff) {
             // how far the k-th neighbour lies, measured: a plain scan of every (n_q / 2048)-th candidate against the
             // whole pool (~0.1 ms, once per plan) -- the independent-base model knows the pool's composition, not the
@@ -847,13 +879,14 @@ static int run_pigeon_level(gm_index* idx, int level, bool nearest, int64_t n_q,
             idx->plan_p_short = p_short;
             idx->plan_nq = n_q;
             idx->plan_k = keff;
+            idx->plan_parent_radius = parent_radius;
         }
         if (!idx->plan_found) return GM_OK;
         if (idx->pg_flooded_k1 == keff + 1) return GM_OK;
         if (level > 0 && idx->pg_cascade == 1) {
             // a level of its own has a fixed price (grouping, merge, read-back: ~150 us): for a few thousand rows the
             // prefix / plain re-scan of the parent is the cheaper way (S1: 5 414 rows, 0.10 ms against 0.19)
-            const double fixed = 300e-6 * 2.6e13 / ((double)idx->n_db * (double)n_q) + 11700.0 / (double)idx->n_db;
+            const double fixed = 300e-6 * 2.6e13 / ((double)idx->n_db * (double)n_q_dec) + 11700.0 / (double)idx->n_db;
             if (idx->plan_cost + fixed >= 1.0) return GM_OK;
         }
         lay = idx->plan_lay;
@@ -867,7 +900,7 @@ static int run_pigeon_level(gm_index* idx, int level, bool nearest, int64_t n_q,
     if ((rc = gm_pg_candidates(idx, n_q, keff, st))) return rc;
     const int kcap = nearest ? 1 : (k <= 5 ? 5 : (k <= 10 ? 10 : 20));
     if (timed && (rc = timing_begin(idx, st))) return rc;
-    if (timed) idx->last_kernel = "k_hamming_scan_pg";
+    if (timed) idx->last_kernel = gm_pg_hit_path_is_registers(idx) ? "k_hamming_scan_pg4" : "k_hamming_scan_pg";
     if ((rc = gm_pg_scan(idx, n_q, keff, kcap, st))) {
         if (rc == GM_ERR_ALLOC) return GM_OK;      // no room for the slot lists: the plain scan takes over
         return rc;
@@ -875,7 +908,25 @@ static int run_pigeon_level(gm_index* idx, int level, bool nearest, int64_t n_q,
     if (timed && (rc = timing_end(idx, st, n_q * idx->n_db))) return rc;
     if ((rc = gm_pg_merge(idx, kcap, n_q, keff, ids, dists, counts, nearest, st))) return rc;
     int64_t n_inc = 0, pairs = 0;
-    if ((rc = gm_pg_incomplete(idx, &n_inc, &pairs, st))) return rc;
+    if (sp) {
+        n_inc = spec_cap(idx->spec.ninc[level]);
+        if (n_inc > n_q) n_inc = n_q;
+        pairs = level < GM_PG_LEVELS ? idx->casc_pairs_last[level] : 0;
+        SpecCheck c{};
+        c.level = level;
+        c.kind = 0;
+        c.cap = n_inc;
+        if ((rc = gm_pg_publish_async(idx, 1, st, &c.pend))) return rc;
+        sp->checks.push_back(c);
+        idx->dev_rows = gm_pg_count_ptr(idx, 0);      // the rows the merge left: every re-scan launch below clamps to it
+    } else {
+        if ((rc = gm_pg_incomplete(idx, &n_inc, &pairs, st))) return rc;
+        if (level < GM_PG_LEVELS) {
+            idx->spec.ninc[level] = n_inc;
+            idx->spec.nleft[level] = idx->spec.nbad[level] = -1;
+            idx->casc_pairs_last[level] = pairs;
+        }
+    }
     if (timed) {
         idx->last_evaluated = pairs;
         idx->last_incomplete = n_inc;
@@ -895,8 +946,9 @@ static int run_pigeon_level(gm_index* idx, int level, bool nearest, int64_t n_q,
     if (planned && !idx->plan_p_short.empty()) expect = idx->plan_p_short[(size_t)(radius < idx->L ? radius : idx->L)];
     // A pool of repeat families floods the hit lists and K1P ends up handing most rows to the plain scan: twice the
     // work of the plain scan alone.  The answer of this query stands (exact either way); remember it for the next.
-    if (planned && (double)n_inc > (expect + 1.0 / 3.0) * (double)n_q && n_q >= 4096 && gm_pg_debug_flags(idx) == 0)
+    if (!sp && planned && (double)n_inc > (expect + 1.0 / 3.0) * (double)n_q && n_q >= 4096 && gm_pg_debug_flags(idx) == 0)
         idx->pg_flooded_k1 = keff + 1;
+    const int64_t n_inc_dec = sp && level < GM_PG_LEVELS ? idx->spec.ninc[level] : n_inc;
     if (n_inc > 0) {
         const uint2* q2 = nullptr;
         int32_t *ids2 = nullptr, *dists2 = nullptr, *counts2 = nullptr;
@@ -905,9 +957,9 @@ static int run_pigeon_level(gm_index* idx, int level, bool nearest, int64_t n_q,
         // radius the majority needs) -> a deeper K1P level over the compact rows, planned for THEIR number and the
         // conditional distribution of their k-th neighbour; what that level leaves takes its own re-scan paths.
         if (level + 1 < GM_PG_LEVELS && idx->pg_cascade != 0 && idx->pg_flooded_k1 != keff + 1 &&
-            (idx->pg_cascade == 2 ? n_inc >= 64
-                                  : (n_inc >= 4096 && !idx->plan_p_short.empty() &&
-                                     (idx->plan_cascade != 0 || n_inc >= 16384)))) {      // (the plan counted on a deeper level, or far more rows are short than it expected)
+            (idx->pg_cascade == 2 ? n_inc_dec >= 64
+                                  : (n_inc_dec >= 4096 && !idx->plan_p_short.empty() &&
+                                     (idx->plan_cascade != 0 || n_inc_dec >= 16384)))) {      // (the plan counted on a deeper level, or far more rows are short than it expected)
             std::vector<double> ps2;
             if (!idx->plan_p_short.empty()) {
                 const int L = idx->L;
@@ -921,10 +973,11 @@ static int run_pigeon_level(gm_index* idx, int level, bool nearest, int64_t n_q,
             bool used2 = false;
             {
                 const gm_pigeon* parent = gm_pg_state(idx);
+                const int* rows_dev = idx->dev_rows;      // (this level's count: the deeper level's candidates)
                 PgLevelScope scope(idx, level + 1, q2);
                 gm_pg_inherit(idx, parent);
                 rc = run_pigeon_level(idx, level + 1, nearest, n_inc, k, ids2, dists2, counts2, st, &used2, false,
-                                      ps2.empty() ? nullptr : ps2.data(), radius);
+                                      ps2.empty() ? nullptr : ps2.data(), radius, sp, n_inc_dec, rows_dev);
             }
             if (rc) return rc;
             if (used2) {
@@ -937,16 +990,30 @@ static int run_pigeon_level(gm_index* idx, int level, bool nearest, int64_t n_q,
         // at r + 1 with the smallest ids, and the first part of the pool (id order) almost surely holds them: scan only
         // that prefix, fold in the partial lists, and hand the plain re-scan just the rows that are still short (and
         // those whose lists overflowed).
-        const double frac = gm_pg_prefix_fraction(idx, keff);
+        const double frac = sp && level < GM_PG_LEVELS ? idx->spec.frac[level] : gm_pg_prefix_fraction(idx, keff);
+        if (!sp && level < GM_PG_LEVELS) idx->spec.frac[level] = frac;
         if (frac <= 0.6) {
             if ((rc = run_hamming_prefix(idx, nearest, n_inc, keff, kcap, q2, radius + 2, frac, ids, dists, counts, st)))
                 return rc;
             if ((rc = gm_pg_scatter(idx, n_inc, keff, nearest, ids, dists, counts, st))) return rc;
             if ((rc = gm_pg_collect_bad(idx, n_inc, keff, nearest, st))) return rc;
             int64_t n_left = 0;
-            if ((rc = gm_pg_read_bad(idx, &n_left, st))) return rc;
+            if (sp) {
+                n_left = spec_cap_small(level < GM_PG_LEVELS ? idx->spec.nleft[level] : 0);
+                if (n_left > n_inc) n_left = n_inc;
+                SpecCheck c{};
+                c.level = level;
+                c.kind = 1;
+                c.cap = n_left;
+                if ((rc = gm_pg_publish_async(idx, 2, st, &c.pend))) return rc;
+                sp->checks.push_back(c);
+                idx->dev_rows = gm_pg_count_ptr(idx, 1);      // the rows the collect left (as of this publish)
+            } else {
+                if ((rc = gm_pg_read_bad(idx, &n_left, st))) return rc;
+                if (level < GM_PG_LEVELS) idx->spec.nleft[level] = n_left;
+            }
             if (std::getenv("GM_DEBUG"))
-                fprintf(stderr, "[gm] prefix re-scan: %lld rows, fraction %.3f, %lld left\n", (long long)n_inc, frac, (long long)n_left);
+                fprintf(stderr, "[gm] prefix re-scan: %lld rows, fraction %.3f, %lld left%s\n", (long long)n_inc, frac, (long long)n_left, sp ? " (predicted)" : "");
             if (n_left == 0) {
                 *used = true;
                 return GM_OK;
@@ -963,7 +1030,20 @@ static int run_pigeon_level(gm_index* idx, int level, bool nearest, int64_t n_q,
         // the rows whose list did not fill under the guess (and only those) go through the unseeded scan
         int64_t n_bad = 0;
         if ((rc = gm_pg_collect_bad(idx, n_inc, keff, nearest, st))) return rc;
-        if ((rc = gm_pg_read_bad(idx, &n_bad, st))) return rc;
+        if (sp) {
+            n_bad = spec_cap_small(level < GM_PG_LEVELS ? idx->spec.nbad[level] : 0);
+            if (n_bad > n_inc) n_bad = n_inc;
+            SpecCheck c{};
+            c.level = level;
+            c.kind = 2;
+            c.cap = n_bad;
+            if ((rc = gm_pg_publish_async(idx, 3, st, &c.pend))) return rc;
+            sp->checks.push_back(c);
+            idx->dev_rows = gm_pg_count_ptr(idx, 1);
+        } else {
+            if ((rc = gm_pg_read_bad(idx, &n_bad, st))) return rc;
+            if (level < GM_PG_LEVELS) idx->spec.nbad[level] = n_bad;
+        }
         if (std::getenv("GM_DEBUG"))
             fprintf(stderr, "[gm] plain re-scan: %lld rows under the bound %d, %lld left for the unseeded scan\n", (long long)n_inc,
                     guess, (long long)n_bad);
@@ -980,16 +1060,66 @@ static int run_pigeon_level(gm_index* idx, int level, bool nearest, int64_t n_q,
 int run_hamming_pigeon(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t* ids, int32_t* dists,
                        int32_t* counts, hipStream_t st, bool* used, bool timed = true) {
     idx->casc_levels = 0;
-    return run_pigeon_level(idx, 0, nearest, n_q, k, ids, dists, counts, st, used, timed, nullptr, -1);
+    auto& S = idx->spec;
+    const bool same_shape = S.valid && S.n_q == n_q && S.k == k && S.nearest == nearest;
+    if (!same_shape) S.cooldown = 0;
+    const bool speculate = same_shape && idx->pg_spec != 0 && S.cooldown == 0 && gm_pg_mailbox_usable(idx) && !std::getenv("GM_DEBUG");
+    if (S.cooldown > 0) --S.cooldown;
+    idx->spec_last = 0;
+    if (speculate) {
+        // Everything is enqueued on predicted row counts; ONE look at the mailboxes afterwards.
+        SpecRun sp;
+        int rc = run_pigeon_level(idx, 0, nearest, n_q, k, ids, dists, counts, st, used, timed, nullptr, -1, &sp, n_q, nullptr);
+        if (rc) return rc;
+        bool ok = true;
+        for (const SpecCheck& c : sp.checks) {
+            int64_t n_inc = 0, n_bad = 0, pairs = 0;
+            if ((rc = gm_pg_pending_wait(&c.pend, c.kind == 0, st, &n_inc, &n_bad, &pairs))) {
+                ok = false;      // (no mailbox on this platform after all: the synchronous run below decides)
+                break;
+            }
+            const int64_t actual = c.kind == 0 ? n_inc : n_bad;
+            if (actual > c.cap) ok = false;
+            if (c.level < GM_PG_LEVELS) {
+                if (c.kind == 0) {
+                    S.ninc[c.level] = actual;
+                    idx->casc_left[c.level] = actual;
+                    idx->casc_pairs[c.level] = idx->casc_pairs_last[c.level] = pairs;
+                    if (c.level == 0 && timed) {
+                        idx->last_evaluated = pairs;
+                        idx->last_incomplete = actual;
+                    }
+                    if (c.level + 1 < GM_PG_LEVELS && c.level + 1 < idx->casc_levels) idx->casc_nq[c.level + 1] = actual;
+                } else if (c.kind == 1) {
+                    S.nleft[c.level] = actual;
+                } else {
+                    S.nbad[c.level] = actual;
+                }
+            }
+        }
+        idx->spec_last = ok ? 1 : 2;
+        if (ok) return GM_OK;
+        // a level left more rows than its cap covers: this query again, waiting for the counts; the next few stay that way
+        S.valid = false;
+        S.cooldown = 4;
+        idx->casc_levels = 0;
+    }
+    const int rc = run_pigeon_level(idx, 0, nearest, n_q, k, ids, dists, counts, st, used, timed, nullptr, -1, nullptr, n_q, nullptr);
+    if (rc == GM_OK && *used) {
+        S.valid = true;
+        S.n_q = n_q;
+        S.k = k;
+        S.nearest = nearest;
+    } else {
+        S.valid = false;
+    }
+    return rc;
 }
 
-// variant 0 = default (K1L look-up kernel), 1 = popcount kernel K1, 5 and 2x/3x = K1v knobs
+// variant 0 = default, 7 = K1L with its k-lists in LDS, 8 = plain two-phase K1L (no K1P), 100 + ... = forced K1P layouts; 1 =
+// popcount kernel K1 (anything else that is not listed runs K1 as well)
 bool use_lookup(const gm_index* idx) {
-    return idx->metric == GM_METRIC_HAMMING && idx->d_onehot != nullptr && (idx->variant == 0 || idx->variant == 7 || idx->variant == 8 || idx->variant == 9 || (idx->variant >= 40 && idx->variant < 100) || (idx->variant >= 102 && idx->variant < 1000 && idx->variant % 100 >= 2 && idx->variant % 100 <= GM_PG_MAXB));
-}
-
-bool use_bitslice(const gm_index* idx) {
-    return idx->metric == GM_METRIC_HAMMING && idx->d_vert != nullptr && idx->variant != 1 && !use_lookup(idx);
+    return idx->metric == GM_METRIC_HAMMING && idx->d_onehot != nullptr && (idx->variant == 0 || idx->variant == 7 || idx->variant == 8 || (idx->variant >= 102 && idx->variant < 1000 && idx->variant % 100 >= 2 && idx->variant % 100 <= GM_PG_MAXB));
 }
 
 // (one event pair per timed launch: with a reserved history the pair of the history slot serves gm_last_kernel_ms as
@@ -1343,13 +1473,6 @@ int gm_index_create_dev(const void* d_packed, int64_t n_db, int guidelen, int me
             return rc;
         }
         if (guidelen >= 10 && guidelen <= 27) {
-            if (metric == GM_METRIC_HAMMING && guidelen == 20) {      // K1v A/B baseline exists for L = 20 only
-                int rcv = gm_build_vertical(idx, st);
-                if (rcv != GM_OK) {
-                    gm_index_free(idx);
-                    return rcv;
-                }
-            }
             // one-hot table for the look-up kernel
             const int64_t lk_groups = round_up((n_db + gm::LK_GROUP - 1) / gm::LK_GROUP, 2 * gm::LK_TG);   // even tile count
             idx->n_lk_tiles = lk_groups / gm::LK_TG;
@@ -1425,7 +1548,6 @@ void gm_index_free(gm_index* idx) {
     if (!idx) return;
     (void)hipSetDevice(idx->device);
     if (idx->d_db) (void)hipFree(idx->d_db);
-    if (idx->d_vert) (void)hipFree(idx->d_vert);
     gm_lp_free(idx);
     gm_pg_free(idx);
     for (auto& lv : idx->pg_deeper) {      // the deeper cascade levels' K1P state
@@ -1455,12 +1577,18 @@ int gm_index_metric(const gm_index* idx) { return idx ? idx->metric : -1; }
 int gm_set_variant(gm_index* idx, int variant) {
     if (check_index(idx)) return GM_ERR_ARG;
     idx->variant = variant;
+    idx->spec.valid = false;
     return GM_OK;
 }
 
 int gm_set_param(gm_index* idx, const char* name, int value) {
     if (check_index(idx)) return GM_ERR_ARG;
     if (!name) return fail(GM_ERR_ARG, "gm_set_param: null name");
+    idx->spec.valid = false;      // (the follow-up counts learnt under the old settings say nothing about the new ones)
+    if (std::strcmp(name, "pg_spec") == 0) {
+        idx->pg_spec = value != 0;
+        return GM_OK;
+    }
     if (std::strcmp(name, "lk_seg") == 0) {
         idx->lk_seg = value;
         return GM_OK;
@@ -1530,10 +1658,7 @@ static int knn_query_dev_impl(gm_index* idx, const void* d_q, int64_t n_q, int k
     rc = timing_begin(idx, st);
     if (rc) return rc;
     const int R = pick_r(k);
-    if (use_bitslice(idx)) {
-        idx->last_kernel = "k_hamming_knn_bs";
-        rc = gm_launch_bs20(idx, false, n_q, k, ids, dists, counts, st);
-    } else if (idx->metric == GM_METRIC_HAMMING) {
+    if (idx->metric == GM_METRIC_HAMMING) {
         idx->last_kernel = "k_hamming_knn";
         rc = R == 4 ? launch_hamming_knn<4>(idx, n_q, k, ids, dists, counts, st)
            : R == 2 ? launch_hamming_knn<2>(idx, n_q, k, ids, dists, counts, st)
@@ -1613,11 +1738,7 @@ static int nearest_dist_dev_impl(gm_index* idx, const void* d_q, int64_t n_q, vo
     int n_tiles = (int)(idx->n_db_pad / gm::TILE);
     rc = timing_begin(idx, st);
     if (rc) return rc;
-    if (use_bitslice(idx)) {
-        idx->last_kernel = "k_hamming_knn_bs(nearest)";
-        rc = gm_launch_bs20(idx, true, n_q, 1, nullptr, d1, nullptr, st);
-        if (rc) return rc;
-    } else if (idx->metric == GM_METRIC_HAMMING) {
+    if (idx->metric == GM_METRIC_HAMMING) {
         constexpr int R = 4;
         int64_t blocks = (n_q + R * gm::WAVE - 1) / (R * gm::WAVE);
         idx->last_kernel = "k_hamming_nearest";
@@ -1781,6 +1902,7 @@ int64_t gm_last_kernel_pairs(gm_index* idx) { return idx ? idx->last_pairs : 0; 
 int64_t gm_last_kernel_evaluated(gm_index* idx) { return idx ? idx->last_evaluated : 0; }
 int64_t gm_last_incomplete(gm_index* idx) { return idx ? idx->last_incomplete : 0; }
 int gm_pigeon_blocks(gm_index* idx) { return idx ? gm_pg_blocks_of(idx) : 0; }
+int gm_last_speculation(gm_index* idx) { return idx ? idx->spec_last : 0; }
 int gm_pigeon_block_info(gm_index* idx, int b, int* positions, int64_t* pairs) {
     if (!idx || !positions || !pairs) return 0;
     return gm_pg_block_info(idx, b, positions, pairs);

@@ -181,6 +181,10 @@ int64_t gm_last_kernel_pairs(gm_index* idx);
 int64_t gm_last_kernel_evaluated(gm_index* idx);
 int64_t gm_last_incomplete(gm_index* idx);
 /* Number of blocks B of the K1P layout currently built for this handle (0: none built yet). */
+/* How the last K1P query sized the follow-up launches of the rows its levels left short: 0 = it waited for the device's
+ * counts, 1 = from the previous query's counts, checked once at the end (gm_set_param "pg_spec"), 2 = so, but a level left
+ * more rows than provided for and the query was run again the waiting way. */
+int gm_last_speculation(gm_index* idx);
 int gm_pigeon_blocks(gm_index* idx);
 /* Block b of that layout: the positions per pair its scan evaluates (guide length minus the block itself, which its
  * copy's table leaves out) and the pairs its part of the last K1P launch evaluated.  Returns 1, or 0 when there is no
@@ -232,13 +236,13 @@ int gm_timing_reserve(gm_index* idx, int n);
 int gm_timing_read(gm_index* idx, double* ms_out, int max_n);
 
 /* A/B knob for experiments, benchmarks and tests; results are identical for every value.  0 = default.
- *   Hamming:     8 = plain two-phase look-up scan K1L (no pigeonhole partition); 9 = K1L in a single pass;
- *                7 = K1L with its k-lists in LDS; 1 = popcount kernel K1; 20..36 = scalar-load bit-sliced kernel
- *                K1v (L = 20 only); 40..49 = K1L with the resident waves capped; 50..99 = K1L with
- *                (variant - 50) pool segments; 100 + B = K1P with B blocks, no expansion; 200 + B / 300 + B one
- *                expansion block (even length / one base longer); 400 + B / 500 + B two / three longer expansion
- *                blocks; 600 + B / 700 + B two / three expansion blocks of even length; 800 + B block 0 with the
- *                two-substitution neighbourhood; 900 + B the same plus block 1 with the one-substitution one.
+ *   Hamming:     8 = plain two-phase look-up scan K1L (no pigeonhole partition); 7 = K1L with its k-lists in LDS (the
+ *                path of k > 20); 1 = popcount kernel K1 (the path of guides shorter than 10 bases); 100 + B = K1P with
+ *                B blocks, no expansion; 200 + B / 300 + B one expansion block (even length / one base longer);
+ *                400 + B / 500 + B two / three longer expansion blocks; 600 + B / 700 + B two / three expansion blocks of
+ *                even length; 800 + B block 0 with the two-substitution neighbourhood; 900 + B the same plus block 1 with
+ *                the one-substitution one.  (Round 3's 9, 20..36, 40..49 and 50..99 -- a single-pass K1L, the scalar-load
+ *                kernel K1v, capped occupancy, forced segment counts -- had no test or tool left and are gone.)
  *   Levenshtein: 2 = per-pair Myers kernel K2L; 1 = plane-based kernel (also used for L < 10 and k > 20). */
 int gm_set_variant(gm_index* idx, int variant);
 /* Named tuning knobs (experiments; results are identical for every value).
@@ -264,6 +268,10 @@ int gm_set_variant(gm_index* idx, int variant);
  *   2 = every lane keeps its candidate's k best keys in registers, hits reach it through a mailbox in LDS and the scan
  *   writes k keys per list (k_hamming_scan_pg4); 1 (default) = chosen per cascade level (register lists for k <= 10 on
  *   >= 400 000 candidates);
+ *   "pg_spec": 1 (default) = a query of the same shape (n_q, k) as the handle's previous one sizes the follow-up launches of
+ *   the rows each K1P level leaves short from that query's counts (+ an eighth + 1024, the lists padded with duplicate
+ *   rows) instead of waiting for the device's counts, and checks the counts once after everything is enqueued (a level
+ *   that left more runs the query again the waiting way); 0 = always wait (A/B, tests);
  *   "pg_per": target buckets per K1P workgroup (0 = choose: 16 / pg_sub, all of them with register lists);
  *   ("pg_debug", a round-3 knob that made the scan skip work for timing and its results WRONG, is gone from the library:
  *   it answers GM_ERR_ARG; such timings are separate builds, -DGM_PG_TIMING in guidemaker_amd/csrc/Makefile's CXXFLAGS);

@@ -12,7 +12,7 @@ L, k = pool["guidelen"], pool["k"]
 idx = _lib.Index(pool["packed_db"], L, _lib.METRIC_HAMMING, 0)
 got = distributed.sharded_knn_index(idx, pool["packed_all"], k, 0)      # this rank scans ITS shard only, one all-gather
 lo, hi, per = distributed.shard_range(pool["packed_all"].shape[0], world, rank)
-assert idx.last_kernel()[0] == "k_hamming_scan_pg"
+assert idx.last_kernel()[0] .startswith("k_hamming_scan_pg")
 if rank == 0:
     want = idx.knn(pool["packed_all"], k)                              # the single-rank table of all 599 093 candidates
     for g, w in zip(got, want):

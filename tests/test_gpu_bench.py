@@ -45,7 +45,7 @@ def test_bench_single_gpu_line():
             assert key in w, (name, key)
         assert w["steps"] == 3 and w["ms_per_step"] > 0 and 0.0 < w["useful_frac"] <= 1.0
         assert w["roofline"]["counters"] in (None, "stale") or isinstance(w["roofline"]["counters"], dict)
-    assert ex["pao1"]["data"] == "real genome" and ex["pao1"]["kernel"] == "k_hamming_scan_pg"
+    assert ex["pao1"]["data"] == "real genome" and ex["pao1"]["kernel"] .startswith("k_hamming_scan_pg")
     assert ex["cfd"]["roofline"]["bound"] == "hbm" and 0.0 < ex["cfd"]["roofline"]["frac"] <= 1.0
 
 

@@ -96,7 +96,7 @@ def test_hamming_workload_full_size(oracle, name):
     try:
         ids, dists, counts = idx.knn(q, k)
         # the layout bench.py runs: the pigeonhole-partitioned scan with the planner's own layout for this pool
-        assert idx.last_kernel()[0] == "k_hamming_scan_pg"
+        assert idx.last_kernel()[0] .startswith("k_hamming_scan_pg")
         assert idx.pigeon_blocks() in (3, 4)      # (5,5,5,5) with three expanded blocks, or (7,7,6) / (8,6,6) with a radius-2 block
         evaluated, rescanned = idx.last_evaluated()
         assert 0 < evaluated < 0.15 * q.shape[0] * db.shape[0]

@@ -390,13 +390,13 @@ def test_list_capacity_boundaries(oracle, k):
 
 
 def test_kernel_variants_agree(oracle):
-    # A/B knobs must not change results: K1 popcount (1), K1v scalar-load bit-slice (20), K1L LDS lists (7)
+    # A/B knobs must not change results: K1 popcount (1), K1L with its lists in LDS (7), plain K1L (8)
     L = 20
     db = list(dict.fromkeys(random_pool(4000, L, seed=90)))
     q = db[::3]
     idx = _lib.Index(_lib.pack(db, L), L, _lib.METRIC_HAMMING)
     ref = idx.knn(_lib.pack(q, L), 10)
-    for v in (1, 7, 20, 22):
+    for v in (1, 7, 8):
         idx.set_variant(v)
         got = idx.knn(_lib.pack(q, L), 10)
         assert all((a == b).all() for a, b in zip(ref, got)), v
@@ -466,7 +466,7 @@ def test_pigeonhole_repeat_family_overflows_to_rescan(oracle):
     idx = _lib.Index(_lib.pack(db, L), L, _lib.METRIC_HAMMING)
     idx.set_variant(107)
     ids, dists, counts = idx.knn(_lib.pack(q, L), k)
-    assert idx.last_kernel()[0] == "k_hamming_scan_pg"
+    assert idx.last_kernel()[0] .startswith("k_hamming_scan_pg")
     assert idx.last_evaluated()[1] >= 100          # the family rows were re-scanned
     oi, od, oc = _oracle_true_units(oracle, db, q, L, "hamming", k)
     assert (counts == oc).all() and (dists == od).all() and (ids == oi).all()
@@ -483,7 +483,7 @@ def test_pigeonhole_default_path_sampled_oracle(oracle):
     idx = _lib.Index(packed, L, _lib.METRIC_HAMMING)
     q = np.concatenate([packed[:60_000], core.pack_codes(rng.integers(0, 4, size=(20_000, L), dtype=np.uint8))])
     ids, dists, counts = idx.knn(q, k)
-    assert idx.last_kernel()[0] == "k_hamming_scan_pg"
+    assert idx.last_kernel()[0] .startswith("k_hamming_scan_pg")
     evaluated, rescanned = idx.last_evaluated()
     assert evaluated < 0.5 * q.shape[0] * packed.shape[0]
     idx.set_variant(8)
@@ -492,7 +492,7 @@ def test_pigeonhole_default_path_sampled_oracle(oracle):
     assert (i8 == ids).all() and (d8 == dists).all() and (c8 == counts).all()
     idx.set_variant(0)
     d1 = idx.nearest(q)
-    assert idx.last_kernel()[0] == "k_hamming_scan_pg" and (d1 == dists[:, 0]).all()
+    assert idx.last_kernel()[0] .startswith("k_hamming_scan_pg") and (d1 == dists[:, 0]).all()
     sample = rng.choice(q.shape[0], size=48, replace=False)
     db_str = _lib.unpack(packed, L)
     oi, od, oc = _oracle_true_units(oracle, db_str, _lib.unpack(q[sample], L), L, "hamming", k)
@@ -749,7 +749,7 @@ def test_get_control_seqs_at_genome_scale(tmp_path):
     d_plain = tl.nmslib_index.nearest(probe)
     tl.nmslib_index.set_variant(0)
     d_pg = tl.nmslib_index.nearest(probe)
-    assert tl.nmslib_index.last_kernel()[0] == "k_hamming_scan_pg"
+    assert tl.nmslib_index.last_kernel()[0] .startswith("k_hamming_scan_pg")
     assert (np.bincount(d_pg, minlength=21) == np.bincount(d_plain, minlength=21)).all() and (d_pg == d_plain).all()
     with pytest.raises(ValueError):
         tl.get_control_seqs(genome, configpath=str(cfg_path), length=L + 1, n=10)
@@ -806,7 +806,7 @@ def test_layouts_with_two_radius2_blocks(oracle, n, L, k, layout):
     try:
         idx.set_param("pg_layout", layout)
         ids, dists, counts = idx.knn(q, k)
-        assert idx.last_kernel()[0] == "k_hamming_scan_pg"
+        assert idx.last_kernel()[0] .startswith("k_hamming_scan_pg")
         d1 = idx.nearest(q)
         assert (d1 == dists[:, 0]).all()
         idx.set_variant(8)
@@ -837,7 +837,7 @@ def test_prefix_rescan_matches_plain_rescan_and_oracle(oracle, n, L, k, planted,
         ids, dists, counts = idx.knn(q, k)
         name, rescanned = idx.last_kernel()[0], idx.last_evaluated()[1]
         if layout:
-            assert name == "k_hamming_scan_pg" and rescanned >= 256, (name, rescanned)
+            assert name .startswith("k_hamming_scan_pg") and rescanned >= 256, (name, rescanned)
         idx.set_param("pg_prefix", 0)
         i0, d0, c0 = idx.knn(q, k)
         assert (i0 == ids).all() and (d0 == dists).all() and (c0 == counts).all()
@@ -877,7 +877,7 @@ def test_cascade_of_k1p_levels_is_exact(oracle, n, L, k, planted, lay1, lay2):
         idx.set_param("pg_cascade", 2)
         idx.set_param("pg_layout2", lay2)
         ids, dists, counts = idx.knn(q, k)
-        assert idx.last_kernel()[0] == "k_hamming_scan_pg"
+        assert idx.last_kernel()[0] .startswith("k_hamming_scan_pg")
         info = idx.cascade_info()
         assert len(info) >= 2 and info[0]["n_q"] == q.shape[0] and info[1]["n_q"] == info[0]["left"] >= 64, info
         assert info[1]["radius"] > info[0]["radius"], info
@@ -1011,7 +1011,7 @@ def test_id_cutoff_is_exact(oracle, n, k, cut):
     try:
         idx.set_param("pg_cut", cut)
         ids, dists, counts = idx.knn(q, k)
-        assert idx.last_kernel()[0] == "k_hamming_scan_pg"
+        assert idx.last_kernel()[0] .startswith("k_hamming_scan_pg")
         idx.set_param("pg_cut", 100)
         i0, d0, c0 = idx.knn(q, k)
         assert (i0 == ids).all() and (d0 == dists).all() and (c0 == counts).all()
@@ -1080,10 +1080,10 @@ def test_repeat_flooded_pool_falls_back_to_plain_scan_next_time(oracle, hit):
         second = idx.last_kernel()[0]
         assert (i1 == i2).all() and (d1 == d2).all() and (c1 == c2).all()
         if hit == 0:
-            assert first == "k_hamming_scan_pg" and rescanned > q.shape[0] // 3, (first, rescanned)
+            assert first .startswith("k_hamming_scan_pg") and rescanned > q.shape[0] // 3, (first, rescanned)
             assert second.startswith("k_hamming_knn_lk"), second
         else:
-            assert first == "k_hamming_scan_pg" and second == "k_hamming_scan_pg", (first, second)
+            assert first .startswith("k_hamming_scan_pg") and second .startswith("k_hamming_scan_pg"), (first, second)
             assert rescanned < q.shape[0] // 3, rescanned
         rows = rng.choice(q.shape[0], size=400, replace=False)
         oi, od, oc = oracle.knn(_packed_to_bytes(db, L), _packed_to_bytes(q[rows], L), L, "hamming", k)
@@ -1322,3 +1322,44 @@ def test_timing_knob_is_not_in_the_release_library():
             idx.set_param("pg_hit", 3)
     finally:
         idx.close()
+
+
+def test_speculative_follow_ups_are_exact(oracle):
+    """gm_set_param "pg_spec": a query of the same shape as the handle's previous one enqueues the follow-ups of the rows
+    each K1P level leaves short on PREDICTED counts (no host wait between the kernels) and validates once at the end.
+    (a) repeated identical queries: the speculative runs equal the waiting one and the plain scan; (b) the same shape
+    with very different content -- five times the rows left short, then hardly any -- must come out exact too (the
+    misprediction is caught and the query runs again the waiting way); cascade levels, prefix and plain re-scans."""
+    n, L, k = 300_000, 20, 10
+    db = _random_packed(n, L, seed=4401, planted=0.01)
+    members = db[:150_000]
+    foreign = _random_packed(200_000, L, seed=4402)[:150_000]
+    mixed = np.concatenate([members[:75_000], foreign[:75_000]])
+    plain = _lib.Index(db, L, _lib.METRIC_HAMMING)
+    plain.set_variant(8)
+    want = {name: plain.knn(q, k) for name, q in (("members", members), ("foreign", foreign), ("mixed", mixed))}
+    want1 = plain.nearest(foreign)
+    plain.close()
+    for setup in ({}, {"pg_layout": 717160, "pg_cascade": 2, "pg_layout2": 61515140}, {"pg_hit": 2}):
+        idx = _lib.Index(db, L, _lib.METRIC_HAMMING)
+        try:
+            for name, val in setup.items():
+                idx.set_param(name, val)
+            how = []
+            for name, q in (("members", members), ("members", members), ("members", members), ("foreign", foreign),
+                            ("foreign", foreign), ("mixed", mixed), ("members", members), ("members", members)):
+                got = idx.knn(q, k)
+                assert idx.last_kernel()[0] .startswith("k_hamming_scan_pg")
+                assert all((a == b).all() for a, b in zip(got, want[name])), (setup, name)
+                how.append(idx.last_speculation())
+            # the first query waits; its repeats run on its counts; a query of the same shape that leaves more rows than
+            # provided for is caught (2) and answered the waiting way, as are the next few
+            assert how[0] == 0 and how[1] == 1 and how[2] == 1, how
+            assert set(how) <= {0, 1, 2}
+            assert (idx.nearest(foreign) == want1).all() and (idx.nearest(foreign) == want1).all()
+            idx.set_param("pg_spec", 0)
+            got = idx.knn(members, k)
+            assert idx.last_speculation() == 0
+            assert all((a == b).all() for a, b in zip(got, want["members"]))
+        finally:
+            idx.close()

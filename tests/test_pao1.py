@@ -91,7 +91,7 @@ def test_pao1_flow_gpu(oracle):
     tp.create_index(guidemaker_amd.CONFIG_PATH)
     tp.get_neighbors(guidemaker_amd.CONFIG_PATH)
     idx = tp.nmslib_index
-    assert idx.last_kernel()[0] == "k_hamming_scan_pg"                            # the production kernel on real data
+    assert idx.last_kernel()[0] .startswith("k_hamming_scan_pg")                            # the production kernel on real data
     ids, dists, counts = tp.last_knn
     n_q = ids.shape[0]
     assert n_q == s["n_query"]                                                    # core.py:495 on the reference's flags
@@ -106,7 +106,7 @@ def test_pao1_flow_gpu(oracle):
     # the layout planned from the independent-base model alone (no scanned sample): another layout, the same answer
     idx.set_param("pg_sample", 0)
     i0, d0, c0 = idx.knn(q, 10)
-    assert idx.last_kernel()[0] == "k_hamming_scan_pg"
+    assert idx.last_kernel()[0] .startswith("k_hamming_scan_pg")
     rescanned_model = idx.last_evaluated()[1]
     idx.set_param("pg_sample", 1)
     assert (i0 == ids).all() and (d0 == dists).all() and (c0 == counts).all()
