@@ -1218,11 +1218,12 @@ int gm_pg_prepare(gm_index* idx, const gm_pg_layout* lay, hipStream_t st) {
 // hit-list numbering
 // The hit path of a level.  Register lists (k_hamming_scan_pg4): exact bound, no hit buffer, a merge that reads 40 dense
 // bytes per list -- at 6 instead of 8 waves per SIMD (10 more VGPRs) and with a serial sorted insert per delivered key.
-// Measured (profiles/r04/NOTES.md): faster where hits are dense and chunks plentiful (PAO1 level 0: scan 1.82 -> 1.56 ms,
-// merge 0.40 -> 0.11), equal on S1, slower on the deeper levels' few short-handed chunks and with 20-key lists.
+// Measured (profiles/r04/NOTES.md): faster where hits are dense and chunks plentiful (PAO1 level 0: scan 1.82 -> 1.46 ms,
+// merge 0.40 -> 0.10; S3 level 0: 0.58 -> 0.46), a little faster on S1 and -- through the merge -- on S4's 20-key lists,
+// slower on the deeper levels' few short-handed chunks (PAO1 levels 1 + 2: 0.92 -> 1.4 ms).
 static bool pg_use_reglists(const gm_pigeon* pg, int64_t n_q, int k) {
     if (pg->tune_hit != 1) return pg->tune_hit == 2;
-    return k <= 10 && n_q >= 400000;
+    return k <= 20 && n_q >= 400000;
 }
 
 static void pg_geometry(gm_pigeon* pg) {
@@ -1514,8 +1515,8 @@ int gm_pg_merge(gm_index* idx, int kcap, int64_t n_q, int k, int32_t* ids, int32
 #define GM_MERGE(KC, SP)                                                                                                          \
     do {                                                                                                                          \
         if (pg->hit_reg)                                                                                                          \
-            hipLaunchKernelGGL((gm::k_merge_pg3<KC, SP>), grid, block, 0, st, pg->keys3, pg->blocks.n_lists, n_q, k, ids, dists,   \
-                               counts, nr, pg->inc, n_inc, &pg->ctr->n_over, pg->ctr->chist,                                      \
+            hipLaunchKernelGGL((gm::k_merge_pg3<KC, 1>), grid_for(n_q), block, 0, st, pg->keys3, pg->blocks.n_lists, n_q, k, ids,  \
+                               dists, counts, nr, pg->inc, n_inc, &pg->ctr->n_over, pg->ctr->chist,                               \
                                pg->cut_id != 0xffffffffu ? pg->cflag : nullptr, idx->dev_nq);                                     \
         else                                                                                                                      \
             hipLaunchKernelGGL((gm::k_merge_hits<KC, SP>), grid, block, 0, st, pg->blocks, pg->lists, n_q, k, ids, dists, counts,  \

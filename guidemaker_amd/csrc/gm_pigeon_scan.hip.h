@@ -406,7 +406,7 @@ constexpr uint32_t PG4_NONE = 0xffffffffu;      // "no key" (= RegList::EMPTY: i
 constexpr int PG4_MAIL = 4;                     // mailbox slots per candidate and round
 __host__ __device__ constexpr size_t pg4_lds_bytes(int L) {
     // tiles, ring (position u32 + lane u8), mailbox, mailbox counts, published k-th keys
-    return sizeof(uint32_t) * (size_t)(2 * pg_pair_words(L) + PG_QCAP + PG_QCAP / 4 + PG4_MAIL * WAVE + WAVE + WAVE);
+    return sizeof(uint32_t) * (size_t)(2 * pg_pair_words(L) + PG_QCAP + PG_QCAP / 4 + PG4_MAIL * WAVE + WAVE + WAVE + 2 * WAVE);
 }
 
 struct Pg4Queue {
@@ -415,6 +415,8 @@ struct Pg4Queue {
     uint32_t* mail;     // [PG4_MAIL][WAVE]  keys + 1 delivered to candidate c this round
     int* mc;            // [WAVE]     keys delivered to (or tried for) candidate c this round
     uint32_t* kth;      // [WAVE]     candidate c's k-th key + 1 as of its last drain (PG4_NONE: list not full)
+    uint2* qpl;         // [WAVE]     candidate planes; bit 31 of .x = the candidate takes the id cut-off (in LDS, not
+                        //            fetched from the owner lane by ds_bpermute: two VGPRs the loop does not have at 16 positions)
     int head, tail;     // wave-uniform ring positions (monotonic)
 };
 
@@ -425,10 +427,10 @@ struct Pg4Queue {
 #endif
 
 // one round of the flush: the first <= 64 queued hits are resolved, one per lane, and delivered to their candidates'
-// owner lanes; qv = this lane's own candidate planes, bit 31 of .x = the candidate takes the id cut-off
+// owner lanes
 template <int KCAP>
 __device__ __forceinline__ void pg4_round(Pg4Queue& Q, int lane, const uint4* __restrict__ recs, int thr0, uint32_t cut_id,
-                                          uint2 qv, RegList<KCAP>& list
+                                          RegList<KCAP>& list
 #ifdef GM_PG_STATS
                                           , unsigned long long (&st_)[8]
 #endif
@@ -444,11 +446,9 @@ __device__ __forceinline__ void pg4_round(Pg4Queue& Q, int lane, const uint4* __
         cl = (int)Q.ln[s];
     }
     Q.head += n;
-    // (every lane takes part in the two permutes; lanes without an entry read lane 0's planes and drop them)
-    const uint2 cq = make_uint2((uint32_t)__builtin_amdgcn_ds_bpermute(cl << 2, (int)qv.x),
-                                (uint32_t)__builtin_amdgcn_ds_bpermute(cl << 2, (int)qv.y));
     uint32_t x = PG4_NONE;
     if (mine) {
+        const uint2 cq = Q.qpl[cl];
 #if defined(GM_PG_TIMING) && (GM_PG_TIMING & 4)      // timing build only (results WRONG): no record gather
         const uint4 t = make_uint4(pos, pos * 31u, pos * 977u & ID_MASK, 0u);
 #else
@@ -507,6 +507,61 @@ __device__ __forceinline__ uint64_t pg4_eval(const uint32_t* const (&ptr)[L], co
     return ((uint64_t)h1 << 32) | (uint64_t)h0;
 }
 
+// The descriptors of a chunk's target buckets, prefetched: lane j holds bucket e_base + j's {first group, groups | add << 28}
+// (and, under the id cut-off, its groups below the cut) from ONE vector gather with all loads in flight; the scan's
+// iterator then takes them with v_readlane -- no dependent scalar load per bucket in front of the next table unit's DMA
+// (k_hamming_scan_pg's pg_next pays one per bucket: ~20 per workgroup with every target bucket of a chunk in one
+// workgroup).  More than 64 buckets (a radius-2 block): the next 64 are fetched when the iterator gets there.
+template <bool CUT>
+struct Pg4Desc {
+    int g0v, gcv, cutv;
+    int e_base;
+    __device__ __forceinline__ void load(const gm_pg_blocks& P, const gm_pg_chunk& ch, int base, int lane) {
+        e_base = base;
+        const int e = base + lane;
+        g0v = 0;
+        gcv = 0;
+        cutv = 0;
+        if (e < ch.e_hi) {
+            int add;
+            const int vt = pg_target_bucket(ch.v, e, P.blen[ch.b], P.skiplen[ch.b], add);
+            const int2 d = P.bdesc[ch.b][vt];
+            g0v = d.x;
+            gcv = d.y > 0 ? (d.y | (add << 28)) : 0;
+            if constexpr (CUT) cutv = P.bcut[ch.b][vt];
+        }
+    }
+};
+template <bool CUT>
+__device__ __forceinline__ bool pg4_next(const gm_pg_blocks& P, const gm_pg_chunk& ch, Pg4Desc<CUT>& D, PgIter& it, int& g, int& ng,
+                                         int& add, int& uncut, int lane) {
+    if (2 * (it.pi + 1) < it.gc) {
+        ++it.pi;
+    } else {
+        do {
+            if (++it.e >= ch.e_hi) return false;
+            if (it.e - D.e_base >= WAVE) D.load(P, ch, D.e_base + WAVE, lane);
+            const int rel = it.e - D.e_base;
+            const int gcw = __builtin_amdgcn_readlane(D.gcv, rel);
+            it.g0 = __builtin_amdgcn_readlane(D.g0v, rel);
+            it.gc = gcw & 0x0fffffff;
+            it.add = (int)((unsigned)gcw >> 28);
+            if constexpr (CUT) it.cutg = __builtin_amdgcn_readlane(D.cutv, rel);
+        } while (it.gc <= 0);
+        it.pi = 0;
+    }
+    g = it.g0 + 2 * it.pi;
+    ng = it.gc - 2 * it.pi < 2 ? it.gc - 2 * it.pi : 2;
+    add = it.add;
+    if constexpr (CUT) {
+        const int left = it.cutg - 2 * it.pi;
+        uncut = left < 0 ? 0 : (left > 2 ? 2 : left);
+    } else {
+        uncut = 2;
+    }
+    return true;
+}
+
 // keys: [n_lists][n_q][KCAP] raw lists (see above)
 #ifndef GM_PG4_W10
 #define GM_PG4_W10 6      /* waves per SIMD asked for with a 5 / 10-key register list */
@@ -537,16 +592,18 @@ __global__ __launch_bounds__(WAVE, pg4_min_waves(L, KCAP)) void k_hamming_scan_p
     Q.mail = Q.pos + PG_QCAP + PG_QCAP / 4;
     Q.mc = reinterpret_cast<int*>(Q.mail + PG4_MAIL * WAVE);
     Q.kth = reinterpret_cast<uint32_t*>(Q.mc + WAVE);
+    Q.qpl = reinterpret_cast<uint2*>(Q.kth + WAVE);
     Q.head = Q.tail = 0;
     const int lane = threadIdx.x;
     const bool valid = lane < ch.cn;
     const int64_t qi = valid ? (int64_t)P.cperm[ch.b][ch.c0 + lane] : 0;
-    uint2 qv = valid ? q[qi] : make_uint2(0u, 0u);
+    const uint2 qv = valid ? q[qi] : make_uint2(0u, 0u);
     const bool lane_cut = CUT && valid && P.cflag[qi] != 0;
     RegList<KCAP> list;
     list.init(k, nullptr, 0);
     Q.mc[lane] = 0;
     Q.kth[lane] = list.v[KCAP - 1];
+    Q.qpl[lane] = make_uint2(qv.x | (lane_cut ? 0x80000000u : 0u), qv.y);
 
     const int skip_start = P.skip[ch.b], skip_len = P.skiplen[ch.b];
     const uint32_t* ptr[L];
@@ -561,11 +618,12 @@ __global__ __launch_bounds__(WAVE, pg4_min_waves(L, KCAP)) void k_hamming_scan_p
 #else
     int thr = valid ? thr0 : 0;              // accept d < thr
 #endif
-    qv.x |= lane_cut ? 0x80000000u : 0u;      // (after the look-up addresses were formed from the planes)
     uint32_t Tb[5];
     PgIter it{ch.e_lo - 1, 0, 0, 0, 0, 0};
+    Pg4Desc<CUT> D;
+    D.load(P, ch, ch.e_lo, lane);
     int gA = 0, ngA = 0, addA = 0, ucA = 2, gB = 0, ngB = 0, addB = 0, ucB = 2;
-    bool okA = pg_next<CUT>(P, ch, it, gA, ngA, addA, ucA), okB = false;
+    bool okA = pg4_next<CUT>(P, ch, D, it, gA, ngA, addA, ucA, lane), okB = false;
     if (okA) pg_stage<L>(table, gA, tiles, lane);
     const uint32_t cut_id = CUT ? P.cut_id : 0xffffffffu;
     int cur = -1;      // (add << 1 | cut) the comparator words were formed for; -1 = stale
@@ -601,7 +659,7 @@ __global__ __launch_bounds__(WAVE, pg4_min_waves(L, KCAP)) void k_hamming_scan_p
             }                                                                                                  \
             Q.tail += __builtin_popcountll(bal);                                                               \
             if (Q.tail - Q.head >= WAVE) {                                                                     \
-                pg4_round<KCAP>(Q, lane, recs, thr0, cut_id, qv, list GM_PG_STARG);                            \
+                pg4_round<KCAP>(Q, lane, recs, thr0, cut_id, list GM_PG_STARG);                            \
                 const int nt = list.v[KCAP - 1] == PG4_NONE ? thr : (int)((list.v[KCAP - 1] - 1u) >> ID_BITS) + 1; \
                 if (nt < thr) thr = nt;                                                                        \
                 cur = -1;                                                                                      \
@@ -610,7 +668,7 @@ __global__ __launch_bounds__(WAVE, pg4_min_waves(L, KCAP)) void k_hamming_scan_p
         }                                                                                                      \
     }
     while (okA) {
-        okB = pg_next<CUT>(P, ch, it, gB, ngB, addB, ucB);
+        okB = pg4_next<CUT>(P, ch, D, it, gB, ngB, addB, ucB, lane);
         lk_stage_wait();                                        // unit A has landed in buffer 0
         if (okB) pg_stage<L>(table, gB, tiles + PW, lane);
         GM_PG_BOUND(addA, ucA < 1)
@@ -620,7 +678,7 @@ __global__ __launch_bounds__(WAVE, pg4_min_waves(L, KCAP)) void k_hamming_scan_p
             GM_PG_GROUP(GW, gA + 1)
         }
         if (!okB) break;
-        okA = pg_next<CUT>(P, ch, it, gA, ngA, addA, ucA);
+        okA = pg4_next<CUT>(P, ch, D, it, gA, ngA, addA, ucA, lane);
         lk_stage_wait();                                        // unit B has landed in buffer 1
         if (okA) pg_stage<L>(table, gA, tiles, lane);
         GM_PG_BOUND(addB, ucB < 1)
@@ -634,7 +692,7 @@ __global__ __launch_bounds__(WAVE, pg4_min_waves(L, KCAP)) void k_hamming_scan_p
 #undef GM_PG_BOUND
     while (Q.tail - Q.head > 0) {
         GM_PG_STAT(4, 1);
-        pg4_round<KCAP>(Q, lane, recs, thr0, cut_id, qv, list GM_PG_STARG);
+        pg4_round<KCAP>(Q, lane, recs, thr0, cut_id, list GM_PG_STARG);
     }
 #ifdef GM_PG_STATS
     if (lane == 0) {
@@ -760,61 +818,90 @@ __global__ void k_merge_hits(gm_pg_blocks P, const uint32_t* __restrict__ lists,
     list.store(k, qi, ids, dists, counts, nearest != 0);
 }
 
-// K1P merge for the LDS-list scan (k_hamming_scan_pg3): folds the n_lists raw lists keys[list][row][KCAP] of a row --
-// a pair that several blocks found sits in several of them with the same key: insert_unique -- into the top k.  SPLIT
-// adjacent lanes per row, as k_merge_hits; a row whose merged list is not full (or that took the id cut-off and is
-// short) is listed in `inc`.  There is no overflow: the lists are exact top-k lists of what their workgroups saw.
+// K1P merge for the register-list scan (k_hamming_scan_pg4): one thread per row folds the row's n_lists raw lists
+// keys[list][row][KCAP] -- each the image of a SORTED register list: keys + 1 ascending, unused leading slots 0, empty
+// slots 0xffffffff -- by two-way merges in registers: ten steps, each takes the smaller head (both when they are equal: a
+// pair that several blocks found sits in several lists with the same key) and shifts the list(s) it came from by
+// predicated moves.  ~21 KCAP VALU ops per list and row; the first version -- SPLIT lanes per row, insert_unique per key,
+// a shuffle tree -- spent 2 400 lane-ops per row and 237 us on PAO1's first level, memory would allow ~70.
+// A row whose merged list is not full (or that took the id cut-off and is short) is listed in `inc`.  There is no
+// overflow: the lists are exact top-k lists of what their workgroups saw.
 template <int KCAP, int SPLIT>
 __global__ void k_merge_pg3(const uint32_t* __restrict__ keys, int n_lists, int64_t n_q, int k,
                             int32_t* __restrict__ ids, int32_t* __restrict__ dists, int32_t* __restrict__ counts,
                             int nearest, int32_t* __restrict__ inc, int* __restrict__ inc_count,
-                            int* __restrict__ over_count, int* __restrict__ chist, const uint8_t* __restrict__ cflag, const int* __restrict__ n_dev) {
+                            int* __restrict__ over_count, int* __restrict__ chist, const uint8_t* __restrict__ cflag,
+                            const int* __restrict__ n_dev) {
+    static_assert(SPLIT == 1, "one thread per row");
     const int64_t n_stride = n_q;      // row stride of the raw lists: the host's number
     if (n_dev != nullptr && *n_dev < n_q) n_q = *n_dev;      // (speculative follow-ups: launched for an upper bound)
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int sub = (int)(t % SPLIT);
-    const int64_t qi_raw = t / SPLIT;
+    const int64_t qi_raw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = qi_raw < n_q;
-    const int64_t qi = valid ? qi_raw : 0;      // (whole groups stay in the shuffles)
-    // A raw list IS the image of a sorted register list (unused leading slots 0, keys + 1 ascending, empty slots
-    // 0xffffffff): a lane takes its first list over as it stands and inserts only the others' keys -- ascending, so a
-    // list is done at its first key that cannot beat the current k-th (with one list per block and SPLIT >= the number of
-    // blocks no insert happens before the shuffle tree: PAO1's first-level merge 255 -> see profiles/r04/NOTES.md).
+    const int64_t qi = valid ? qi_raw : 0;
+    constexpr uint32_t NONE = RegList<KCAP>::EMPTY;
+    const int lead = KCAP - k;      // unused leading slots of a raw list
+    uint32_t a[KCAP];               // the merged keys so far, ascending, NONE-padded
+#pragma unroll
+    for (int i = 0; i < KCAP; ++i) a[i] = NONE;
+    // a list's rows of this workgroup are one contiguous run of blockDim.x * KCAP words: fetched with coalesced dword loads
+    // into LDS (a thread reading its own 4 KCAP bytes directly spreads every load instruction of a wave over 20 lines: S1's
+    // merge 62 -> 102 us when the lanes per row went from 4 to 1) and read back row by row
+    __shared__ uint32_t s_in[256 * KCAP];
+    const int64_t row0 = (int64_t)blockIdx.x * blockDim.x;
+    const int64_t rows_here = n_stride - row0 < (int64_t)blockDim.x ? n_stride - row0 : (int64_t)blockDim.x;
+    const int n_words = (int)rows_here * KCAP;
+    for (int l = 0; l < n_lists; ++l) {
+        const uint32_t* __restrict__ in = keys + ((int64_t)l * n_stride + row0) * KCAP;
+        if (l > 0) __syncthreads();      // the previous list has been read
+#if defined(GM_PG_TIMING) && (GM_PG_TIMING & 8)      // timing build only (results WRONG): no list loads
+        for (int w = (int)threadIdx.x; w < n_words; w += (int)blockDim.x) s_in[w] = (uint32_t)(w * 2654435761u) | 1u;
+        (void)in;
+#else
+        for (int w = (int)threadIdx.x; w < n_words; w += (int)blockDim.x) s_in[w] = in[w];
+#endif
+        __syncthreads();
+        uint32_t b[KCAP];
+#pragma unroll
+        for (int i = 0; i < KCAP; ++i) b[i] = i < k && valid ? s_in[(int)threadIdx.x * KCAP + lead + i] : NONE;
+        if (l == 0) {
+#pragma unroll
+            for (int i = 0; i < KCAP; ++i) a[i] = b[i];
+            continue;
+        }
+        uint32_t out[KCAP];
+#pragma unroll
+        for (int s = 0; s < KCAP; ++s) {
+            const uint32_t m = a[0] < b[0] ? a[0] : b[0];
+            // (lane masks in SGPR pairs + explicit v_cndmask: left to itself the compiler turns the predicated shifts into
+            // "elements shifted so far" counters and a ten-way select per read -- 2 000 instead of 23 instructions a step)
+            const uint64_t ta = __builtin_amdgcn_ballot_w64(a[0] == m), tb = __builtin_amdgcn_ballot_w64(b[0] == m);
+            out[s] = m;
+#pragma unroll
+            for (int i = 0; i + 1 < KCAP; ++i) {
+                asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(a[i]) : "v"(a[i]), "v"(a[i + 1]), "s"(ta));
+                asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(b[i]) : "v"(b[i]), "v"(b[i + 1]), "s"(tb));
+            }
+            asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(a[KCAP - 1]) : "v"(a[KCAP - 1]), "v"(NONE), "s"(ta));
+            asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(b[KCAP - 1]) : "v"(b[KCAP - 1]), "v"(NONE), "s"(tb));
+        }
+#pragma unroll
+        for (int i = 0; i < KCAP; ++i) a[i] = out[i];
+    }
+    // -> the register-list image the rest of the pipeline stores from: unused leading slots 0, then the keys
     RegList<KCAP> list;
-    list.init(k, nullptr, 0);
-    if (sub < n_lists) {
-        const uint32_t* __restrict__ in = keys + ((int64_t)sub * n_stride + qi) * KCAP;
 #pragma unroll
-        for (int i = 0; i < KCAP; ++i) list.v[i] = in[i];
-    }
-    for (int l = sub + SPLIT; l < n_lists; l += SPLIT) {
-        const uint32_t* __restrict__ in = keys + ((int64_t)l * n_stride + qi) * KCAP;
-        uint32_t v[KCAP];
+    for (int i = 0; i < KCAP; ++i) list.v[i] = i < lead ? 0u : NONE;
 #pragma unroll
-        for (int i = 0; i < KCAP; ++i) v[i] = in[i];
-        bool more = true;
+    for (int i = 0; i < KCAP; ++i)
 #pragma unroll
-        for (int i = 0; i < KCAP; ++i) {
-            more = more && (v[i] == 0u || v[i] < list.v[KCAP - 1]);
-            if (more && v[i] != 0u) list.insert_unique(v[i] - 1u);
-        }
-    }
-#pragma unroll
-    for (int off = SPLIT / 2; off >= 1; off >>= 1) {
-        bool more = true;      // (the partner's keys ascend: it is done at its first key that cannot beat the k-th)
-#pragma unroll
-        for (int i = 0; i < KCAP; ++i) {
-            const uint32_t v = __shfl_down(list.v[i], off, SPLIT);
-            more = more && (v == 0u || v < list.v[KCAP - 1]);
-            if (sub < off && more && v != 0u) list.insert_unique(v - 1u);
-        }
-    }
+        for (int j = 0; j < KCAP; ++j)
+            if (j == i + lead) list.v[j] = a[i];      // (lead is wave-uniform: predicated moves, no dynamic register index)
     __shared__ int s_hist[24], s_over;
     if (threadIdx.x < 24) s_hist[threadIdx.x] = 0;
     if (threadIdx.x == 24) s_over = 0;
     __syncthreads();
-    const bool owner = sub == 0 && valid;
-    const bool full = list.v[KCAP - 1] != RegList<KCAP>::EMPTY;
+    const bool owner = valid;
+    const bool full = list.v[KCAP - 1] != NONE;
     // (a short row that took the id cut-off does not know all its neighbours at r: nothing about it is known)
     const bool unknown = owner && !full && cflag != nullptr && cflag[qi] != 0;
     int32_t entry = 0;
@@ -829,14 +916,41 @@ __global__ void k_merge_pg3(const uint32_t* __restrict__ keys, int n_lists, int6
         take = true;
         int c = 0;
 #pragma unroll
-        for (int s = 0; s < KCAP; ++s) c += (list.v[s] != 0u && list.v[s] != RegList<KCAP>::EMPTY) ? 1 : 0;
+        for (int s = 0; s < KCAP; ++s) c += (list.v[s] != 0u && list.v[s] != NONE) ? 1 : 0;
         atomicAdd(&s_hist[c < 23 ? c : 23], 1);      // (the host sizes the prefix re-scan from this)
     }
     gm_block_append(take, entry, inc, inc_count);      // (contains the barrier that orders the LDS counters)
     if (threadIdx.x < 24 && s_hist[threadIdx.x] != 0) atomicAdd(&chist[threadIdx.x], s_hist[threadIdx.x]);
     if (threadIdx.x == 24 && s_over != 0) atomicAdd(over_count, s_over);
-    if (!owner) return;
-    list.store(k, qi, ids, dists, counts, nearest != 0);
+    // the rows' results leave through LDS as well: ids / dists of the workgroup's rows are one contiguous run each
+    if (nearest != 0) {
+        if (owner) list.store(k, qi, ids, dists, counts, true);
+        return;
+    }
+    const int64_t rows_valid = n_q - row0 < (int64_t)blockDim.x ? n_q - row0 : (int64_t)blockDim.x;      // (may be <= 0)
+    const int n_out = rows_valid > 0 ? (int)rows_valid * k : 0;
+    int cnt = 0;
+    for (int pass = 0; pass < 2; ++pass) {      // ids, then distances
+        __syncthreads();
+#pragma unroll
+        for (int sI = 0; sI < KCAP; ++sI) {
+            const int j = sI - lead;
+            if (j >= 0) {
+                const bool ok = list.v[sI] != NONE;
+                const uint32_t key = list.v[sI] - 1u;
+                s_in[(int)threadIdx.x * k + j] = ok ? (pass == 0 ? (key & ID_MASK) : (key >> ID_BITS)) : 0xffffffffu;
+                if (pass == 0) cnt += ok ? 1 : 0;
+            }
+        }
+        __syncthreads();
+        int32_t* __restrict__ dst = (pass == 0 ? ids : dists) + row0 * k;
+#if defined(GM_PG_TIMING) && (GM_PG_TIMING & 16)      // timing build only (results WRONG): no result stores
+        if (n_out < 0) dst[0] = 0;
+#else
+        for (int w = (int)threadIdx.x; w < n_out; w += (int)blockDim.x) dst[w] = (int32_t)s_in[w];
+#endif
+    }
+    if (owner) counts[qi] = cnt;
 }
 
 // K1P prefix re-scan: fold the n_lists raw lists of a row (the K1L segment lists of the scanned pool prefix and, last,

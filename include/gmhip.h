@@ -27,11 +27,15 @@
  *   - neighbour lists are exact and ordered by (distance ascending, db index ascending); rows with
  *     fewer than k db points are padded with -1 and counts[] holds the valid length
  *   - *_dev variants take DEVICE pointers (HBM-resident inputs/outputs) and a hipStream_t passed as
- *     void*; they enqueue on that stream and return without waiting for the results.  (Large Hamming pools go
- *     through the pigeonhole-partitioned scan, which waits for the stream inside the call: once for the counters of the
- *     rows that need a follow-up scan -- the host sizes that follow-up from them -- and, only when there are such
- *     rows, once or twice more to see what the follow-up left; the waits poll a word in pinned host memory that a small
- *     kernel writes.  The first call on a handle also builds the block-sorted pool copies.)
+ *     void*; they enqueue on that stream and return without waiting for the RESULTS.  Large Hamming pools go through the
+ *     pigeonhole-partitioned scan, whose follow-up launches (the rows a level leaves short) are sized from row counts the
+ *     device produces.  A query of the same shape (n_q, k) as the handle's previous one takes those counts from that
+ *     query (upper bounds; every kernel clamps to the device's own count), enqueues EVERYTHING without a host round trip
+ *     between the kernels, and looks at the counts once, after the last launch, through words a small kernel writes to
+ *     pinned host memory -- so the call returns when the counts have arrived (the scans are done by then; the tail is
+ *     still running), not when it was enqueued; a count above its bound makes the query run again the waiting way.  The
+ *     first query of a shape waits for each count as it is needed (once per level that leaves rows, once or twice more for
+ *     what the re-scans leave) and builds the block-sorted pool copies.  gm_last_speculation() tells which it was.
  *   - one host thread per handle; handles are independent; one handle = one GPU (multi-GPU is one
  *     process per GPU)
  *   - there is NO CPU fallback: without a gfx950 device every compute entry point fails with
@@ -266,12 +270,12 @@ int gm_set_variant(gm_index* idx, int variant);
  *   "pg_msplit": lanes per candidate in K1P's merge (0 = choose, 1, 2, 4);
  *   "pg_hit": K1P's hit path: 0 = every hit is stored to a hit buffer in HBM and the merge selects (k_hamming_scan_pg);
  *   2 = every lane keeps its candidate's k best keys in registers, hits reach it through a mailbox in LDS and the scan
- *   writes k keys per list (k_hamming_scan_pg4); 1 (default) = chosen per cascade level (register lists for k <= 10 on
+ *   writes k keys per list (k_hamming_scan_pg4); 1 (default) = chosen per cascade level (register lists for k <= 20 on
  *   >= 400 000 candidates);
  *   "pg_spec": 1 (default) = a query of the same shape (n_q, k) as the handle's previous one sizes the follow-up launches of
- *   the rows each K1P level leaves short from that query's counts (+ an eighth + 1024, the lists padded with duplicate
- *   rows) instead of waiting for the device's counts, and checks the counts once after everything is enqueued (a level
- *   that left more runs the query again the waiting way); 0 = always wait (A/B, tests);
+ *   the rows each K1P level leaves short from that query's counts (+ a quarter + 2048 as an upper bound; the kernels clamp
+ *   to the device's counts) instead of waiting for them, and checks the counts once after everything is enqueued (a
+ *   level that left more runs the query again the waiting way); 0 = always wait (A/B, tests);
  *   "pg_per": target buckets per K1P workgroup (0 = choose: 16 / pg_sub, all of them with register lists);
  *   ("pg_debug", a round-3 knob that made the scan skip work for timing and its results WRONG, is gone from the library:
  *   it answers GM_ERR_ARG; such timings are separate builds, -DGM_PG_TIMING in guidemaker_amd/csrc/Makefile's CXXFLAGS);
