@@ -55,7 +55,10 @@ template <int L>
 int launch_pg_cfg(gm_index* idx, const gm_pg_blocks* blocks, const gm_pg_chunk* chunks, const int* c_begin,
                   const int* c_end, int64_t grid, int64_t n_q, int k, int thr0, uint32_t* lists, hipStream_t st) {
     (void)idx;
-    const size_t lds = gm::pg_lds_bytes(L);
+    size_t lds = gm::pg_lds_bytes(L);
+#ifdef GM_PG_LDS_PAD      // occupancy experiments (timing builds): LDS bytes per workgroup, e.g. 6826 = 6 waves per SIMD, 10240 = 4
+    if (lds < (size_t)GM_PG_LDS_PAD) lds = (size_t)GM_PG_LDS_PAD;
+#endif
     if (blocks->cut_id != 0xffffffffu)
         hipLaunchKernelGGL((gm::k_hamming_scan_pg<L, true>), dim3((unsigned)grid), dim3(gm::WAVE), lds, st, *blocks, chunks,
                            c_begin, c_end, idx->d_q, n_q, k, thr0, lists);

@@ -474,7 +474,7 @@ def test_optional_gpu_config_block(tmp_path, monkeypatch):
     monkeypatch.delenv("GM_SHARD_CANDIDATES", raising=False)
     with open(guidemaker_amd.CONFIG_PATH) as fh:
         cfg = yaml.safe_load(fh)
-    assert cfg["GPU"] == {"DEVICE": 0, "SHARD_CANDIDATES": False}
+    assert cfg["GPU"] == {"DEVICE": 0, "SHARD_CANDIDATES": False, "CONTROL_FAIL_FAST": False}
     calls = {}
 
     class FakeIndex:

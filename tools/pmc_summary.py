@@ -41,17 +41,36 @@ def short_name(name):
     return s[:120]
 
 
-def collect(root, dispatch_min_ns=0.0):
+def collect(root, dispatch_min_ns=0.0, split=()):
+    """split: substrings of kernel names whose dispatches are told apart by their ORDER inside a query (since the query's
+    first kernel, k_to_planes): 'k_leven_part_bs<23, 10, false> #0' is the first partitioned level of every query, '#1'
+    the second -- the same instantiation launched twice per step with different work."""
     per = collections.defaultdict(lambda: collections.defaultdict(list))
     dur = collections.defaultdict(list)
     regs = {}
     for path in sorted(glob.glob(os.path.join(root, "**", "*_counter_collection.csv"), recursive=True)):
         seen = set()
         with open(path, newline="") as fh:
-            for row in csv.DictReader(fh):
+            rows = list(csv.DictReader(fh))
+        order = {}      # Dispatch_Id -> occurrence index of its kernel inside its query
+        if split:
+            first = {}
+            for row in rows:
+                first.setdefault(int(row["Dispatch_Id"]), short_name(row["Kernel_Name"]))
+            seen_in_query = collections.Counter()
+            for did in sorted(first):
+                if "k_to_planes" in first[did]:
+                    seen_in_query.clear()
+                if any(t in first[did] for t in split):
+                    order[did] = seen_in_query[first[did]]
+                    seen_in_query[first[did]] += 1
+        if True:
+            for row in rows:
                 if int(row["End_Timestamp"]) - int(row["Start_Timestamp"]) < dispatch_min_ns:
                     continue      # e.g. one-pair spot-check launches of the same kernel
                 k = short_name(row["Kernel_Name"])
+                if int(row["Dispatch_Id"]) in order:
+                    k += " #%d" % order[int(row["Dispatch_Id"])]
                 per[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
                 regs[k] = {"vgpr": int(row["VGPR_Count"]), "sgpr": int(row["SGPR_Count"]),
                            "lds_bytes": int(row["LDS_Block_Size"]), "scratch": int(row["Scratch_Size"]),
@@ -81,6 +100,8 @@ def main():
     ap.add_argument("--stats-out")
     ap.add_argument("--min-ns", type=float, default=0.0, help="drop kernels whose mean dispatch is shorter")
     ap.add_argument("--dispatch-min-ns", type=float, default=0.0, help="ignore single dispatches shorter than this")
+    ap.add_argument("--split-kernel", action="append", default=[],
+                    help="kernel-name substring: tell its dispatches apart by their order inside a query (see collect)")
     ap.add_argument("--counters-json", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                                             "profiles", "counters.json"))
     ap.add_argument("--register", help="workload key: record the dominant kernel's counters in --counters-json, where "
@@ -91,7 +112,7 @@ def main():
                                          "(pairs evaluated, positions per block) is registered with the counters, and "
                                          "bench.py uses the counters only for a live launch of the same shape")
     a = ap.parse_args()
-    table = collect(a.root, a.dispatch_min_ns)
+    table = collect(a.root, a.dispatch_min_ns, tuple(a.split_kernel))
     table = {k: v for k, v in table.items() if v["mean_ns_in_pmc_passes"] >= a.min_ns}
     with open(a.out, "w") as fh:
         json.dump({"_source": a.root, "_note": __doc__.split("\n\n")[2].replace("\n", " "), "kernels": table},
