@@ -424,14 +424,20 @@ struct gm_pigeon {
     int Lp[GM_PG_MAXB]{};              // positions the scan evaluates under block b = L - skiplen[b] (>= 10)
     int64_t bgrid[GM_PG_MAXB]{};       // upper bound of block b's chunk count
     int64_t last_bpairs[GM_PG_MAXB]{}; // pairs block b's part of the last launch evaluated
-    int tune_sub = 2;                  // workgroups per expansion chunk (gm_set_param "pg_sub")
+    int tune_sub = 0;                  // workgroups per expansion chunk (gm_set_param "pg_sub"); 0 = choose: 2 on the first
+                                       // cascade level, 8 (two target buckets per workgroup, up to six workgroups per chunk)
+                                       // on the deeper ones: their few, uneven chunks want finer work items (PAO1 2.99 ->
+                                       // 2.85 ms/step; first levels of 100 k .. 300 k candidates lose 3 .. 5 % with 8)
+    bool deep = false;                 // the state of a cascade level >= 1 (gm_pg_inherit)
     int tune_per = 0;                  // target buckets per workgroup, 0 = 16 / pg_sub (gm_set_param "pg_per")
     int tune_hit = 1;                  // hit path (gm_set_param "pg_hit"): 0 = hit buffer in HBM (k_hamming_scan_pg), 2 = register lists
                                        // (k_hamming_scan_pg4), 1 = chosen per level (pg_use_reglists)
     bool hit_reg = false;              // the hit path of the launch being prepared / merged
     int tune_layout = 0;               // experiments: forced layout, decimal digit pairs (len, radius) per block
     int tune_gap = 0;                  // table gaps: 0 = choose, 1 = common gap (one launch), 2 = per-block gaps
-    int tune_run = 128;                // chunk-table entries per XCD run (gm_set_param "pg_run")
+    int tune_run = 0;                  // chunk-table entries per XCD run (gm_set_param "pg_run"); 0 = choose: 128, or 32 with
+                                       // register lists (one workgroup per chunk: a run of 32 covers the chunks of ~10 buckets;
+                                       // PAO1 / S3 level 0 -2 .. -4 %, S1 equal: profiles/r04/NOTES.md)
     int tune_msplit = 0;               // lanes per candidate in the merge, 0 = choose (gm_set_param "pg_msplit")
     int tune_sample = 1;               // 0 = the layout planner uses the Poisson model instead of a scanned sample (gm_set_param "pg_sample")
     int tune_prefix = 1;               // 0 = the incomplete rows go straight to the plain re-scan (gm_set_param "pg_prefix")
@@ -949,6 +955,7 @@ void gm_pg_inherit(gm_index* idx, const gm_pigeon* parent) {
     pg->p_match = parent->p_match;
     for (int b = 0; b < 4; ++b) pg->base_freq[b] = parent->base_freq[b];
     pg->tune_sub = parent->tune_sub;
+    pg->deep = true;
     pg->tune_per = parent->tune_per;
     pg->tune_hit = parent->tune_hit;
     pg->tune_run = parent->tune_run;
@@ -980,7 +987,7 @@ int gm_pg_set_param(gm_index* idx, const char* name, int value) {
     }
     if (!idx->pg) idx->pg = new gm_pigeon();
     if (std::strcmp(name, "pg_sub") == 0) {
-        if (value < 1 || value > 19) return gm_fail(GM_ERR_ARG, "pg_sub: 1..19");
+        if (value < 0 || value > 19) return gm_fail(GM_ERR_ARG, "pg_sub: 0 (choose), 1..19");
         idx->pg->tune_sub = value;
         return GM_OK;
     }
@@ -1026,7 +1033,7 @@ int gm_pg_set_param(gm_index* idx, const char* name, int value) {
         return GM_OK;
     }
     if (std::strcmp(name, "pg_run") == 0) {
-        if (value < 1 || value > 65536) return gm_fail(GM_ERR_ARG, "pg_run: 1..65536");
+        if (value < 0 || value > 65536) return gm_fail(GM_ERR_ARG, "pg_run: 0 (choose), 1..65536");
         idx->pg->tune_run = value;
         return GM_OK;
     }
@@ -1229,7 +1236,8 @@ static bool pg_use_reglists(const gm_pigeon* pg, int64_t n_q, int k) {
 static void pg_geometry(gm_pigeon* pg) {
     // (register lists: every chunk's target buckets in ONE workgroup -- a list sees all the block's hits of its candidates,
     // its bound tightens three times sooner, and the merge has a third of the lists to fold)
-    const int per_target = pg->tune_per > 0 ? pg->tune_per : (pg->hit_reg ? 4096 : (16 + pg->tune_sub - 1) / pg->tune_sub);
+    const int sub = pg->tune_sub > 0 ? pg->tune_sub : (pg->deep ? 8 : 2);
+    const int per_target = pg->tune_per > 0 ? pg->tune_per : (pg->hit_reg ? 4096 : (16 + sub - 1) / sub);
     int cap_sub = 6;
     for (;;) {
         int lists = 0;
@@ -1465,7 +1473,7 @@ int gm_pg_scan(gm_index* idx, int64_t n_q, int k, int kcap, hipStream_t st) {
     blocks.cut_id = pg->cut_id;
     blocks.cflag = pg->cflag;
     const int thr0 = gm_pg_radius(idx) + 1;      // accept d < thr0, i.e. d <= r
-    blocks.run = pg->tune_run;
+    blocks.run = pg->tune_run > 0 ? pg->tune_run : (pg->hit_reg ? 32 : 128);
     const int64_t unit = 8 * (int64_t)blocks.run;      // the kernel's entry mapping permutes whole units
     // one launch per run of consecutive blocks whose copies keep the same number of positions
     for (int b0 = 0; b0 < pg->B;) {

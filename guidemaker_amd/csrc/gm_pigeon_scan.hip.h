@@ -428,37 +428,53 @@ struct Pg4Queue {
 
 // one round of the flush: the first <= 64 queued hits are resolved, one per lane, and delivered to their candidates'
 // owner lanes
-template <int KCAP>
-__device__ __forceinline__ void pg4_round(Pg4Queue& Q, int lane, const uint4* __restrict__ recs, int thr0, uint32_t cut_id,
-                                          RegList<KCAP>& list
-#ifdef GM_PG_STATS
-                                          , unsigned long long (&st_)[8]
-#endif
-                                          ) {
+// A round in two halves, so that the record gather of one round is in flight while the next groups are evaluated
+// (pg4_pipelined): ISSUE takes <= 64 entries off the ring and starts their gathers; FINISH -- at the next trigger, or at the
+// end -- turns the records into keys and delivers them.  The bound a lane evaluates under lags one round (conservative: the key
+// test at delivery is what decides).
+struct Pg4Pending {
+    int n;            // entries taken (wave-uniform); 0 = nothing pending
+    int cl;           // the entry's candidate lane
+    uint32_t tx, ty, tz;      // the target's record: planes, pool id
+};
+__device__ __forceinline__ void pg4_round_issue(Pg4Queue& Q, int lane, const uint4* __restrict__ recs, Pg4Pending& R) {
     const int avail = Q.tail - Q.head;
-    const int n = avail < WAVE ? avail : WAVE;
+    R.n = avail < WAVE ? avail : WAVE;
     const int s = (Q.head + lane) & (PG_QCAP - 1);
-    const bool mine = lane < n;
-    uint32_t pos = 0u;
-    int cl = 0;
-    if (mine) {
-        pos = Q.pos[s];
-        cl = (int)Q.ln[s];
-    }
-    Q.head += n;
-    uint32_t x = PG4_NONE;
-    if (mine) {
-        const uint2 cq = Q.qpl[cl];
+    R.cl = 0;
+    R.tx = R.ty = R.tz = 0u;
+    if (lane < R.n) {
+        const uint32_t pos = Q.pos[s];
+        R.cl = (int)Q.ln[s];
 #if defined(GM_PG_TIMING) && (GM_PG_TIMING & 4)      // timing build only (results WRONG): no record gather
-        const uint4 t = make_uint4(pos, pos * 31u, pos * 977u & ID_MASK, 0u);
+        R.tx = pos;
+        R.ty = pos * 31u;
+        R.tz = pos * 977u & ID_MASK;
 #else
         const uint4 t = recs[pos];
+        R.tx = t.x;
+        R.ty = t.y;
+        R.tz = t.z;
 #endif
-        const uint32_t mism = ((cq.x ^ t.x) | (cq.y ^ t.y)) & 0x7fffffffu;      // one bit per mismatching position
+    }
+    Q.head += R.n;
+}
+template <int KCAP>
+__device__ __forceinline__ void pg4_round_finish(Pg4Queue& Q, int lane, Pg4Pending& R, int thr0, uint32_t cut_id, RegList<KCAP>& list
+#ifdef GM_PG_STATS
+                                                 , unsigned long long (&st_)[8]
+#endif
+                                                 ) {
+    const int n = R.n, cl = R.cl;
+    R.n = 0;
+    uint32_t x = PG4_NONE;
+    if (lane < n) {
+        const uint2 cq = Q.qpl[cl];
+        const uint32_t mism = ((cq.x ^ R.tx) | (cq.y ^ R.ty)) & 0x7fffffffu;      // one bit per mismatching position
         const int d = __popc(mism);
         const uint32_t cut_c = (cq.x >> 31) != 0u ? cut_id : 0xffffffffu;      // id cut-off: at distance r only ids below it count
-        const uint32_t key1 = (((uint32_t)d << ID_BITS) | t.z) + 1u;
-        if (!(d == thr0 - 1 && t.z >= cut_c) && key1 < Q.kth[cl]) x = key1;
+        const uint32_t key1 = (((uint32_t)d << ID_BITS) | R.tz) + 1u;
+        if (!(d == thr0 - 1 && R.tz >= cut_c) && key1 < Q.kth[cl]) x = key1;
     }
 #if defined(GM_PG_TIMING) && (GM_PG_TIMING & 1)      // timing build only (results WRONG): nothing is delivered
     x = PG4_NONE;
@@ -569,6 +585,11 @@ __device__ __forceinline__ bool pg4_next(const gm_pg_blocks& P, const gm_pg_chun
 #ifndef GM_PG4_W20
 #define GM_PG4_W20 4      /* ... with a 20-key list */
 #endif
+// the gather of a round stays in flight across the next groups where five more VGPRs fit under the occupancy the kernel has
+#ifndef GM_PG4_PIPE
+#define GM_PG4_PIPE 1
+#endif
+__host__ __device__ constexpr bool pg4_pipelined(int L, int KCAP) { return GM_PG4_PIPE != 0 && L <= 14 && KCAP == 10; }
 __host__ __device__ constexpr int pg4_min_waves(int L, int KCAP) { return L > 20 ? 1 : (KCAP <= 1 ? 8 : (KCAP <= 10 ? GM_PG4_W10 : GM_PG4_W20)); }
 template <int L, bool CUT, int KCAP>
 __global__ __launch_bounds__(WAVE, pg4_min_waves(L, KCAP)) void k_hamming_scan_pg4(
@@ -619,6 +640,7 @@ __global__ __launch_bounds__(WAVE, pg4_min_waves(L, KCAP)) void k_hamming_scan_p
     int thr = valid ? thr0 : 0;              // accept d < thr
 #endif
     uint32_t Tb[5];
+    Pg4Pending R{0, 0, 0u, 0u, 0u};
     PgIter it{ch.e_lo - 1, 0, 0, 0, 0, 0};
     Pg4Desc<CUT> D;
     D.load(P, ch, ch.e_lo, lane);
@@ -659,7 +681,13 @@ __global__ __launch_bounds__(WAVE, pg4_min_waves(L, KCAP)) void k_hamming_scan_p
             }                                                                                                  \
             Q.tail += __builtin_popcountll(bal);                                                               \
             if (Q.tail - Q.head >= WAVE) {                                                                     \
-                pg4_round<KCAP>(Q, lane, recs, thr0, cut_id, list GM_PG_STARG);                            \
+                if (pg4_pipelined(L, KCAP)) {                                                                  \
+                    if (R.n > 0) pg4_round_finish<KCAP>(Q, lane, R, thr0, cut_id, list GM_PG_STARG);           \
+                    pg4_round_issue(Q, lane, recs, R);                                                         \
+                } else {                                                                                       \
+                    pg4_round_issue(Q, lane, recs, R);                                                         \
+                    pg4_round_finish<KCAP>(Q, lane, R, thr0, cut_id, list GM_PG_STARG);                        \
+                }                                                                                              \
                 const int nt = list.v[KCAP - 1] == PG4_NONE ? thr : (int)((list.v[KCAP - 1] - 1u) >> ID_BITS) + 1; \
                 if (nt < thr) thr = nt;                                                                        \
                 cur = -1;                                                                                      \
@@ -690,9 +718,11 @@ __global__ __launch_bounds__(WAVE, pg4_min_waves(L, KCAP)) void k_hamming_scan_p
     }
 #undef GM_PG_GROUP
 #undef GM_PG_BOUND
+    if (R.n > 0) pg4_round_finish<KCAP>(Q, lane, R, thr0, cut_id, list GM_PG_STARG);
     while (Q.tail - Q.head > 0) {
         GM_PG_STAT(4, 1);
-        pg4_round<KCAP>(Q, lane, recs, thr0, cut_id, list GM_PG_STARG);
+        pg4_round_issue(Q, lane, recs, R);
+        pg4_round_finish<KCAP>(Q, lane, R, thr0, cut_id, list GM_PG_STARG);
     }
 #ifdef GM_PG_STATS
     if (lane == 0) {

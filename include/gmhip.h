@@ -250,9 +250,10 @@ int gm_timing_read(gm_index* idx, double* ms_out, int max_n);
  *   Levenshtein: 2 = per-pair Myers kernel K2L; 1 = plane-based kernel (also used for L < 10 and k > 20). */
 int gm_set_variant(gm_index* idx, int variant);
 /* Named tuning knobs (experiments; results are identical for every value).
- *   "pg_sub" (1..19, default 2): workgroups the target buckets of one expansion chunk of the pigeonhole-partitioned
- *   scan are split over (more = shorter work items and more hit lists per candidate);
- *   "pg_run" (default 128): consecutive chunk-table entries of that scan executed on the same XCD;
+ *   "pg_sub" (0 = choose: 2 on the first cascade level, 8 on the deeper ones; 1..19): workgroups the target buckets of one
+ *   expansion chunk of the pigeonhole-partitioned scan are split over on the hit-buffer path (more = shorter work items and
+ *   more hit lists per candidate);
+ *   "pg_run" (0 = choose: 128, 32 on the register-list path): consecutive chunk-table entries of that scan executed on the same XCD;
  *   "pg_layout": force a layout of that scan, decimal digit pairs (bases, radius) per block, e.g. 826161 = blocks of
  *   8, 6, 6 bases with the two-, one-, one-substitution neighbourhoods (0 = let the planner choose);
  *   "pg_gap": 2 = every copy's table leaves out its own block up to the length of the most-visited block (one launch
