@@ -58,104 +58,110 @@ __global__ __launch_bounds__(1024) void k_cand_hist(const uint2* __restrict__ pl
 // and in the same pass the chunk table's geometry -- chunks per (block, bucket) entry = ceil(count / 64) x the
 // workgroups an entry's target buckets are split over, their exclusive offsets INSIDE the block (cbase) and the block's
 // total (btot) --; it leaves the histogram zeroed for the next query.  (Count and chunk sums travel through the scan as
-// one 64-bit word.)  k_chunk_starts then turns the totals into the blocks' chunk ranges.
+// one 64-bit word.)  The workgroup that finishes last turns the totals into the blocks' chunk ranges.
 struct PgSubArg {
     int n[GM_PG_MAXB];      // workgroups an entry's target buckets are split over, per block
 };
+__device__ __forceinline__ unsigned long long pg_offsets_word(unsigned c, unsigned ns) {
+    return (unsigned long long)c | ((unsigned long long)((c + 63u) / 64u * ns) << 32);
+}
 __global__ __launch_bounds__(1024) void k_cand_offsets(PgKeyArg K, PgSubArg nsub, int* __restrict__ hist,
                                                        int* __restrict__ cursor, int* __restrict__ cbase,
-                                                       int* __restrict__ btot) {
-    __shared__ unsigned long long s[64];
-    const int tid = threadIdx.x;
+                                                       int* __restrict__ btot, int* __restrict__ ctr_words, int ctr_n_words,
+                                                       int* __restrict__ cstart, int* __restrict__ n_chunks) {
+    __shared__ unsigned long long s[16];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
-    const int e0 = K.ebase[b], nb = K.ebase[b + 1] - e0, ns = nsub.n[b];
-    const int per = (nb + 1023) / 1024;
-    const int lo = tid * per, hi = lo + per < nb ? lo + per : nb;
-    // (one workgroup per block: the kernel is a handful of waves and lives on memory latency -- a thread's <= 16 counts
-    // are fetched with all loads in flight, and written back the same way: 49 -> ~12 us for three 16 384-bucket blocks)
+    const int e0 = K.ebase[b], nb = K.ebase[b + 1] - e0;
+    const unsigned ns = (unsigned)nsub.n[b];
+    // One workgroup per block: a handful of waves living on memory latency.  Wave w owns the entries [w x span, (w + 1) x
+    // span); iteration i of a wave covers 64 CONSECUTIVE entries (one coalesced load / store per array -- a thread
+    // walking its own 16 consecutive entries made every store instruction 64 separate 4-byte writes: 36 us for three
+    // 16 384-bucket blocks), all loads of a wave in flight at once (<= 16 iterations: blocks of <= 7 bases).
+    const int iters = (nb + 1023) / 1024;
+    const int lo = wave * iters * 64;
     constexpr int PER_REG = 16;
-    const bool in_regs = per <= PER_REG;
+    const bool in_regs = iters <= PER_REG;
     int cnt[PER_REG];
     unsigned long long sum = 0;
     if (in_regs) {
 #pragma unroll
-        for (int i = 0; i < PER_REG; ++i) cnt[i] = lo + i < hi ? hist[e0 + lo + i] : 0;
-#pragma unroll
         for (int i = 0; i < PER_REG; ++i) {
-            const unsigned c = (unsigned)cnt[i];
-            sum += (unsigned long long)c | ((unsigned long long)((c + 63u) / 64u * (unsigned)ns) << 32);
+            const int v = lo + i * 64 + lane;
+            cnt[i] = i < iters && v < nb ? hist[e0 + v] : 0;
         }
+#pragma unroll
+        for (int i = 0; i < PER_REG; ++i) sum += pg_offsets_word((unsigned)cnt[i], ns);
     } else {
-        for (int v = lo; v < hi; ++v) {
-            const unsigned c = (unsigned)hist[e0 + v];
-            sum += (unsigned long long)c | ((unsigned long long)((c + 63u) / 64u * (unsigned)ns) << 32);
+        for (int i = 0; i < iters; ++i) {
+            const int v = lo + i * 64 + lane;
+            sum += pg_offsets_word(v < nb ? (unsigned)hist[e0 + v] : 0u, ns);
         }
     }
-    // inclusive scan over the 1024 threads: shuffles inside a wave, the 16 wave totals through LDS
-    unsigned long long inc = sum;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const unsigned long long t = __shfl_up(inc, d, 64);
-        if ((tid & 63) >= d) inc += t;
-    }
-    if ((tid & 63) == 63) s[tid >> 6] = inc;
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);      // the wave's total, in every lane
+    if (lane == 0) s[wave] = sum;
     __syncthreads();
-    if (tid < 64) {
-        unsigned long long w = tid < 16 ? s[tid] : 0ull;
+    unsigned long long carry = 0, total = 0;      // entries before this wave's range / of the whole block
 #pragma unroll
-        for (int d = 1; d < 16; d <<= 1) {
-            const unsigned long long t = __shfl_up(w, d, 64);
-            if (tid >= d) w += t;
+    for (int w = 0; w < 16; ++w) {
+        const unsigned long long t = s[w];
+        carry += w < wave ? t : 0ull;
+        total += t;
+    }
+    auto emit = [&](int i, int c) {
+        const int v = lo + i * 64 + lane;
+        const unsigned long long x = pg_offsets_word((unsigned)c, ns);
+        unsigned long long inc = x;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long t = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += t;
         }
-        if (tid < 16) s[32 + tid] = w;      // inclusive totals of waves 0 .. tid
-    }
-    __syncthreads();
-    const unsigned long long wave_before = (tid >> 6) ? s[32 + (tid >> 6) - 1] : 0ull;
-    const unsigned long long before = wave_before + inc - sum, total = s[32 + 15];
-    int run = (int)(unsigned)before, run_ch = (int)(before >> 32);
+        const unsigned long long before = carry + inc - x;
+        if (v < nb) {
+            K.coff[b][v] = (int)(unsigned)before;
+            cursor[e0 + v] = (int)(unsigned)before;
+            cbase[e0 + v] = (int)(before >> 32);
+            hist[e0 + v] = 0;
+        }
+        carry += __shfl(inc, 63, 64);
+    };
     if (in_regs) {
 #pragma unroll
-        for (int i = 0; i < PER_REG; ++i) {
-            if (lo + i < hi) {
-                const int v = lo + i, c = cnt[i];
-                K.coff[b][v] = run;
-                cursor[e0 + v] = run;
-                cbase[e0 + v] = run_ch;
-                hist[e0 + v] = 0;
-                run += c;
-                run_ch += (c + 63) / 64 * ns;
-            }
-        }
+        for (int i = 0; i < PER_REG; ++i)
+            if (i < iters) emit(i, cnt[i]);
     } else {
-        for (int v = lo; v < hi; ++v) {
-            const int c = hist[e0 + v];
-            K.coff[b][v] = run;
-            cursor[e0 + v] = run;
-            cbase[e0 + v] = run_ch;
-            hist[e0 + v] = 0;
-            run += c;
-            run_ch += (c + 63) / 64 * ns;
+        for (int i = 0; i < iters; ++i) {
+            const int v = lo + i * 64 + lane;
+            emit(i, v < nb ? hist[e0 + v] : 0);
         }
     }
-    if (tid == 1023) {
+    // The workgroup that finishes LAST turns the blocks' totals into their chunk ranges (ctr->cstart) and clears the
+    // caller's per-query counter words (a kernel of its own before: ~5 us per grouping for one wave of work); the ticket
+    // btot[GM_PG_MAXB] is zero on entry and left zero.
+    // (the totals cross workgroups as device-scope stores / loads, complete before the ticket is taken: a release fence
+    // at device scope would write the XCD's L2 back)
+    if (tid == 0) {
         K.coff[b][nb] = (int)(unsigned)total;
-        btot[b] = (int)(total >> 32);
+        __hip_atomic_store(&btot[b], (int)(total >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_last = atomicAdd(&btot[GM_PG_MAXB], 1) == (int)gridDim.x - 1 ? 1 : 0;
     }
-}
-
-// the chunk range of every block (ctr->cstart) and the total; also clears the per-query counters
-__global__ __launch_bounds__(64) void k_chunk_starts(const int* __restrict__ btot, int B, int* __restrict__ ctr_words,
-                                                     int ctr_n_words, int* __restrict__ cstart, int* __restrict__ n_chunks) {
-    for (int i = threadIdx.x; i < ctr_n_words; i += 64) ctr_words[i] = 0;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (s_last == 0) return;
+    for (int i = tid; i < ctr_n_words; i += 1024) ctr_words[i] = 0;
+    __syncthreads();
+    if (tid == 0) {
         int run = 0;
-        for (int b = 0; b < B; ++b) {
-            cstart[b] = run;
-            run += btot[b];
+        for (int bb = 0; bb < K.B; ++bb) {
+            cstart[bb] = run;
+            run += __hip_atomic_load(&btot[bb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        cstart[B] = run;
+        cstart[K.B] = run;
         *n_chunks = run;
+        btot[GM_PG_MAXB] = 0;
     }
 }
 
@@ -225,9 +231,10 @@ __global__ __launch_bounds__(1024) void k_cand_scatter(const uint2* __restrict__
 }
 
 
-// The launches of one grouping: histogram -> offsets (+ chunk geometry, chunks of <= 64 candidates x nsub.n[b] per bucket) ->
-// chunk ranges of the blocks (also clears the caller's counter words) -> scatter.  K.coff[b] (4^len + 1 ints), K.cperm[b]
-// (n_q), hist / cursor / cbase (K.ebase[B] ints; hist zeroed on entry and left zeroed), btot (GM_PG_MAXB ints).
+// The launches of one grouping: histogram -> offsets (+ chunk geometry, chunks of <= 64 candidates x nsub.n[b] per bucket, and
+// the chunk ranges of the blocks; also clears the caller's counter words) -> scatter.  K.coff[b] (4^len + 1 ints), K.cperm[b]
+// (n_q), hist / cursor / cbase (K.ebase[B] ints; hist zeroed on entry and left zeroed), btot (GM_PG_MAXB + 1 ints, the
+// last one -- the offsets kernel's ticket -- zeroed on entry and left zeroed).
 inline int gm_group_launch(const uint2* q, int64_t n_q, const PgKeyArg& K, const PgSubArg& nsub, int* hist, int* cursor, int* cbase,
                            int* btot, int* ctr_words, int ctr_n_words, int* cstart, int* n_chunks, int device, hipStream_t st, const int* n_dev = nullptr) {
     // tiles of 1024 candidates per workgroup: as many as leave ~128 workgroups
@@ -274,8 +281,8 @@ inline int gm_group_launch(const uint2* q, int64_t n_q, const PgKeyArg& K, const
         const size_t lds = runs[i].lds ? sizeof(int) * (size_t)(K.ebase[runs[i].hi] - K.ebase[runs[i].lo]) : 0;
         GM_LAUNCH_T(k_cand_hist, q, n_q, K, hist, runs[i].lds, runs[i].lo, runs[i].hi, n_dev);
     }
-    hipLaunchKernelGGL(k_cand_offsets, dim3(K.B), dim3(1024), 0, st, K, nsub, hist, cursor, cbase, btot);
-    hipLaunchKernelGGL(k_chunk_starts, dim3(1), dim3(64), 0, st, btot, K.B, ctr_words, ctr_n_words, cstart, n_chunks);
+    hipLaunchKernelGGL(k_cand_offsets, dim3(K.B), dim3(1024), 0, st, K, nsub, hist, cursor, cbase, btot, ctr_words, ctr_n_words, cstart,
+                       n_chunks);
     for (int i = 0; i < n_runs; ++i) {
         const size_t lds = runs[i].lds ? sizeof(int) * (size_t)(K.ebase[runs[i].hi] - K.ebase[runs[i].lo]) : 0;
         GM_LAUNCH_T(k_cand_scatter, q, n_q, K, cursor, runs[i].lds, runs[i].lo, runs[i].hi, n_dev);

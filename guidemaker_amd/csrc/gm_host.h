@@ -152,6 +152,7 @@ struct gm_lk_args {
     int k = 0;
     int n_seg = 1, tiles_per_seg = 0, seg_base = 0;
     const uint32_t* seed_keys = nullptr;
+    uint32_t seed_all = 0;        // != 0 (and seed_keys == nullptr): every candidate's bound is this key (k-th key + 1 format)
     uint32_t* out_keys = nullptr;
     int32_t *ids = nullptr, *dists = nullptr, *counts = nullptr;
     const uint2* q = nullptr;     // candidate planes (nullptr: idx->d_q)
@@ -207,14 +208,12 @@ int gm_pg_gather(gm_index* idx, int64_t n_inc, int k, bool nearest, const uint2*
 int gm_pg_scatter(gm_index* idx, int64_t n_inc, int k, bool nearest, int32_t* ids, int32_t* dists, int32_t* counts,
                   hipStream_t st);
 // prefix re-scan of the incomplete rows (gmhip.hip run_hamming_pigeon): fraction of the pool (in id order) that
-// almost surely holds the r + 1 neighbours such a row still needs (1.0: not worth it); the rows' partial K1P lists in
-// the raw list format of the K1L segment lists; fold segment lists + partial list into pg->ids2 / dists2 / counts2
-// (rows that stay short, and rows whose lists had overflowed, come out with count 0); collect those into pg->inc
+// almost surely holds the r + 1 neighbours such a row still needs (1.0: not worth it); gm_pg_merge_prefix folds the
+// prefix's segment lists into the ORIGINAL rows behind the neighbours they already hold (rows that stay short, and rows
+// whose lists had overflowed, come out with count 0 and become the new pg->inc, counted in ctr->n_bad)
 double gm_pg_prefix_fraction(const gm_index* idx, int k);
-int gm_pg_partial_keys(gm_index* idx, int64_t n_inc, int kcap, int k, bool nearest, const int32_t* ids, const int32_t* dists,
-                       const int32_t* counts, uint32_t* out_keys, hipStream_t st);
 int gm_pg_merge_prefix(gm_index* idx, int kcap, const uint32_t* keys, int n_lists, int64_t n_inc, int k, bool nearest,
-                       hipStream_t st);
+                       int32_t* ids, int32_t* dists, int32_t* counts, hipStream_t st);
 int gm_pg_collect_bad(gm_index* idx, int64_t n_inc, int need, bool nearest, hipStream_t st);
 int gm_pg_read_bad(gm_index* idx, int64_t* n_bad, hipStream_t st);
 // rows i of [0, n) with counts[i] < need -> pg->inc (compact; their number arrives with gm_pg_read_bad); the list itself

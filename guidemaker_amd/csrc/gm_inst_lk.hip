@@ -27,14 +27,14 @@ int launch_lk_cfg(gm_index* idx, const gm_lk_args& a, hipStream_t st) {
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)chunks, (unsigned)a.n_seg), dim3(gm::WAVE), lds, st, idx->d_onehot,
                        (int)idx->n_db, a.n_tiles > 0 ? a.n_tiles : (int)idx->n_lk_tiles, a.tiles_per_seg, a.seg_base, a.q ? a.q : idx->d_q, a.n_q, a.k,
-                       a.seed_keys, a.out_keys, a.ids, a.dists, a.counts, a.n_dev);
+                       a.seed_keys, a.out_keys, a.ids, a.dists, a.counts, a.n_dev, a.seed_all);
     HIP_TRY(hipGetLastError());
     return GM_OK;
 }
 
 template <int L, int KCAP, bool NEAREST>
 int launch_lk_seed(gm_index* idx, const gm_lk_args& a, hipStream_t st) {
-    return a.seed_keys ? launch_lk_cfg<L, KCAP, NEAREST, true>(idx, a, st)
+    return a.seed_keys || a.seed_all ? launch_lk_cfg<L, KCAP, NEAREST, true>(idx, a, st)
                        : launch_lk_cfg<L, KCAP, NEAREST, false>(idx, a, st);
 }
 

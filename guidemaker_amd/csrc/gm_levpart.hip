@@ -479,7 +479,7 @@ int gm_lp_prepare(gm_index* idx, int r, hipStream_t st) {
             hipMalloc(reinterpret_cast<void**>(&lp->hist), sizeof(int) * (size_t)n_ent) != hipSuccess ||
             hipMalloc(reinterpret_cast<void**>(&lp->cursor), sizeof(int) * (size_t)n_ent) != hipSuccess ||
             hipMalloc(reinterpret_cast<void**>(&lp->cbase), sizeof(int) * (size_t)n_ent) != hipSuccess ||
-            hipMalloc(reinterpret_cast<void**>(&lp->btot), sizeof(int) * GM_PG_MAXB) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&lp->btot), sizeof(int) * (GM_PG_MAXB + 1)) != hipSuccess ||
             hipMalloc(reinterpret_cast<void**>(&lp->gsum), sizeof(uint32_t) * (size_t)n_ent) != hipSuccess ||
             hipMalloc(&lp->ctr, sizeof(LpCounters)) != hipSuccess ||
             (lp->ctr_host == nullptr && hipHostMalloc(&lp->ctr_host, sizeof(LpCounters)) != hipSuccess)) {
@@ -488,6 +488,7 @@ int gm_lp_prepare(gm_index* idx, int r, hipStream_t st) {
         }
         std::memset(lp->ctr_host, 0, sizeof(LpCounters));
         if (hipMemsetAsync(lp->hist, 0, sizeof(int) * (size_t)n_ent, st) != hipSuccess ||
+            hipMemsetAsync(lp->btot, 0, sizeof(int) * (GM_PG_MAXB + 1), st) != hipSuccess ||      // (the offsets kernel's ticket)
             hipMemcpyAsync(lp->gsum, gsum.data(), sizeof(uint32_t) * gsum.size(), hipMemcpyHostToDevice, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess) {
             lp_free_pool(lp);

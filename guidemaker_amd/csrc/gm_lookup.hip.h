@@ -260,7 +260,7 @@ __global__ __launch_bounds__(WAVE, lk_min_waves(L, KCAP)) void k_hamming_knn_lk(
     const uint32_t* __restrict__ table, int n_db, int n_tiles, int tiles_per_seg, int seg_base,
     const uint2* __restrict__ q, int64_t n_q, int k, const uint32_t* __restrict__ seed_keys,
     uint32_t* __restrict__ out_keys, int32_t* __restrict__ ids, int32_t* __restrict__ dists,
-    int32_t* __restrict__ counts, const int* __restrict__ n_dev) {
+    int32_t* __restrict__ counts, const int* __restrict__ n_dev, uint32_t seed_all) {
     extern __shared__ __align__(16) uint32_t smem[];
     // (speculative follow-ups of K1P: the grid was sized for an upper bound of the rows; the count is on the device)
     const int64_t n_out = n_q;      // row stride of the segment lists: the host's number
@@ -289,8 +289,8 @@ __global__ __launch_bounds__(WAVE, lk_min_waves(L, KCAP)) void k_hamming_knn_lk(
     list.init(k, smem + 2 * TILE_W, lane);
     int thr_seed = L + 1;              // L + 1 accepts every distance until the list is full
     if constexpr (SEEDED && KCAP > 0) {
-        if (valid) {
-            const uint32_t top = seed_keys[qi * KCAP + (KCAP - 1)];
+        if (valid) {      // (seed_keys == nullptr: the same bound `seed_all` for every candidate -- K1P's guessed re-scans)
+            const uint32_t top = seed_keys != nullptr ? seed_keys[qi * KCAP + (KCAP - 1)] : seed_all;
             if (top != 0xffffffffu) thr_seed = (int)((top - 1u) >> ID_BITS);
         }
     }
@@ -364,37 +364,103 @@ __global__ void k_merge_lists(const uint32_t* __restrict__ keys, int n_seg, int6
     list.store(k, qi, ids, dists, counts, nearest != 0);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Folding raw k-lists that share no entry (segment lists of disjoint pool segments) without sorted inserts: a raw list
+// is ascending between a run of 0 (unused leading slots) and a run of EMPTY, i.e. bitonic once 0 reads as EMPTY; a
+// bitonic merger (log2 N stages of N / 2 min / max pairs in registers) sorts it, and two ascending lists a, b fold as
+// c[i] = min(a[i], b[N - 1 - i]) -- the N smallest of both, bitonic again -- + one more merger.  N = KCAP rounded up to
+// a power of two; 16 keys: 16 + 64 VALU ops per fold against ~30 per sorted insert x 10 keys.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int fold_width(int kcap) { return kcap <= 1 ? 1 : (kcap <= 2 ? 2 : (kcap <= 4 ? 4 : (kcap <= 8 ? 8 : (kcap <= 16 ? 16 : 32)))); }
+
+template <int N>
+__device__ __forceinline__ void fold_sort(uint32_t (&v)[N]) {      // bitonic (any rotation) -> ascending
+#pragma unroll
+    for (int j = N / 2; j >= 1; j >>= 1) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            if ((i & j) == 0) {
+                const uint32_t lo = v[i] < v[i | j] ? v[i] : v[i | j];
+                const uint32_t hi = v[i] < v[i | j] ? v[i | j] : v[i];
+                v[i] = lo;
+                v[i | j] = hi;
+            }
+        }
+    }
+}
+// raw list -> v (0, and every raw value below `min_raw`, reads as EMPTY), ascending
+template <int KCAP, int N>
+__device__ __forceinline__ void fold_load(uint32_t (&v)[N], const uint32_t* __restrict__ in, uint32_t min_raw) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = 0xffffffffu;
+#pragma unroll
+    for (int i = 0; i < KCAP; ++i) {
+        const uint32_t x = in[i];
+        v[i] = x < min_raw ? 0xffffffffu : x;
+    }
+    fold_sort<N>(v);
+}
+// acc, t ascending -> acc = the N smallest of both, ascending
+template <int N>
+__device__ __forceinline__ void fold_two(uint32_t (&acc)[N], const uint32_t (&t)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[i] = acc[i] < t[N - 1 - i] ? acc[i] : t[N - 1 - i];
+    fold_sort<N>(acc);
+}
+// the lists s = sub, sub + SPLIT, ... of row `row` (stride n_stride rows per list) folded by lane `sub` of SPLIT adjacent
+// lanes, then across the lanes (shuffle tree): lane sub == 0 ends with the N smallest raw values of all lists, ascending
+template <int KCAP, int SPLIT, int N>
+__device__ __forceinline__ void fold_lists(uint32_t (&acc)[N], const uint32_t* __restrict__ keys, int n_lists, int64_t n_stride,
+                                           int64_t row, int sub, uint32_t min_raw) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[i] = 0xffffffffu;
+    for (int s = sub; s < n_lists; s += SPLIT) {
+        uint32_t t[N];
+        fold_load<KCAP, N>(t, keys + ((int64_t)s * n_stride + row) * KCAP, min_raw);
+        fold_two<N>(acc, t);
+    }
+#pragma unroll
+    for (int off = SPLIT / 2; off >= 1; off >>= 1) {
+        uint32_t t[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) t[i] = __shfl_down(acc[i], off, SPLIT);
+        fold_two<N>(acc, t);
+    }
+}
+
 // k_merge_lists for FEW candidates and many segments (the re-scan of K1P's incomplete rows, controls): with one
 // thread per candidate the kernel is a handful of waves walking n_seg lists serially.  Here SPLIT adjacent lanes
-// share a candidate, lane s folds the segments s, s + SPLIT, ..., and a shuffle tree combines the partial lists.
+// share a candidate, lane s folds the segments s, s + SPLIT, ..., and a shuffle tree combines the partial lists
+// (fold_lists: bitonic folds, the segments share no entry).
 template <int KCAP, int SPLIT>
 __global__ void k_merge_lists_split(const uint32_t* __restrict__ keys, int n_seg, int64_t n_q, int k,
                                     int32_t* __restrict__ ids, int32_t* __restrict__ dists,
                                     int32_t* __restrict__ counts, int nearest, const int* __restrict__ n_dev = nullptr) {
+    constexpr int N = fold_width(KCAP);
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int sub = (int)(t % SPLIT);
     const int64_t qi_raw = t / SPLIT;
     const bool valid = qi_raw < n_q && (n_dev == nullptr || qi_raw < *n_dev);      // (n_q stays the row stride of the lists)
     const int64_t qi = valid ? qi_raw : 0;
-    RegList<KCAP> list;
-    list.init(k, nullptr, 0);
-    for (int s = sub; s < n_seg; s += SPLIT) {
-        const uint32_t* in = keys + ((int64_t)s * n_q + qi) * KCAP;
+    uint32_t acc[N];
+    fold_lists<KCAP, SPLIT, N>(acc, keys, n_seg, n_q, qi, sub, 1u);
+    if (sub != 0 || !valid) return;
+    if (nearest != 0) {
+        dists[qi] = acc[0] == 0xffffffffu ? -1 : (int32_t)((acc[0] - 1u) >> ID_BITS);
+        return;
+    }
+    int cnt = 0;
 #pragma unroll
-        for (int i = 0; i < KCAP; ++i) {
-            const uint32_t v = in[i];
-            if (v != 0u && v != RegList<KCAP>::EMPTY) list.insert(v - 1u);
+    for (int j = 0; j < KCAP; ++j) {
+        if (j < k) {
+            const bool ok = acc[j] != 0xffffffffu;
+            const uint32_t key = acc[j] - 1u;
+            ids[qi * k + j] = ok ? (int32_t)(key & ID_MASK) : -1;
+            dists[qi * k + j] = ok ? (int32_t)(key >> ID_BITS) : -1;
+            cnt += ok ? 1 : 0;
         }
     }
-#pragma unroll
-    for (int off = SPLIT / 2; off >= 1; off >>= 1) {
-#pragma unroll
-        for (int i = 0; i < KCAP; ++i) {
-            const uint32_t v = __shfl_down(list.v[i], off, SPLIT);
-            if (sub < off && v != 0u && v != RegList<KCAP>::EMPTY) list.insert(v - 1u);
-        }
-    }
-    if (sub == 0 && valid) list.store(k, qi, ids, dists, counts, nearest != 0);
+    counts[qi] = cnt;
 }
 
 // fold the per-block raw lists [n_lists][n_q][KCAP] of K2P into the top k: a target found under several blocks /

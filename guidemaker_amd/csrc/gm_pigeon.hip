@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void k_base_counts(const uint2* __restrict__ p
     if (threadIdx.x < 4) atomicAdd(&counts[threadIdx.x], (unsigned long long)s[threadIdx.x]);
 }
 
-#include "gm_group.hip.h"      // PgKeyArg, PgSubArg, k_cand_hist / k_cand_offsets / k_chunk_starts / k_cand_scatter, gm_group_launch
+#include "gm_group.hip.h"      // PgKeyArg, PgSubArg, k_cand_hist / k_cand_offsets / k_cand_scatter, gm_group_launch
 
 // sorted position i (key v = keys[i], pool row rows[i]) -> position bdesc[v].x * 64 + (i - raw_off[v]) of the padded copy
 __global__ __launch_bounds__(256) void k_scatter_recs(const uint2* __restrict__ planes, const uint32_t* __restrict__ keys,
@@ -252,30 +252,6 @@ __global__ __launch_bounds__(256) void k_scatter_rows(const int32_t* __restrict_
     if (counts != nullptr && s == 0) counts[row] = counts2[j];
 }
 
-
-// the partial K1P list of every incomplete row (result arrays of its original row) in the raw format of the K1L
-// segment lists: KCAP slots, keys + 1 ascending, unused leading slots 0, empty slots 0xffffffff
-__global__ __launch_bounds__(256) void k_partial_keys(const int32_t* __restrict__ inc, int64_t n, int kcap, int k, int nearest,
-                                                      const int32_t* __restrict__ ids, const int32_t* __restrict__ dists,
-                                                      const int32_t* __restrict__ counts, uint32_t* __restrict__ out,
-                                                      const int* __restrict__ n_dev) {
-    if (n_dev != nullptr && *n_dev < n) n = *n_dev;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n * kcap) return;
-    const int64_t j = t / kcap;
-    const int s = (int)(t % kcap) - (kcap - k);      // position in the row's result list
-    uint32_t v;
-    if (s < 0) {
-        v = 0u;
-    } else {
-        const uint32_t e = (uint32_t)inc[j];
-        const int64_t row = (int64_t)(e & ~gm::PG_INC_OVERFLOW);
-        // (nearest-distance mode keeps no ids: an incomplete row there has no hit within r at all)
-        const int c = (e & gm::PG_INC_OVERFLOW) != 0u || nearest ? 0 : counts[row];
-        v = s < c ? ((((uint32_t)dists[row * k + s]) << gm::ID_BITS) | (uint32_t)ids[row * k + s]) + 1u : 0xffffffffu;
-    }
-    out[t] = v;
-}
 
 // rows that are still short after the prefix re-scan (count below `need` / no distance): their ORIGINAL row numbers,
 // compacted into out (order irrelevant), counted in *n_out
@@ -1308,7 +1284,10 @@ int gm_pg_candidates(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
     A.n_entries = n_entries;
     if ((rc = ensure(&pg->cbase, &pg->cbase_cap, A.n_entries, "chunk offsets"))) return rc;
     if ((rc = ensure(&pg->chunks, &pg->chunks_cap, grid, "chunk table"))) return rc;
-    if ((rc = ensure(&pg->nch, &pg->nch_cap, GM_PG_MAXB, "chunks per block"))) return rc;
+    if (pg->nch_cap < GM_PG_MAXB + 1) {      // (+ the offsets kernel's ticket: zero on entry, left zero)
+        if ((rc = ensure(&pg->nch, &pg->nch_cap, GM_PG_MAXB + 1, "chunks per block"))) return rc;
+        HIP_TRY(hipMemsetAsync(pg->nch, 0, sizeof(int) * (GM_PG_MAXB + 1), st));
+    }
     if (pg->hist_dirty) {      // (the offsets kernel leaves the histogram zeroed: only a fresh buffer needs this)
         HIP_TRY(hipMemsetAsync(pg->hist, 0, sizeof(int) * (size_t)pg->hist_cap, st));
         pg->hist_dirty = false;
@@ -1614,7 +1593,9 @@ int gm_pg_incomplete(gm_index* idx, int64_t* n_inc, int64_t* pairs_evaluated, hi
 // sized for cap, and every row-indexed kernel behind it clamps n to the device's count (gm_index::dev_rows / dev_nq: a
 // workgroup beyond the count exits at once; measured: padding the list with duplicate rows instead cost more than the
 // read-backs it saved -- +9 % pairs on PAO1's second level).
-// The counters still go to a mailbox (one per read-back kind, k_publish); the host looks at them ONCE, after the whole
+// The counters still go to a mailbox (one per read-back kind, k_publish -- a one-wave kernel of its own: letting the LAST
+// workgroup of the count-producing kernel publish instead was measured and costs more than the ~5 us launch it saves,
+// profiles/r04/NOTES.md); the host looks at them ONCE, after the whole
 // query is enqueued: a level that left more rows than its cap makes the query run again the synchronous way.
 // device address of a row count the follow-up kernels clamp their launch to: 0 = rows the merge left short (n_inc),
 // 1 = rows the last collect left (n_bad as of the last publish, which re-zeroes the live counter)
@@ -1768,30 +1749,31 @@ double gm_pg_prefix_fraction(const gm_index* idx, int k) {
     return best;
 }
 
-int gm_pg_partial_keys(gm_index* idx, int64_t n_inc, int kcap, int k, bool nearest, const int32_t* ids, const int32_t* dists,
-                       const int32_t* counts, uint32_t* out_keys, hipStream_t st) {
-    gm_pigeon* pg = idx->pg;
-    hipLaunchKernelGGL(k_partial_keys, grid_for(n_inc * kcap), dim3(256), 0, st, pg->inc, n_inc, kcap, k, nearest ? 1 : 0, ids,
-                       dists, counts, out_keys, idx->dev_rows);
-    HIP_TRY(hipGetLastError());
-    return GM_OK;
-}
-
+// last step of the prefix re-scan (k_merge_prefix): the segment lists `keys` of the n_inc compact rows are folded into
+// the ORIGINAL rows of ids / dists / counts, and the rows still short become the new pg->inc (the old list is the
+// spare); their number arrives in ctr->n_bad with the caller's next read-back
 int gm_pg_merge_prefix(gm_index* idx, int kcap, const uint32_t* keys, int n_lists, int64_t n_inc, int k, bool nearest,
-                       hipStream_t st) {
+                       int32_t* ids, int32_t* dists, int32_t* counts, hipStream_t st) {
     gm_pigeon* pg = idx->pg;
+    int rc;
+    if ((rc = ensure(&pg->inc_b, &pg->inc_b_cap, pg->inc_cap > n_inc ? pg->inc_cap : n_inc, "incomplete rows (second list)")))
+        return rc;
     constexpr int SP = 16;
     const dim3 grid = grid_for(n_inc * SP), block(256);
     const int nr = nearest ? 1 : 0;
-    int32_t* ids2 = nearest ? nullptr : pg->ids2;
-    int32_t* counts2 = nearest ? nullptr : pg->counts2;
+    const uint32_t min_raw = ((uint32_t)(gm_pg_radius(idx) + 1) << gm::ID_BITS) + 1u;      // keys at distance r + 1 (and beyond)
+    int32_t* ids_o = nearest ? nullptr : ids;
+    int32_t* counts_o = nearest ? nullptr : counts;
+    int* n_bad = &pg->ctr->n_bad;
     switch (kcap) {
-        case 1: hipLaunchKernelGGL((gm::k_merge_prefix<1, SP>), grid, block, 0, st, keys, n_lists, pg->inc, n_inc, k, ids2, pg->dists2, counts2, nr, idx->dev_rows); break;
-        case 5: hipLaunchKernelGGL((gm::k_merge_prefix<5, SP>), grid, block, 0, st, keys, n_lists, pg->inc, n_inc, k, ids2, pg->dists2, counts2, nr, idx->dev_rows); break;
-        case 10: hipLaunchKernelGGL((gm::k_merge_prefix<10, SP>), grid, block, 0, st, keys, n_lists, pg->inc, n_inc, k, ids2, pg->dists2, counts2, nr, idx->dev_rows); break;
-        default: hipLaunchKernelGGL((gm::k_merge_prefix<20, SP>), grid, block, 0, st, keys, n_lists, pg->inc, n_inc, k, ids2, pg->dists2, counts2, nr, idx->dev_rows); break;
+        case 1: hipLaunchKernelGGL((gm::k_merge_prefix<1, SP>), grid, block, 0, st, keys, n_lists, pg->inc, n_inc, k, min_raw, ids_o, dists, counts_o, nr, pg->inc_b, n_bad, idx->dev_rows); break;
+        case 5: hipLaunchKernelGGL((gm::k_merge_prefix<5, SP>), grid, block, 0, st, keys, n_lists, pg->inc, n_inc, k, min_raw, ids_o, dists, counts_o, nr, pg->inc_b, n_bad, idx->dev_rows); break;
+        case 10: hipLaunchKernelGGL((gm::k_merge_prefix<10, SP>), grid, block, 0, st, keys, n_lists, pg->inc, n_inc, k, min_raw, ids_o, dists, counts_o, nr, pg->inc_b, n_bad, idx->dev_rows); break;
+        default: hipLaunchKernelGGL((gm::k_merge_prefix<20, SP>), grid, block, 0, st, keys, n_lists, pg->inc, n_inc, k, min_raw, ids_o, dists, counts_o, nr, pg->inc_b, n_bad, idx->dev_rows); break;
     }
     HIP_TRY(hipGetLastError());
+    std::swap(pg->inc, pg->inc_b);
+    std::swap(pg->inc_cap, pg->inc_b_cap);
     return GM_OK;
 }
 

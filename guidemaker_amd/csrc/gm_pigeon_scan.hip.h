@@ -983,43 +983,66 @@ __global__ void k_merge_pg3(const uint32_t* __restrict__ keys, int n_lists, int6
     if (owner) counts[qi] = cnt;
 }
 
-// K1P prefix re-scan: fold the n_lists raw lists of a row (the K1L segment lists of the scanned pool prefix and, last,
-// the row's partial K1P list -- they share entries, hence insert_unique) into the top k.  SPLIT lanes per row.  A row
-// that does not reach k entries, or whose K1P lists had overflowed (flag on its inc entry), is written with count 0 /
-// distance -1: it goes on to the plain re-scan.
+// K1P prefix re-scan, last step: the n_lists K1L segment lists of the scanned pool prefix (bound d < r + 2) of compact
+// row j are folded and joined with what the row has.  A row the merge left short WITHOUT an overflow holds ALL its c < k
+// neighbours within r in its result row already, so the fold takes only the prefix's targets at distance r + 1
+// (`min_raw`: everything closer is one of the c), the k - c smallest of them go behind the c entries of the ORIGINAL row
+// inc[j] and the row is complete; a row that does not reach k, or whose K1P lists had overflowed (flag on its inc
+// entry), is reset to count 0 / distance -1 and appended to `bad` (*n_bad) for the plain re-scan.  SPLIT lanes per row.
+// (One kernel for what used to be k_partial_keys + k_merge_prefix + k_scatter_rows + k_collect_bad.)
 template <int KCAP, int SPLIT>
-__global__ void k_merge_prefix(const uint32_t* __restrict__ keys, int n_lists, const int32_t* __restrict__ inc, int64_t n,
-                               int k, int32_t* __restrict__ ids, int32_t* __restrict__ dists, int32_t* __restrict__ counts,
-                               int nearest, const int* __restrict__ n_dev) {
+__global__ __launch_bounds__(256) void k_merge_prefix(const uint32_t* __restrict__ keys, int n_lists, const int32_t* __restrict__ inc,
+                                                      int64_t n, int k, uint32_t min_raw, int32_t* __restrict__ ids,
+                                                      int32_t* __restrict__ dists, int32_t* __restrict__ counts, int nearest,
+                                                      int32_t* __restrict__ bad, int* __restrict__ n_bad,
+                                                      const int* __restrict__ n_dev) {
+    constexpr int N = fold_width(KCAP);
     const int64_t n_stride = n;      // row stride of the raw lists: the host's number
     if (n_dev != nullptr && *n_dev < n) n = *n_dev;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int sub = (int)(t % SPLIT);
-    const int64_t row_raw = t / SPLIT;
-    const bool valid = row_raw < n;
-    const int64_t row = valid ? row_raw : 0;
-    RegList<KCAP> list;
-    list.init(k, nullptr, 0);
-    for (int s = sub; s < n_lists; s += SPLIT) {
-        const uint32_t* in = keys + ((int64_t)s * n_stride + row) * KCAP;
+    const int64_t j_raw = t / SPLIT;
+    const bool valid = j_raw < n;
+    const int64_t j = valid ? j_raw : 0;
+    uint32_t acc[N];
+    fold_lists<KCAP, SPLIT, N>(acc, keys, n_lists, n_stride, j, sub, min_raw);
+    bool take = false;
+    int32_t row32 = 0;
+    if (sub == 0 && valid) {
+        const uint32_t e = (uint32_t)inc[j];
+        row32 = (int32_t)(e & ~PG_INC_OVERFLOW);
+        const int64_t row = (int64_t)row32;
+        const bool over = (e & PG_INC_OVERFLOW) != 0u;
+        if (nearest != 0) {      // (no hit within r at all: the nearest target of the prefix at r + 1, if there is one)
+            take = over || acc[0] == 0xffffffffu;
+            dists[row] = take ? -1 : (int32_t)((acc[0] - 1u) >> ID_BITS);
+        } else {
+            const int c = over ? 0 : counts[row];
+            int found = 0;
 #pragma unroll
-        for (int i = 0; i < KCAP; ++i) {
-            const uint32_t v = in[i];
-            if (v != 0u && v < list.v[KCAP - 1]) list.insert_unique(v - 1u);
+            for (int i = 0; i < KCAP; ++i) found += acc[i] != 0xffffffffu ? 1 : 0;
+            take = over || c + found < k;
+            if (take) {
+                for (int s = 0; s < k; ++s) {
+                    ids[row * k + s] = -1;
+                    dists[row * k + s] = -1;
+                }
+                counts[row] = 0;
+            } else {
+#pragma unroll
+                for (int i = 0; i < KCAP; ++i) {
+                    const int dst = c + i;
+                    if (dst < k) {
+                        const uint32_t key = acc[i] - 1u;
+                        ids[row * k + dst] = (int32_t)(key & ID_MASK);
+                        dists[row * k + dst] = (int32_t)(key >> ID_BITS);
+                    }
+                }
+                counts[row] = k;
+            }
         }
     }
-#pragma unroll
-    for (int off = SPLIT / 2; off >= 1; off >>= 1) {
-#pragma unroll
-        for (int i = 0; i < KCAP; ++i) {
-            const uint32_t v = __shfl_down(list.v[i], off, SPLIT);
-            if (sub < off && v != 0u && v < list.v[KCAP - 1]) list.insert_unique(v - 1u);
-        }
-    }
-    if (sub != 0 || !valid) return;
-    const bool full = list.v[KCAP - 1] != RegList<KCAP>::EMPTY;
-    if (!full || ((uint32_t)inc[row] & PG_INC_OVERFLOW) != 0u) list.init(k, nullptr, 0);
-    list.store(k, row, ids, dists, counts, nearest != 0);
+    gm_block_append(take, row32, bad, n_bad);
 }
 
 }  // namespace gm

@@ -154,11 +154,6 @@ int launch_merge(int kcap, const uint32_t* keys, int n_seg, int64_t n_q, int k, 
 
 // K1L Hamming scan of the candidates in idx->d_q.  nearest: k = 1, distances only (into dists).
 // timed: record the HIP events around the dominant launch (false when used as the Levenshtein seeder).
-// all lists of a candidate start with the bound `key`'s distance: seeds[q][kcap - 1] = key, the rest empty
-__global__ void k_fill_seeds(uint32_t* __restrict__ seeds, int64_t n_q, int kcap, uint32_t key) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n_q * kcap) seeds[t] = (t % kcap) == kcap - 1 ? key : 0xffffffffu;
-}
 
 // guess_thr > 0 (K1P's re-scan): the caller knows a distance bound that almost surely holds for these rows;
 // every segment is scanned in ONE seeded launch under it (no unseeded first phase).  A row whose list does
@@ -211,13 +206,9 @@ int run_hamming_lookup(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
     a.tiles_per_seg = (int)tps;
     a.out_keys = idx->d_keys;
     if (guess_thr > 0) {      // one seeded launch over all segments under the caller's bound
-        uint32_t* seeds = idx->d_keys + n_seg * n_q * a.kcap;
-        hipLaunchKernelGGL(k_fill_seeds, dim3((unsigned)((n_q * a.kcap + 255) / 256)), dim3(256), 0, st, seeds, n_q,
-                           a.kcap, ((uint32_t)guess_thr << 27) + 1u);
-        HIP_TRY(hipGetLastError());
         a.n_seg = (int)n_seg;
         a.seg_base = 0;
-        a.seed_keys = seeds;
+        a.seed_all = ((uint32_t)guess_thr << 27) + 1u;
         if ((rc = launch_lk_len(idx, a, st))) return rc;
         return launch_merge(a.kcap, idx->d_keys, (int)n_seg, n_q, a.k, ids, dists, counts, nearest, st, a.n_dev);
     }
@@ -620,9 +611,10 @@ int run_leven_lookup(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* d
 }
 
 // K1P prefix re-scan (gm_pg_prefix_fraction): K1L over the first `frac` of the pool (id order) for the n compacted rows
-// under the bound guess_thr, its segment lists + the rows' partial K1P lists folded into pg->ids2 / dists2 / counts2.
+// under the bound guess_thr; its segment lists complete the rows' partial K1P lists in place (ids / dists / counts: the
+// ORIGINAL rows), and the rows still short become the handle's list of incomplete rows (gm_pg_merge_prefix).
 int run_hamming_prefix(gm_index* idx, bool nearest, int64_t n, int k, int kcap, const uint2* q2, int guess_thr, double frac,
-                       const int32_t* ids, const int32_t* dists, const int32_t* counts, hipStream_t st) {
+                       int32_t* ids, int32_t* dists, int32_t* counts, hipStream_t st) {
     gm_lk_args a;
     a.q = q2;
     a.n_dev = idx->dev_rows;
@@ -643,20 +635,15 @@ int run_hamming_prefix(gm_index* idx, bool nearest, int64_t n, int k, int kcap, 
     tps += tps & 1;
     n_seg = (n_tiles_p + tps - 1) / tps;
     int rc;
-    if ((rc = ensure_u32(&idx->d_keys, &idx->keys_cap, (n_seg + 2) * n * kcap))) return rc;
-    uint32_t* seeds = idx->d_keys + (n_seg + 1) * n * kcap;
-    hipLaunchKernelGGL(k_fill_seeds, dim3((unsigned)((n * kcap + 255) / 256)), dim3(256), 0, st, seeds, n, kcap,
-                       ((uint32_t)guess_thr << 27) + 1u);
-    HIP_TRY(hipGetLastError());
+    if ((rc = ensure_u32(&idx->d_keys, &idx->keys_cap, n_seg * n * kcap))) return rc;
     a.n_seg = (int)n_seg;
     a.seg_base = 0;
     a.tiles_per_seg = (int)tps;
-    a.seed_keys = seeds;
+    a.seed_all = ((uint32_t)guess_thr << 27) + 1u;
     a.out_keys = idx->d_keys;
     a.n_tiles = (int)n_tiles_p;
     if ((rc = launch_lk_len(idx, a, st))) return rc;
-    if ((rc = gm_pg_partial_keys(idx, n, kcap, a.k, nearest, ids, dists, counts, idx->d_keys + n_seg * n * kcap, st))) return rc;
-    return gm_pg_merge_prefix(idx, kcap, idx->d_keys, (int)n_seg + 1, n, a.k, nearest, st);
+    return gm_pg_merge_prefix(idx, kcap, idx->d_keys, (int)n_seg, n, a.k, nearest, ids, dists, counts, st);
 }
 
 // K1P (gm_pigeon.hip): exact Hamming k-NN from B block-sorted pool copies, then a deeper K1P level (larger radius,
@@ -995,8 +982,6 @@ static int run_pigeon_level(gm_index* idx, int level, bool nearest, int64_t n_q,
         if (frac <= 0.6) {
             if ((rc = run_hamming_prefix(idx, nearest, n_inc, keff, kcap, q2, radius + 2, frac, ids, dists, counts, st)))
                 return rc;
-            if ((rc = gm_pg_scatter(idx, n_inc, keff, nearest, ids, dists, counts, st))) return rc;
-            if ((rc = gm_pg_collect_bad(idx, n_inc, keff, nearest, st))) return rc;
             int64_t n_left = 0;
             if (sp) {
                 n_left = spec_cap_small(level < GM_PG_LEVELS ? idx->spec.nleft[level] : 0);
