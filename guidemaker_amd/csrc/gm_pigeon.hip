@@ -441,6 +441,11 @@ struct gm_pigeon {
     // query side (grow-only)
     uint32_t* cperm[GM_PG_MAXB]{};
     int64_t cperm_cap[GM_PG_MAXB]{};
+    uint32_t* ctmp[GM_PG_MAXB]{};      // two-level grouping (gm_group.hip.h): first-pass entries per block; partition counters
+    int64_t ctmp_cap[GM_PG_MAXB]{};
+    int* part_words = nullptr;
+    int64_t part_words_cap = 0;
+    int tune_group = 0;                // gm_set_param "pg_group": 0 = choose (two levels from 262 144 candidates), 1 = one level, 2 = two levels
     int32_t* coff[GM_PG_MAXB]{};
     uint32_t *k0 = nullptr, *k1 = nullptr, *r0 = nullptr, *r1 = nullptr;
     int64_t k0_cap = 0, k1_cap = 0, r0_cap = 0, r1_cap = 0;
@@ -935,6 +940,7 @@ void gm_pg_inherit(gm_index* idx, const gm_pigeon* parent) {
     pg->tune_per = parent->tune_per;
     pg->tune_hit = parent->tune_hit;
     pg->tune_run = parent->tune_run;
+    pg->tune_group = parent->tune_group;
     pg->tune_msplit = parent->tune_msplit;
     pg->tune_prefix = parent->tune_prefix;
     pg->tune_layout = idx->pg_layout_deeper;
@@ -1013,6 +1019,11 @@ int gm_pg_set_param(gm_index* idx, const char* name, int value) {
         idx->pg->tune_run = value;
         return GM_OK;
     }
+    if (std::strcmp(name, "pg_group") == 0) {      // candidate grouping: 0 = choose, 1 = one counting sort, 2 = two levels
+        if (value < 0 || value > 2) return gm_fail(GM_ERR_ARG, "pg_group: 0, 1 or 2");
+        idx->pg->tune_group = value;
+        return GM_OK;
+    }
     return gm_fail(GM_ERR_ARG, std::string("unknown parameter ") + name);
 }
 
@@ -1022,9 +1033,11 @@ void gm_pg_free(gm_index* idx) {
     free_pool_side(pg);
     for (auto& ps : pg->stash) free_side(ps);
     pg->stash.clear();
-    for (int b = 0; b < GM_PG_MAXB; ++b)
+    for (int b = 0; b < GM_PG_MAXB; ++b) {
         if (pg->cperm[b]) (void)hipFree(pg->cperm[b]);
-    void* bufs[] = {pg->k0, pg->k1, pg->r0, pg->r1, pg->sort_tmp, pg->nch, pg->cbase, pg->hist, pg->cursor, pg->chunks, pg->ctr,
+        if (pg->ctmp[b]) (void)hipFree(pg->ctmp[b]);
+    }
+    void* bufs[] = {pg->part_words, pg->k0, pg->k1, pg->r0, pg->r1, pg->sort_tmp, pg->nch, pg->cbase, pg->hist, pg->cursor, pg->chunks, pg->ctr,
                     pg->lists, pg->hdr, pg->keys3, pg->raw_off, pg->inc, pg->inc_b, pg->cflag, pg->shist, pg->q2, pg->ids2, pg->dists2, pg->counts2};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
@@ -1259,6 +1272,35 @@ int gm_pg_candidates(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
     pg_geometry(pg);
     int64_t grid = 0;
     for (int b = 0; b <= pg->B; ++b) A.ebase[b] = K.ebase[b] = pg->ebase[b];
+    // two-level grouping for large candidate sets (gm_group.hip.h): partitions = the high key bits, at least 64 per block
+    // where the block has that many values; the low <= 7 bits are sorted inside a partition
+    bool two_level = (pg->tune_group == 2 || (pg->tune_group == 0 && n_q >= 262144)) && n_q < ((int64_t)1 << (32 - PG_PART_LO_MAX));
+    if (two_level) {
+        int n_parts = 0;
+        for (int b = 0; b < pg->B; ++b) {
+            const int bits = 2 * pg->blen[b];
+            // (low bits: at most 5 -- more partitions make the first pass's runs shorter and the second pass's workgroups
+            // smaller; S4 / PAO1, first + second pass: 146 / 82 us with 7 bits, 112 / 81 with 5, 142 / 96 with 4)
+            int lo = bits - 6;
+            lo = lo < 0 ? 0 : (lo > PG_PART_LO ? PG_PART_LO : lo);
+            K.lo_bits[b] = lo;
+            K.part_base[b] = n_parts;
+            n_parts += 1 << (bits - lo);
+        }
+        K.part_base[pg->B] = n_parts;
+        if (n_parts > PG_PART_MAX) two_level = false;      // (three blocks of 8 bases: the one-level sort)
+    }
+    if (two_level) {
+        const int n_parts = K.part_base[pg->B];
+        for (int b = 0; b < pg->B; ++b) {
+            if ((rc = ensure(&pg->ctmp[b], &pg->ctmp_cap[b], n_q, "candidate order (first pass)"))) return rc;
+            K.ctmp[b] = pg->ctmp[b];
+        }
+        if (pg->part_words_cap < 2 * (int64_t)n_parts) {      // (zero on entry, left zero by the offsets kernel)
+            if ((rc = ensure(&pg->part_words, &pg->part_words_cap, 2 * (int64_t)n_parts, "partition counters"))) return rc;
+            HIP_TRY(hipMemsetAsync(pg->part_words, 0, sizeof(int) * (size_t)pg->part_words_cap, st));
+        }
+    }
     for (int b = 0; b < pg->B; ++b) {
         if ((rc = ensure(&pg->cperm[b], &pg->cperm_cap[b], n_q, "candidate order"))) return rc;
         K.bstart[b] = pg->bstart[b];
@@ -1295,7 +1337,8 @@ int gm_pg_candidates(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
     PgSubArg nsub{};
     for (int b = 0; b < pg->B; ++b) nsub.n[b] = pg->nsub[b];
     if ((rc = gm_group_launch(idx->d_q, n_q, K, nsub, pg->hist, pg->cursor, pg->cbase, pg->nch, reinterpret_cast<int*>(pg->ctr),
-                              (int)(sizeof(PgCounters) / sizeof(int)), pg->ctr->cstart, &pg->ctr->n_chunks, idx->device, st, idx->dev_nq)))
+                              (int)(sizeof(PgCounters) / sizeof(int)), pg->ctr->cstart, &pg->ctr->n_chunks, idx->device, st, idx->dev_nq,
+                              two_level ? pg->part_words : nullptr)))
         return rc;
     hipLaunchKernelGGL(k_fill_chunks, grid_for((int64_t)A.n_entries * A.smax), dim3(256), 0, st, A, pg->cbase, pg->chunks, pg->ctr);
     HIP_TRY(hipGetLastError());

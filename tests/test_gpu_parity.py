@@ -433,6 +433,7 @@ def test_pigeonhole_layouts_match_oracle(oracle, L, variant, hit):
     idx = _lib.Index(_lib.pack(db, L), L, _lib.METRIC_HAMMING)
     idx.set_variant(variant)
     idx.set_param("pg_hit", hit)
+    idx.set_param("pg_group", 1 if hit == 0 else 2)      # candidate grouping: one counting sort / two levels (partitions)
     qp = _lib.pack(q, L)
     for k in (2, 5, 10, 20):
         ids, dists, counts = idx.knn(qp, k)
@@ -1340,7 +1341,8 @@ def test_speculative_follow_ups_are_exact(oracle):
     want = {name: plain.knn(q, k) for name, q in (("members", members), ("foreign", foreign), ("mixed", mixed))}
     want1 = plain.nearest(foreign)
     plain.close()
-    for setup in ({}, {"pg_layout": 717160, "pg_cascade": 2, "pg_layout2": 61515140}, {"pg_hit": 2}):
+    for setup in ({}, {"pg_layout": 717160, "pg_cascade": 2, "pg_layout2": 61515140}, {"pg_hit": 2},
+                  {"pg_group": 2, "pg_layout": 717160, "pg_cascade": 2, "pg_layout2": 61515140}):
         idx = _lib.Index(db, L, _lib.METRIC_HAMMING)
         try:
             for name, val in setup.items():
