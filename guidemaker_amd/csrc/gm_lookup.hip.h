@@ -441,10 +441,11 @@ __global__ void k_merge_lists_split(const uint32_t* __restrict__ keys, int n_seg
     const int sub = (int)(t % SPLIT);
     const int64_t qi_raw = t / SPLIT;
     const bool valid = qi_raw < n_q && (n_dev == nullptr || qi_raw < *n_dev);      // (n_q stays the row stride of the lists)
-    const int64_t qi = valid ? qi_raw : 0;
+    if (!valid) return;      // (the SPLIT lanes of a row leave together: the shuffles below stay inside a row)
+    const int64_t qi = qi_raw;
     uint32_t acc[N];
     fold_lists<KCAP, SPLIT, N>(acc, keys, n_seg, n_q, qi, sub, 1u);
-    if (sub != 0 || !valid) return;
+    if (sub != 0) return;
     if (nearest != 0) {
         dists[qi] = acc[0] == 0xffffffffu ? -1 : (int32_t)((acc[0] - 1u) >> ID_BITS);
         return;

@@ -175,8 +175,30 @@ __device__ __forceinline__ void pg_entry(const PgLayoutArg& A, int e, int& b, in
     v = e - A.ebase[b];
 }
 
+// gsum[entry x smax + s] = the 64 x 64 groups one chunk of that (block, bucket) entry evaluates in run s of its target
+// buckets.  A property of the pool copies and the launch geometry, not of the candidates: computed when those change
+// (gm_pg_candidates keeps a signature), not per query -- the walk over a radius-2 block's 211 target buckets per thread
+// made k_fill_chunks 61 us of every S4 step.
+__global__ __launch_bounds__(256) void k_group_sums(PgLayoutArg A, uint32_t* __restrict__ gsum) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = t / A.smax, s = t % A.smax;
+    if (e >= A.n_entries) return;
+    int b = 0, v = 0;
+    pg_entry(A, e, b, v);
+    uint32_t groups = 0;
+    if (s < A.nsub[b]) {
+        const int n_bk = A.nbk[b], per = A.per[b];
+        const int e_lo = s * per, e_hi = e_lo + per < n_bk ? e_lo + per : n_bk;
+        for (int u = e_lo; u < e_hi; ++u) {
+            int add;
+            groups += (uint32_t)A.bdesc[b][gm::pg_target_bucket(v, u, A.blen[b], A.skiplen[b], add)].y;
+        }
+    }
+    gsum[t] = groups;
+}
+
 // one thread per ((block, bucket) entry, run of target buckets)
-__global__ __launch_bounds__(256) void k_fill_chunks(PgLayoutArg A, const int* __restrict__ cbase,
+__global__ __launch_bounds__(256) void k_fill_chunks(PgLayoutArg A, const int* __restrict__ cbase, const uint32_t* __restrict__ gsum,
                                                      gm_pg_chunk* __restrict__ chunks, PgCounters* __restrict__ ctr) {
     __shared__ unsigned long long s_pairs[GM_PG_MAXB];      // pairs per block, summed per workgroup first: thousands of
     if (threadIdx.x < GM_PG_MAXB) s_pairs[threadIdx.x] = 0ull;      // 64-bit atomics on one address take ~150 us
@@ -204,12 +226,7 @@ __global__ __launch_bounds__(256) void k_fill_chunks(PgLayoutArg A, const int* _
         for (int c = c0; c < c1; c += 64, ++w)
             chunks[w] = gm_pg_chunk{b, v, c, c1 - c < 64 ? c1 - c : 64, e_lo, e_hi, lst, 0};
         // the 64 x 64 groups the scan evaluates for this run
-        unsigned long long groups = 0;
-        for (int u = e_lo; u < e_hi; ++u) {
-            int add;
-            groups += (unsigned long long)A.bdesc[b][gm::pg_target_bucket(v, u, A.blen[b], A.skiplen[b], add)].y;
-        }
-        atomicAdd(&s_pairs[b], (unsigned long long)n_ch * 64ull * groups * gm::LK_GROUP);
+        atomicAdd(&s_pairs[b], (unsigned long long)n_ch * 64ull * (unsigned long long)gsum[t] * gm::LK_GROUP);
     }
     __syncthreads();
     if (threadIdx.x < GM_PG_MAXB && s_pairs[threadIdx.x] != 0ull)
@@ -445,6 +462,9 @@ struct gm_pigeon {
     int64_t ctmp_cap[GM_PG_MAXB]{};
     int* part_words = nullptr;
     int64_t part_words_cap = 0;
+    uint32_t* gsum = nullptr;          // k_group_sums: groups per chunk of every (entry, run of target buckets) ...
+    int64_t gsum_cap = 0;
+    std::vector<int64_t> gsum_sig;     // ... for this geometry and these pool copies
     int tune_group = 0;                // gm_set_param "pg_group": 0 = choose (two levels from 262 144 candidates), 1 = one level, 2 = two levels
     int32_t* coff[GM_PG_MAXB]{};
     uint32_t *k0 = nullptr, *k1 = nullptr, *r0 = nullptr, *r1 = nullptr;
@@ -529,6 +549,7 @@ int ensure_sort_buffers(gm_pigeon* pg, int64_t n) {
 }
 
 void free_pool_side(gm_pigeon* pg) {
+    pg->gsum_sig.clear();      // (the group sums belong to these copies)
     for (int b = 0; b < GM_PG_MAXB; ++b) {
         if (pg->table[b]) (void)hipFree(pg->table[b]);
         if (pg->recs[b]) (void)hipFree(pg->recs[b]);
@@ -594,6 +615,7 @@ void stash_pool_side(gm_pigeon* pg) {
         for (size_t i = 1; i < pg->stash.size(); ++i)
             if (pg->stash[i].stamp < pg->stash[old].stamp) old = i;
         free_side(pg->stash[old]);
+        pg->gsum_sig.clear();      // (its addresses may come back with other contents)
         pg->stash.erase(pg->stash.begin() + (long)old);
     }
     pg->stash.push_back(ps);
@@ -1037,7 +1059,7 @@ void gm_pg_free(gm_index* idx) {
         if (pg->cperm[b]) (void)hipFree(pg->cperm[b]);
         if (pg->ctmp[b]) (void)hipFree(pg->ctmp[b]);
     }
-    void* bufs[] = {pg->part_words, pg->k0, pg->k1, pg->r0, pg->r1, pg->sort_tmp, pg->nch, pg->cbase, pg->hist, pg->cursor, pg->chunks, pg->ctr,
+    void* bufs[] = {pg->part_words, pg->gsum, pg->k0, pg->k1, pg->r0, pg->r1, pg->sort_tmp, pg->nch, pg->cbase, pg->hist, pg->cursor, pg->chunks, pg->ctr,
                     pg->lists, pg->hdr, pg->keys3, pg->raw_off, pg->inc, pg->inc_b, pg->cflag, pg->shist, pg->q2, pg->ids2, pg->dists2, pg->counts2};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
@@ -1340,7 +1362,20 @@ int gm_pg_candidates(gm_index* idx, int64_t n_q, int k, hipStream_t st) {
                               (int)(sizeof(PgCounters) / sizeof(int)), pg->ctr->cstart, &pg->ctr->n_chunks, idx->device, st, idx->dev_nq,
                               two_level ? pg->part_words : nullptr)))
         return rc;
-    hipLaunchKernelGGL(k_fill_chunks, grid_for((int64_t)A.n_entries * A.smax), dim3(256), 0, st, A, pg->cbase, pg->chunks, pg->ctr);
+    {      // the group sums of this geometry over these pool copies: once, not per query
+        std::vector<int64_t> sig{(int64_t)A.B, (int64_t)A.smax, (int64_t)A.n_entries};
+        for (int b = 0; b < pg->B; ++b) {
+            const int64_t w[] = {(int64_t)reinterpret_cast<uintptr_t>(A.bdesc[b]), pg->bstart[b], A.blen[b], A.nbk[b], A.nsub[b], A.per[b], A.skiplen[b]};
+            sig.insert(sig.end(), w, w + 7);
+        }
+        if (sig != pg->gsum_sig || pg->gsum == nullptr) {
+            if ((rc = ensure(&pg->gsum, &pg->gsum_cap, (int64_t)A.n_entries * A.smax, "group sums"))) return rc;
+            hipLaunchKernelGGL(k_group_sums, grid_for((int64_t)A.n_entries * A.smax), dim3(256), 0, st, A, pg->gsum);
+            HIP_TRY(hipGetLastError());
+            pg->gsum_sig = sig;
+        }
+    }
+    hipLaunchKernelGGL(k_fill_chunks, grid_for((int64_t)A.n_entries * A.smax), dim3(256), 0, st, A, pg->cbase, pg->gsum, pg->chunks, pg->ctr);
     HIP_TRY(hipGetLastError());
     pg->grid = grid;
     return GM_OK;

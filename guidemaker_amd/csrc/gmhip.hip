@@ -117,7 +117,7 @@ int ensure_u32(uint32_t** buf, int64_t* cap, int64_t need) {
 int launch_merge(int kcap, const uint32_t* keys, int n_seg, int64_t n_q, int k, int32_t* ids, int32_t* dists,
                  int32_t* counts, bool nearest, hipStream_t st, const int* n_dev = nullptr) {
     const int nr = nearest ? 1 : 0;
-    if (n_seg >= 128 && n_q <= 2048) {      // a handful of candidates, hundreds of lists: a whole wave per candidate
+    if (n_seg >= 128 && n_q <= 8192) {      // a handful of candidates, hundreds of lists: a whole wave per candidate
         constexpr int SP = 64;
         const dim3 grid((unsigned)((n_q * SP + 255) / 256)), block(256);
         switch (kcap) {
@@ -158,9 +158,11 @@ int launch_merge(int kcap, const uint32_t* keys, int n_seg, int64_t n_q, int k, 
 // guess_thr > 0 (K1P's re-scan): the caller knows a distance bound that almost surely holds for these rows;
 // every segment is scanned in ONE seeded launch under it (no unseeded first phase).  A row whose list does
 // not fill under the guess is NOT exact -- the caller checks the counts and repeats without a guess.
+// n_expect >= 0 (speculative follow-ups): n_q is an upper bound the launch is sized for, about n_expect rows are real --
+// the pool is cut for THAT many (S4: 249 rows under a bound of 2 359 got a tenth of the segments they fill the chip with).
 int run_hamming_lookup(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t* ids, int32_t* dists,
                        int32_t* counts, bool timed, hipStream_t st, const uint2* qplanes = nullptr,
-                       int guess_thr = 0) {
+                       int guess_thr = 0, int64_t n_expect = -1) {
     gm_lk_args a;
     a.q = qplanes;
     a.n_dev = qplanes != nullptr ? idx->dev_rows : nullptr;      // (K1P's re-scan of compact rows in a speculative run)
@@ -170,7 +172,8 @@ int run_hamming_lookup(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
     a.ids = ids;
     a.dists = dists;
     a.counts = counts;
-    const int64_t chunks = (n_q + gm::WAVE - 1) / gm::WAVE;
+    const int64_t n_real = n_expect >= 0 && n_expect < n_q ? (n_expect > 0 ? n_expect : 1) : n_q;
+    const int64_t chunks = (n_real + gm::WAVE - 1) / gm::WAVE;      // (the chunks that do work; the grid below covers n_q)
     const int64_t n_tiles = idx->n_lk_tiles;                       // even
     // work items wanted per resident wave slot: more items = smaller tail round, but every extra segment
     // re-collects up to k keys and lengthens the merge, so fewer for long lists (measured on S1-sized
@@ -188,6 +191,7 @@ int run_hamming_lookup(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
     const int64_t fill = (int64_t)idx->n_simd * 8 / (chunks > 0 ? chunks : 1);
     if (fill > seg_cap) seg_cap = fill < 512 ? fill : 512;
     if (n_seg > seg_cap) n_seg = seg_cap;
+    while (n_seg > 2 && (n_seg + 1) * n_q * (a.kcap > 0 ? a.kcap : 1) > ((int64_t)1 << 26)) n_seg /= 2;      // (segment lists: <= 256 MiB)
     if (guess_thr > 0 && idx->lk_seg > 0) n_seg = idx->lk_seg < n_tiles / 2 ? idx->lk_seg : n_tiles / 2;
     int rc;
     if (a.kcap == 0 || n_seg < 2) {           // single pass over the whole pool
@@ -936,6 +940,7 @@ static int run_pigeon_level(gm_index* idx, int level, bool nearest, int64_t n_q,
     if (!sp && planned && (double)n_inc > (expect + 1.0 / 3.0) * (double)n_q && n_q >= 4096 && gm_pg_debug_flags(idx) == 0)
         idx->pg_flooded_k1 = keff + 1;
     const int64_t n_inc_dec = sp && level < GM_PG_LEVELS ? idx->spec.ninc[level] : n_inc;
+    int64_t n_real = sp && level < GM_PG_LEVELS ? idx->spec.ninc[level] : -1;      // speculative run: rows expected under the bound n_inc
     if (n_inc > 0) {
         const uint2* q2 = nullptr;
         int32_t *ids2 = nullptr, *dists2 = nullptr, *counts2 = nullptr;
@@ -1004,13 +1009,14 @@ static int run_pigeon_level(gm_index* idx, int level, bool nearest, int64_t n_q,
                 return GM_OK;
             }
             n_inc = n_left;
+            n_real = sp && level < GM_PG_LEVELS ? idx->spec.nleft[level] : -1;
             if ((rc = gm_pg_gather(idx, n_inc, keff, nearest, &q2, &ids2, &dists2, &counts2, st))) return rc;
         }
         // these rows have fewer than k neighbours within r (or a flooded slot list): their k-th neighbour is
         // almost surely at r + 1, so scan under the bound d < r + 2 first and fall back to the unseeded scan
         // only if a list still does not fill
         const int guess = radius + 2;
-        if ((rc = run_hamming_lookup(idx, nearest, n_inc, keff, ids2, dists2, counts2, false, st, q2, guess))) return rc;
+        if ((rc = run_hamming_lookup(idx, nearest, n_inc, keff, ids2, dists2, counts2, false, st, q2, guess, n_real))) return rc;
         if ((rc = gm_pg_scatter(idx, n_inc, keff, nearest, ids, dists, counts, st))) return rc;
         // the rows whose list did not fill under the guess (and only those) go through the unseeded scan
         int64_t n_bad = 0;
@@ -1034,7 +1040,9 @@ static int run_pigeon_level(gm_index* idx, int level, bool nearest, int64_t n_q,
                     guess, (long long)n_bad);
         if (n_bad > 0) {
             if ((rc = gm_pg_gather(idx, n_bad, keff, nearest, &q2, &ids2, &dists2, &counts2, st))) return rc;
-            if ((rc = run_hamming_lookup(idx, nearest, n_bad, keff, ids2, dists2, counts2, false, st, q2))) return rc;
+            if ((rc = run_hamming_lookup(idx, nearest, n_bad, keff, ids2, dists2, counts2, false, st, q2, 0,
+                                         sp && level < GM_PG_LEVELS ? idx->spec.nbad[level] : -1)))
+                return rc;
             if ((rc = gm_pg_scatter(idx, n_bad, keff, nearest, ids, dists, counts, st))) return rc;
         }
     }
