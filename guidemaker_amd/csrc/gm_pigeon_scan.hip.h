@@ -880,16 +880,29 @@ __global__ void k_merge_pg3(const uint32_t* __restrict__ keys, int n_lists, int6
     const int64_t row0 = (int64_t)blockIdx.x * blockDim.x;
     const int64_t rows_here = n_stride - row0 < (int64_t)blockDim.x ? n_stride - row0 : (int64_t)blockDim.x;
     const int n_words = (int)rows_here * KCAP;
-    for (int l = 0; l < n_lists; ++l) {
+    // (the NEXT list's words are fetched into registers while this one is merged -- KCAP words per thread, 256 threads --
+    // and moved to LDS behind the merge: the kernel is memory-bound and ran list by list, load -> wait -> merge)
+    uint32_t nxt[KCAP];
+    auto fetch = [&](int l) {
         const uint32_t* __restrict__ in = keys + ((int64_t)l * n_stride + row0) * KCAP;
-        if (l > 0) __syncthreads();      // the previous list has been read
+#pragma unroll
+        for (int i = 0; i < KCAP; ++i) {
+            const int w = (int)threadIdx.x + i * 256;
 #if defined(GM_PG_TIMING) && (GM_PG_TIMING & 8)      // timing build only (results WRONG): no list loads
-        for (int w = (int)threadIdx.x; w < n_words; w += (int)blockDim.x) s_in[w] = (uint32_t)(w * 2654435761u) | 1u;
-        (void)in;
+            nxt[i] = (uint32_t)(w * 2654435761u) | 1u;
+            (void)in;
 #else
-        for (int w = (int)threadIdx.x; w < n_words; w += (int)blockDim.x) s_in[w] = in[w];
+            nxt[i] = w < n_words ? in[w] : NONE;
 #endif
+        }
+    };
+    fetch(0);
+    for (int l = 0; l < n_lists; ++l) {
+        if (l > 0) __syncthreads();      // the previous list has been read
+#pragma unroll
+        for (int i = 0; i < KCAP; ++i) s_in[(int)threadIdx.x + i * 256] = nxt[i];
         __syncthreads();
+        if (l + 1 < n_lists) fetch(l + 1);
         uint32_t b[KCAP];
 #pragma unroll
         for (int i = 0; i < KCAP; ++i) b[i] = i < k && valid ? s_in[(int)threadIdx.x * KCAP + lead + i] : NONE;
