@@ -156,6 +156,7 @@ struct gm_lk_args {
     uint32_t* out_keys = nullptr;
     int32_t *ids = nullptr, *dists = nullptr, *counts = nullptr;
     const uint2* q = nullptr;     // candidate planes (nullptr: idx->d_q)
+    const int32_t* q_rows = nullptr;      // != nullptr: candidate i is row (q_rows[i] & 0x7fffffff) of q (K1P's list of incomplete rows)
     int n_tiles = 0;              // scan only the first n_tiles tiles of the pool (0: all) -- K1P's prefix re-scan
     const int* n_dev = nullptr;   // device count n_q is an upper bound of (speculative follow-ups); nullptr: exact
 };
@@ -203,8 +204,10 @@ int gm_pg_scan(gm_index* idx, int64_t n_q, int k, int kcap, hipStream_t st);
 int gm_pg_merge(gm_index* idx, int kcap, int64_t n_q, int k, int32_t* ids, int32_t* dists, int32_t* counts,
                 bool nearest, hipStream_t st);
 int gm_pg_incomplete(gm_index* idx, int64_t* n_inc, int64_t* pairs_evaluated, hipStream_t st);
+// (rows_only != nullptr: no compact copy of the candidates -- *q2 = the candidate planes as they are, *rows_only = the
+// device list of the rows, for a consumer that indexes through it (the K1L re-scans))
 int gm_pg_gather(gm_index* idx, int64_t n_inc, int k, bool nearest, const uint2** q2, int32_t** ids2,
-                 int32_t** dists2, int32_t** counts2, hipStream_t st);
+                 int32_t** dists2, int32_t** counts2, hipStream_t st, const int32_t** rows_only = nullptr);
 int gm_pg_scatter(gm_index* idx, int64_t n_inc, int k, bool nearest, int32_t* ids, int32_t* dists, int32_t* counts,
                   hipStream_t st);
 // prefix re-scan of the incomplete rows (gmhip.hip run_hamming_pigeon): fraction of the pool (in id order) that

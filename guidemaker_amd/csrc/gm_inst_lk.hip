@@ -27,7 +27,7 @@ int launch_lk_cfg(gm_index* idx, const gm_lk_args& a, hipStream_t st) {
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)chunks, (unsigned)a.n_seg), dim3(gm::WAVE), lds, st, idx->d_onehot,
                        (int)idx->n_db, a.n_tiles > 0 ? a.n_tiles : (int)idx->n_lk_tiles, a.tiles_per_seg, a.seg_base, a.q ? a.q : idx->d_q, a.n_q, a.k,
-                       a.seed_keys, a.out_keys, a.ids, a.dists, a.counts, a.n_dev, a.seed_all);
+                       a.seed_keys, a.out_keys, a.ids, a.dists, a.counts, a.n_dev, a.seed_all, a.q_rows);
     HIP_TRY(hipGetLastError());
     return GM_OK;
 }

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(WAVE, lk_min_waves(L, KCAP)) void k_hamming_knn_lk(
     const uint32_t* __restrict__ table, int n_db, int n_tiles, int tiles_per_seg, int seg_base,
     const uint2* __restrict__ q, int64_t n_q, int k, const uint32_t* __restrict__ seed_keys,
     uint32_t* __restrict__ out_keys, int32_t* __restrict__ ids, int32_t* __restrict__ dists,
-    int32_t* __restrict__ counts, const int* __restrict__ n_dev, uint32_t seed_all) {
+    int32_t* __restrict__ counts, const int* __restrict__ n_dev, uint32_t seed_all, const int32_t* __restrict__ q_rows) {
     extern __shared__ __align__(16) uint32_t smem[];
     // (speculative follow-ups of K1P: the grid was sized for an upper bound of the rows; the count is on the device)
     const int64_t n_out = n_q;      // row stride of the segment lists: the host's number
@@ -275,7 +275,9 @@ __global__ __launch_bounds__(WAVE, lk_min_waves(L, KCAP)) void k_hamming_knn_lk(
 
     const int64_t qi = (int64_t)blockIdx.x * WAVE + lane;
     const bool valid = qi < n_q;
-    const uint2 qv = valid ? q[qi] : make_uint2(0u, 0u);
+    // (q_rows != nullptr: candidate qi is row q_rows[qi] of q -- K1P's re-scans read the rows the merge listed, flag bit
+    // masked, instead of a compact copy that a kernel of its own would have to gather first)
+    const uint2 qv = valid ? q[q_rows != nullptr ? (int64_t)((uint32_t)q_rows[qi] & 0x7fffffffu) : qi] : make_uint2(0u, 0u);
 
     // LDS address of this lane's (position, base) pair inside group 0 of buffer 0
     const uint32_t* ptr[L];

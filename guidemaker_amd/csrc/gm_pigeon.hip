@@ -1761,16 +1761,21 @@ int gm_pg_count_incomplete(gm_index* idx, int64_t n, int need, const int32_t* co
 }
 
 int gm_pg_gather(gm_index* idx, int64_t n_inc, int k, bool nearest, const uint2** q2, int32_t** ids2, int32_t** dists2,
-                 int32_t** counts2, hipStream_t st) {
+                 int32_t** counts2, hipStream_t st, const int32_t** rows_only) {
     gm_pigeon* pg = idx->pg;
     int rc;
-    if ((rc = ensure(&pg->q2, &pg->q2_cap, n_inc, "compact query"))) return rc;
+    if (rows_only == nullptr && (rc = ensure(&pg->q2, &pg->q2_cap, n_inc, "compact query"))) return rc;
     if ((rc = ensure(&pg->ids2, &pg->ids2_cap, n_inc * k, "compact ids"))) return rc;
     if ((rc = ensure(&pg->dists2, &pg->dists2_cap, n_inc * k, "compact distances"))) return rc;
     if ((rc = ensure(&pg->counts2, &pg->counts2_cap, n_inc, "compact counts"))) return rc;
-    hipLaunchKernelGGL(k_gather_rows, grid_for(n_inc), dim3(256), 0, st, idx->d_q, pg->inc, n_inc, pg->q2, idx->dev_rows);
-    HIP_TRY(hipGetLastError());
-    *q2 = pg->q2;
+    if (rows_only != nullptr) {
+        *rows_only = pg->inc;
+        *q2 = idx->d_q;
+    } else {
+        hipLaunchKernelGGL(k_gather_rows, grid_for(n_inc), dim3(256), 0, st, idx->d_q, pg->inc, n_inc, pg->q2, idx->dev_rows);
+        HIP_TRY(hipGetLastError());
+        *q2 = pg->q2;
+    }
     *ids2 = nearest ? nullptr : pg->ids2;
     *dists2 = pg->dists2;
     *counts2 = nearest ? nullptr : pg->counts2;

@@ -882,34 +882,32 @@ __global__ void k_merge_pg3(const uint32_t* __restrict__ keys, int n_lists, int6
     const int n_words = (int)rows_here * KCAP;
     // (the NEXT list's words are fetched into registers while this one is merged -- KCAP words per thread, 256 threads --
     // and moved to LDS behind the merge: the kernel is memory-bound and ran list by list, load -> wait -> merge)
-    uint32_t nxt[KCAP];
-    auto fetch = [&](int l) {
+    auto fetch = [&](int l, uint32_t (&dst)[KCAP]) {
         const uint32_t* __restrict__ in = keys + ((int64_t)l * n_stride + row0) * KCAP;
 #pragma unroll
         for (int i = 0; i < KCAP; ++i) {
             const int w = (int)threadIdx.x + i * 256;
 #if defined(GM_PG_TIMING) && (GM_PG_TIMING & 8)      // timing build only (results WRONG): no list loads
-            nxt[i] = (uint32_t)(w * 2654435761u) | 1u;
+            dst[i] = (uint32_t)(w * 2654435761u) | 1u;
             (void)in;
 #else
-            nxt[i] = w < n_words ? in[w] : NONE;
+            dst[i] = w < n_words ? in[w] : NONE;
 #endif
         }
     };
-    fetch(0);
-    for (int l = 0; l < n_lists; ++l) {
-        if (l > 0) __syncthreads();      // the previous list has been read
+    // one list: its words (in registers) -> LDS -> this thread's row -> merged into a[]
+    auto fold_in = [&](const uint32_t (&src)[KCAP], bool first) {
+        if (!first) __syncthreads();      // the previous list has been read
 #pragma unroll
-        for (int i = 0; i < KCAP; ++i) s_in[(int)threadIdx.x + i * 256] = nxt[i];
+        for (int i = 0; i < KCAP; ++i) s_in[(int)threadIdx.x + i * 256] = src[i];
         __syncthreads();
-        if (l + 1 < n_lists) fetch(l + 1);
         uint32_t b[KCAP];
 #pragma unroll
         for (int i = 0; i < KCAP; ++i) b[i] = i < k && valid ? s_in[(int)threadIdx.x * KCAP + lead + i] : NONE;
-        if (l == 0) {
+        if (first) {
 #pragma unroll
             for (int i = 0; i < KCAP; ++i) a[i] = b[i];
-            continue;
+            return;
         }
         uint32_t out[KCAP];
 #pragma unroll
@@ -929,6 +927,32 @@ __global__ void k_merge_pg3(const uint32_t* __restrict__ keys, int n_lists, int6
         }
 #pragma unroll
         for (int i = 0; i < KCAP; ++i) a[i] = out[i];
+    };
+    if constexpr (KCAP <= 5) {
+        // short lists (k <= 5, the reference's default): a list is 5 KB per workgroup and its fetch is all latency -- the
+        // first four lists are requested together (S3's first level: 68 us for 93 MB)
+        constexpr int AHEAD = 4;
+        uint32_t pre[AHEAD][KCAP];
+#pragma unroll
+        for (int j = 0; j < AHEAD; ++j)
+            if (j < n_lists) fetch(j, pre[j]);
+#pragma unroll
+        for (int j = 0; j < AHEAD; ++j)
+            if (j < n_lists) fold_in(pre[j], j == 0);
+        for (int l = AHEAD; l < n_lists; ++l) {
+            uint32_t nxt[KCAP];
+            fetch(l, nxt);
+            fold_in(nxt, false);
+        }
+    } else {
+        uint32_t cur[KCAP], nxt[KCAP];
+        fetch(0, cur);
+        for (int l = 0; l < n_lists; ++l) {
+            if (l + 1 < n_lists) fetch(l + 1, nxt);      // (in flight while list l is merged)
+            fold_in(cur, l == 0);
+#pragma unroll
+            for (int i = 0; i < KCAP; ++i) cur[i] = nxt[i];
+        }
     }
     // -> the register-list image the rest of the pipeline stores from: unused leading slots 0, then the keys
     RegList<KCAP> list;

@@ -162,9 +162,10 @@ int launch_merge(int kcap, const uint32_t* keys, int n_seg, int64_t n_q, int k, 
 // the pool is cut for THAT many (S4: 249 rows under a bound of 2 359 got a tenth of the segments they fill the chip with).
 int run_hamming_lookup(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t* ids, int32_t* dists,
                        int32_t* counts, bool timed, hipStream_t st, const uint2* qplanes = nullptr,
-                       int guess_thr = 0, int64_t n_expect = -1) {
+                       int guess_thr = 0, int64_t n_expect = -1, const int32_t* q_rows = nullptr) {
     gm_lk_args a;
     a.q = qplanes;
+    a.q_rows = q_rows;
     a.n_dev = qplanes != nullptr ? idx->dev_rows : nullptr;      // (K1P's re-scan of compact rows in a speculative run)
     a.kcap = nearest ? 1 : (idx->variant == 7 || k > 20 ? 0 : (k <= 5 ? 5 : (k <= 10 ? 10 : 20)));
     a.n_q = n_q;
@@ -617,10 +618,11 @@ int run_leven_lookup(gm_index* idx, int64_t n_q, int k, int32_t* ids, int32_t* d
 // K1P prefix re-scan (gm_pg_prefix_fraction): K1L over the first `frac` of the pool (id order) for the n compacted rows
 // under the bound guess_thr; its segment lists complete the rows' partial K1P lists in place (ids / dists / counts: the
 // ORIGINAL rows), and the rows still short become the handle's list of incomplete rows (gm_pg_merge_prefix).
-int run_hamming_prefix(gm_index* idx, bool nearest, int64_t n, int k, int kcap, const uint2* q2, int guess_thr, double frac,
-                       int32_t* ids, int32_t* dists, int32_t* counts, hipStream_t st) {
+int run_hamming_prefix(gm_index* idx, bool nearest, int64_t n, int k, int kcap, const uint2* q2, const int32_t* q_rows, int guess_thr,
+                       double frac, int32_t* ids, int32_t* dists, int32_t* counts, hipStream_t st) {
     gm_lk_args a;
     a.q = q2;
+    a.q_rows = q_rows;
     a.n_dev = idx->dev_rows;
     a.kcap = kcap;
     a.n_q = n;
@@ -943,15 +945,17 @@ static int run_pigeon_level(gm_index* idx, int level, bool nearest, int64_t n_q,
     int64_t n_real = sp && level < GM_PG_LEVELS ? idx->spec.ninc[level] : -1;      // speculative run: rows expected under the bound n_inc
     if (n_inc > 0) {
         const uint2* q2 = nullptr;
+        const int32_t* q_rows = nullptr;      // (the K1L re-scans read the listed rows in place: no compact copy, no gather launch)
         int32_t *ids2 = nullptr, *dists2 = nullptr, *counts2 = nullptr;
-        if ((rc = gm_pg_gather(idx, n_inc, keff, nearest, &q2, &ids2, &dists2, &counts2, st))) return rc;
         // Cascade: many rows left short (their k-th neighbour lies beyond this level's radius: the planner chose the
         // radius the majority needs) -> a deeper K1P level over the compact rows, planned for THEIR number and the
         // conditional distribution of their k-th neighbour; what that level leaves takes its own re-scan paths.
-        if (level + 1 < GM_PG_LEVELS && idx->pg_cascade != 0 && idx->pg_flooded_k1 != keff + 1 &&
+        const bool go_deeper = level + 1 < GM_PG_LEVELS && idx->pg_cascade != 0 && idx->pg_flooded_k1 != keff + 1 &&
             (idx->pg_cascade == 2 ? n_inc_dec >= 64
                                   : (n_inc_dec >= 4096 && !idx->plan_p_short.empty() &&
-                                     (idx->plan_cascade != 0 || n_inc_dec >= 16384)))) {      // (the plan counted on a deeper level, or far more rows are short than it expected)
+                                     (idx->plan_cascade != 0 || n_inc_dec >= 16384)));      // (the plan counted on a deeper level, or far more rows are short than it expected)
+        if ((rc = gm_pg_gather(idx, n_inc, keff, nearest, &q2, &ids2, &dists2, &counts2, st, go_deeper ? nullptr : &q_rows))) return rc;
+        if (go_deeper) {
             std::vector<double> ps2;
             if (!idx->plan_p_short.empty()) {
                 const int L = idx->L;
@@ -985,7 +989,7 @@ static int run_pigeon_level(gm_index* idx, int level, bool nearest, int64_t n_q,
         const double frac = sp && level < GM_PG_LEVELS ? idx->spec.frac[level] : gm_pg_prefix_fraction(idx, keff);
         if (!sp && level < GM_PG_LEVELS) idx->spec.frac[level] = frac;
         if (frac <= 0.6) {
-            if ((rc = run_hamming_prefix(idx, nearest, n_inc, keff, kcap, q2, radius + 2, frac, ids, dists, counts, st)))
+            if ((rc = run_hamming_prefix(idx, nearest, n_inc, keff, kcap, q2, q_rows, radius + 2, frac, ids, dists, counts, st)))
                 return rc;
             int64_t n_left = 0;
             if (sp) {
@@ -1010,13 +1014,13 @@ static int run_pigeon_level(gm_index* idx, int level, bool nearest, int64_t n_q,
             }
             n_inc = n_left;
             n_real = sp && level < GM_PG_LEVELS ? idx->spec.nleft[level] : -1;
-            if ((rc = gm_pg_gather(idx, n_inc, keff, nearest, &q2, &ids2, &dists2, &counts2, st))) return rc;
+            if ((rc = gm_pg_gather(idx, n_inc, keff, nearest, &q2, &ids2, &dists2, &counts2, st, &q_rows))) return rc;
         }
         // these rows have fewer than k neighbours within r (or a flooded slot list): their k-th neighbour is
         // almost surely at r + 1, so scan under the bound d < r + 2 first and fall back to the unseeded scan
         // only if a list still does not fill
         const int guess = radius + 2;
-        if ((rc = run_hamming_lookup(idx, nearest, n_inc, keff, ids2, dists2, counts2, false, st, q2, guess, n_real))) return rc;
+        if ((rc = run_hamming_lookup(idx, nearest, n_inc, keff, ids2, dists2, counts2, false, st, q2, guess, n_real, q_rows))) return rc;
         if ((rc = gm_pg_scatter(idx, n_inc, keff, nearest, ids, dists, counts, st))) return rc;
         // the rows whose list did not fill under the guess (and only those) go through the unseeded scan
         int64_t n_bad = 0;
@@ -1039,9 +1043,9 @@ static int run_pigeon_level(gm_index* idx, int level, bool nearest, int64_t n_q,
             fprintf(stderr, "[gm] plain re-scan: %lld rows under the bound %d, %lld left for the unseeded scan\n", (long long)n_inc,
                     guess, (long long)n_bad);
         if (n_bad > 0) {
-            if ((rc = gm_pg_gather(idx, n_bad, keff, nearest, &q2, &ids2, &dists2, &counts2, st))) return rc;
+            if ((rc = gm_pg_gather(idx, n_bad, keff, nearest, &q2, &ids2, &dists2, &counts2, st, &q_rows))) return rc;
             if ((rc = run_hamming_lookup(idx, nearest, n_bad, keff, ids2, dists2, counts2, false, st, q2, 0,
-                                         sp && level < GM_PG_LEVELS ? idx->spec.nbad[level] : -1)))
+                                         sp && level < GM_PG_LEVELS ? idx->spec.nbad[level] : -1, q_rows)))
                 return rc;
             if ((rc = gm_pg_scatter(idx, n_bad, keff, nearest, ids, dists, counts, st))) return rc;
         }
