@@ -986,9 +986,14 @@ __global__ void k_merge_pg3(const uint32_t* __restrict__ keys, int n_lists, int6
         for (int s = 0; s < KCAP; ++s) c += (list.v[s] != 0u && list.v[s] != NONE) ? 1 : 0;
         atomicAdd(&s_hist[c < 23 ? c : 23], 1);      // (the host sizes the prefix re-scan from this)
     }
+#if defined(GM_PG_TIMING) && (GM_PG_TIMING & 32)      // timing build only (results WRONG): no device-wide atomics in the merge
+    __syncthreads();
+    if (take) inc[qi] = entry;
+#else
     gm_block_append(take, entry, inc, inc_count);      // (contains the barrier that orders the LDS counters)
     if (threadIdx.x < 24 && s_hist[threadIdx.x] != 0) atomicAdd(&chist[threadIdx.x], s_hist[threadIdx.x]);
     if (threadIdx.x == 24 && s_over != 0) atomicAdd(over_count, s_over);
+#endif
     // the rows' results leave through LDS as well: ids / dists of the workgroup's rows are one contiguous run each
     if (nearest != 0) {
         if (owner) list.store(k, qi, ids, dists, counts, true);

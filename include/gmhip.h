@@ -254,6 +254,8 @@ int gm_set_variant(gm_index* idx, int variant);
  *   expansion chunk of the pigeonhole-partitioned scan are split over on the hit-buffer path (more = shorter work items and
  *   more hit lists per candidate);
  *   "pg_run" (0 = choose: 128, 32 on the register-list path): consecutive chunk-table entries of that scan executed on the same XCD;
+ *   "pg_group" (0 = choose: two levels from 262 144 candidates; 1 = one counting sort; 2 = two levels): how that scan's
+ *   candidates are grouped by block value (gm_group.hip.h: partitions of the high key bits, then an LDS sort per partition);
  *   "pg_layout": force a layout of that scan, decimal digit pairs (bases, radius) per block, e.g. 826161 = blocks of
  *   8, 6, 6 bases with the two-, one-, one-substitution neighbourhoods (0 = let the planner choose);
  *   "pg_gap": 2 = every copy's table leaves out its own block up to the length of the most-visited block (one launch
