@@ -462,9 +462,14 @@ struct gm_pigeon {
     int64_t ctmp_cap[GM_PG_MAXB]{};
     int* part_words = nullptr;
     int64_t part_words_cap = 0;
+    int32_t* inc_slots = nullptr;      // the merge's incomplete rows per workgroup (gm::pg_block_stash) and their counters
+    int64_t inc_slots_cap = 0;
+    int* inc_meta = nullptr;
+    int64_t inc_meta_cap = 0;
     uint32_t* gsum = nullptr;          // k_group_sums: groups per chunk of every (entry, run of target buckets) ...
     int64_t gsum_cap = 0;
     std::vector<int64_t> gsum_sig;     // ... for this geometry and these pool copies
+    int tune_slots = 0;                // gm_set_param "pg_slots": the merge's list of incomplete rows: 0 = choose, 1 = atomics, 2 = workgroup slots
     int tune_group = 0;                // gm_set_param "pg_group": 0 = choose (two levels from 262 144 candidates), 1 = one level, 2 = two levels
     int32_t* coff[GM_PG_MAXB]{};
     uint32_t *k0 = nullptr, *k1 = nullptr, *r0 = nullptr, *r1 = nullptr;
@@ -963,6 +968,7 @@ void gm_pg_inherit(gm_index* idx, const gm_pigeon* parent) {
     pg->tune_hit = parent->tune_hit;
     pg->tune_run = parent->tune_run;
     pg->tune_group = parent->tune_group;
+    pg->tune_slots = parent->tune_slots;
     pg->tune_msplit = parent->tune_msplit;
     pg->tune_prefix = parent->tune_prefix;
     pg->tune_layout = idx->pg_layout_deeper;
@@ -1041,6 +1047,11 @@ int gm_pg_set_param(gm_index* idx, const char* name, int value) {
         idx->pg->tune_run = value;
         return GM_OK;
     }
+    if (std::strcmp(name, "pg_slots") == 0) {      // the register-list merge's list of incomplete rows: 0 = choose, 1 = atomics, 2 = slots
+        if (value < 0 || value > 2) return gm_fail(GM_ERR_ARG, "pg_slots: 0, 1 or 2");
+        idx->pg->tune_slots = value;
+        return GM_OK;
+    }
     if (std::strcmp(name, "pg_group") == 0) {      // candidate grouping: 0 = choose, 1 = one counting sort, 2 = two levels
         if (value < 0 || value > 2) return gm_fail(GM_ERR_ARG, "pg_group: 0, 1 or 2");
         idx->pg->tune_group = value;
@@ -1059,7 +1070,7 @@ void gm_pg_free(gm_index* idx) {
         if (pg->cperm[b]) (void)hipFree(pg->cperm[b]);
         if (pg->ctmp[b]) (void)hipFree(pg->ctmp[b]);
     }
-    void* bufs[] = {pg->part_words, pg->gsum, pg->k0, pg->k1, pg->r0, pg->r1, pg->sort_tmp, pg->nch, pg->cbase, pg->hist, pg->cursor, pg->chunks, pg->ctr,
+    void* bufs[] = {pg->part_words, pg->gsum, pg->inc_slots, pg->inc_meta, pg->k0, pg->k1, pg->r0, pg->r1, pg->sort_tmp, pg->nch, pg->cbase, pg->hist, pg->cursor, pg->chunks, pg->ctr,
                     pg->lists, pg->hdr, pg->keys3, pg->raw_off, pg->inc, pg->inc_b, pg->cflag, pg->shist, pg->q2, pg->ids2, pg->dists2, pg->counts2};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
@@ -1573,16 +1584,26 @@ int gm_pg_merge(gm_index* idx, int kcap, int64_t n_q, int k, int32_t* ids, int32
     int rc;
     if ((rc = ensure(&pg->inc, &pg->inc_cap, n_q, "incomplete rows"))) return rc;
     const int nr = nearest ? 1 : 0;
-    int* n_inc = &pg->ctr->n_inc;
     int split = kcap >= 20 ? 2 : 4;      // (S4, k = 20: 15.3 / 15.0 / 15.8 ms per query with 1 / 2 / 4; S1, k = 10: 1.23 / 1.15 / 1.13)
     if (pg->tune_msplit > 0) split = pg->tune_msplit;
-    const dim3 grid = grid_for(n_q * split), block(256);
+    const dim3 grid = pg->hit_reg ? grid_for(n_q) : grid_for(n_q * split), block(256);
+    int* n_inc = &pg->ctr->n_inc;
+    // Where many rows are expected short (about one per workgroup or more: S1 0.9 %, a cascade's first level 12 .. 30 %) the
+    // register-list merge lists them WITHOUT device-wide atomics: a slot per workgroup, packed by k_compact_inc (S3's first
+    // level 63 -> 21 + 12 us, PAO1's 89 -> 45 + 12, S1's 45 -> 31 + 9).  Where hardly any are (S4: 249 of 3.1 M) and on the
+    // hit-buffer merge (its time is its key reads: 49 -> 41 + 10) the atomics stay.
+    const bool slots = pg->hit_reg && (pg->tune_slots == 2 || (pg->tune_slots == 0 && n_q >= 65536 && pg->expect_short * 256.0 >= 0.5));
+    const int64_t n_wg = grid.x;
+    if (slots) {
+        if ((rc = ensure(&pg->inc_slots, &pg->inc_slots_cap, n_wg * gm::PG_STASH_ROWS, "incomplete rows (workgroup slots)"))) return rc;
+        if ((rc = ensure(&pg->inc_meta, &pg->inc_meta_cap, n_wg * (gm::PG_STASH_META + 1), "incomplete rows (workgroup counters)"))) return rc;
+    }
 #define GM_MERGE(KC, SP)                                                                                                          \
     do {                                                                                                                          \
         if (pg->hit_reg)                                                                                                          \
-            hipLaunchKernelGGL((gm::k_merge_pg3<KC, 1>), grid_for(n_q), block, 0, st, pg->keys3, pg->blocks.n_lists, n_q, k, ids,  \
-                               dists, counts, nr, pg->inc, n_inc, &pg->ctr->n_over, pg->ctr->chist,                               \
-                               pg->cut_id != 0xffffffffu ? pg->cflag : nullptr, idx->dev_nq);                                     \
+            hipLaunchKernelGGL((gm::k_merge_pg3<KC, 1>), grid, block, 0, st, pg->keys3, pg->blocks.n_lists, n_q, k, ids, dists,    \
+                               counts, nr, pg->inc, n_inc, &pg->ctr->n_over, pg->ctr->chist, slots ? pg->inc_slots : nullptr,     \
+                               slots ? pg->inc_meta : nullptr, pg->cut_id != 0xffffffffu ? pg->cflag : nullptr, idx->dev_nq);     \
         else                                                                                                                      \
             hipLaunchKernelGGL((gm::k_merge_hits<KC, SP>), grid, block, 0, st, pg->blocks, pg->lists, n_q, k, ids, dists, counts,  \
                                nr, pg->inc, n_inc, &pg->ctr->n_over, pg->ctr->chist,                                              \
@@ -1598,6 +1619,11 @@ int gm_pg_merge(gm_index* idx, int kcap, int64_t n_q, int k, int32_t* ids, int32
 #undef GM_MERGE_KC
 #undef GM_MERGE
     HIP_TRY(hipGetLastError());
+    if (slots) {
+        hipLaunchKernelGGL(gm::k_compact_inc, dim3((unsigned)((n_wg + gm::PG_COMPACT_WGS - 1) / gm::PG_COMPACT_WGS)), dim3(256), 0, st,
+                           pg->inc_slots, pg->inc_meta, (int)n_wg, pg->inc, n_inc, &pg->ctr->n_over, pg->ctr->chist);
+        HIP_TRY(hipGetLastError());
+    }
     return GM_OK;
 }
 

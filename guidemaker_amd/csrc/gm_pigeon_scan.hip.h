@@ -765,6 +765,91 @@ __device__ __forceinline__ void gm_block_append(bool take, int32_t value, int32_
     if (take) out[s_base + s_wave[wave] + before] = value;
 }
 
+// The K1P merges list their incomplete rows WITHOUT device-wide atomics: a workgroup ranks its entries (ballots + an LDS scan,
+// as gm_block_append), writes them to its own slot of `stash` (PG_STASH_ROWS entries per workgroup) and its count and
+// counters to `meta` (the counts, dense, then PG_STASH_META words per workgroup: chist[24], overflowed rows); k_compact_inc packs the slots.
+// (One returning atomic on the list cursor + up to 25 on the counters per workgroup were most of a memory-bound merge:
+// S3's first level 63 -> 18 us, PAO1's 89 -> 45, S1's 45 -> 30 without them.)
+constexpr int PG_STASH_ROWS = 256;      // = the merge kernels' workgroup size
+constexpr int PG_STASH_META = 32;
+__device__ __forceinline__ void pg_block_stash(bool take, int32_t value, const int* s_hist24, const int* s_over, int32_t* __restrict__ stash,
+                                               int* __restrict__ meta) {
+    __shared__ int s_wave[16];
+    const uint64_t bal = __builtin_amdgcn_ballot_w64(take);
+    const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+    const int before = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+    if (lane == 0) s_wave[wave] = __builtin_popcountll(bal);
+    __syncthreads();      // (also orders the caller's LDS counters)
+    const int n_waves = (int)((blockDim.x + 63u) >> 6);
+    int base = 0, tot = 0;
+    for (int w = 0; w < n_waves; ++w) {
+        const int c = s_wave[w];
+        base += w < wave ? c : 0;
+        tot += c;
+    }
+    // meta: [gridDim.x] counts (dense: k_compact_inc sums runs of them), then PG_STASH_META counter words per workgroup
+    int* __restrict__ m = meta + gridDim.x + (int64_t)blockIdx.x * PG_STASH_META;
+    if (take) stash[(int64_t)blockIdx.x * PG_STASH_ROWS + base + before] = value;
+    if (threadIdx.x == 0) meta[blockIdx.x] = tot;
+    if (threadIdx.x >= 1 && threadIdx.x <= 24) m[threadIdx.x] = s_hist24[threadIdx.x - 1];
+    if (threadIdx.x == 25) m[25] = *s_over;
+}
+// the slots of PG_COMPACT_WGS consecutive merge workgroups per workgroup -> inc[0 .. n_inc), *inc_count, *over_count, chist[]
+constexpr int PG_COMPACT_WGS = 16;      // (64: 10 -> 28 us)
+static __global__ __launch_bounds__(256) void k_compact_inc(const int32_t* __restrict__ stash, const int* __restrict__ meta, int n_wg,
+                                                     int32_t* __restrict__ inc, int* __restrict__ inc_count, int* __restrict__ over_count,
+                                                     int* __restrict__ chist) {
+    __shared__ int s_red[4], s_off[PG_COMPACT_WGS + 1], s_cnt[PG_COMPACT_WGS];
+    const int tid = threadIdx.x, w0 = blockIdx.x * PG_COMPACT_WGS;
+    int before = 0;      // entries of the workgroups in front of this one's
+    // (w0 is a multiple of 16: whole int4s; four of them in flight per thread -- one 4-byte load per loop iteration made this
+    // walk over a few thousand counts most of the kernel's 9 .. 13 us)
+    const int4* __restrict__ m4 = reinterpret_cast<const int4*>(meta);
+    for (int w = tid; w < w0 / 4; w += 4 * 256) {
+        int4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = w + j * 256 < w0 / 4 ? m4[w + j * 256] : make_int4(0, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) before += v[j].x + v[j].y + v[j].z + v[j].w;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d, 64);
+    if ((tid & 63) == 0) s_red[tid >> 6] = before;
+    if (tid < PG_COMPACT_WGS) s_cnt[tid] = w0 + tid < n_wg ? meta[w0 + tid] : 0;      // (all of them in flight at once)
+    __syncthreads();
+    if (tid == 0) {
+        int run = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+        for (int j = 0; j < PG_COMPACT_WGS; ++j) {
+            s_off[j] = run;
+            run += s_cnt[j];
+        }
+        s_off[PG_COMPACT_WGS] = run;
+        if (w0 + PG_COMPACT_WGS >= n_wg) *inc_count = run;      // (the last workgroup: the total)
+    }
+    if (tid >= 64 + 1 && tid <= 64 + 25) {      // counters of this workgroup's slots (a wave of its own: not behind thread 0's scan)
+        const int c = tid - 64;
+        int sum = 0;
+        for (int j0 = 0; j0 < PG_COMPACT_WGS; j0 += 16) {
+            int v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = w0 + j0 + j < n_wg ? meta[n_wg + (int64_t)(w0 + j0 + j) * PG_STASH_META + c] : 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) sum += v[j];
+        }
+        if (sum != 0) atomicAdd(c <= 24 ? &chist[c - 1] : over_count, sum);
+    }
+    __syncthreads();
+    // all the slots' entries as one index space (a slot-by-slot loop was a load -> store round trip per slot)
+    const int first = s_off[0], total = s_off[PG_COMPACT_WGS] - first;
+    for (int t = tid; t < total; t += 256) {
+        int j = 0;
+#pragma unroll
+        for (int step = PG_COMPACT_WGS / 2; step >= 1; step >>= 1)
+            if (s_off[j + step] - first <= t) j += step;
+        inc[first + t] = stash[(int64_t)(w0 + j) * PG_STASH_ROWS + (t - (s_off[j] - first))];
+    }
+}
+
 // K1P merge: SPLIT adjacent lanes per candidate (4 for lists of <= 10 keys, where the kernel waits for memory; fewer
 // for 20 keys, where the sorted-insert ripples of a divergent wave are the cost), each folding every SPLIT-th hit list into its
 // own register list (duplicates taken once), then lane 0 of the group takes the other lists over by shuffles and
@@ -860,8 +945,8 @@ template <int KCAP, int SPLIT>
 __global__ void k_merge_pg3(const uint32_t* __restrict__ keys, int n_lists, int64_t n_q, int k,
                             int32_t* __restrict__ ids, int32_t* __restrict__ dists, int32_t* __restrict__ counts,
                             int nearest, int32_t* __restrict__ inc, int* __restrict__ inc_count,
-                            int* __restrict__ over_count, int* __restrict__ chist, const uint8_t* __restrict__ cflag,
-                            const int* __restrict__ n_dev) {
+                            int* __restrict__ over_count, int* __restrict__ chist, int32_t* __restrict__ stash, int* __restrict__ meta,
+                            const uint8_t* __restrict__ cflag, const int* __restrict__ n_dev) {
     static_assert(SPLIT == 1, "one thread per row");
     const int64_t n_stride = n_q;      // row stride of the raw lists: the host's number
     if (n_dev != nullptr && *n_dev < n_q) n_q = *n_dev;      // (speculative follow-ups: launched for an upper bound)
@@ -986,14 +1071,14 @@ __global__ void k_merge_pg3(const uint32_t* __restrict__ keys, int n_lists, int6
         for (int s = 0; s < KCAP; ++s) c += (list.v[s] != 0u && list.v[s] != NONE) ? 1 : 0;
         atomicAdd(&s_hist[c < 23 ? c : 23], 1);      // (the host sizes the prefix re-scan from this)
     }
-#if defined(GM_PG_TIMING) && (GM_PG_TIMING & 32)      // timing build only (results WRONG): no device-wide atomics in the merge
-    __syncthreads();
-    if (take) inc[qi] = entry;
-#else
-    gm_block_append(take, entry, inc, inc_count);      // (contains the barrier that orders the LDS counters)
-    if (threadIdx.x < 24 && s_hist[threadIdx.x] != 0) atomicAdd(&chist[threadIdx.x], s_hist[threadIdx.x]);
-    if (threadIdx.x == 24 && s_over != 0) atomicAdd(over_count, s_over);
-#endif
+    // (both contain the barrier that orders the LDS counters)
+    if (meta != nullptr) {      // many rows are expected short: workgroup slots, packed by k_compact_inc -- no device-wide atomics
+        pg_block_stash(take, entry, s_hist, &s_over, stash, meta);
+    } else {                    // hardly any (S4: 1 in 12 000): one atomic in the few workgroups that have one
+        gm_block_append(take, entry, inc, inc_count);
+        if (threadIdx.x < 24 && s_hist[threadIdx.x] != 0) atomicAdd(&chist[threadIdx.x], s_hist[threadIdx.x]);
+        if (threadIdx.x == 24 && s_over != 0) atomicAdd(over_count, s_over);
+    }
     // the rows' results leave through LDS as well: ids / dists of the workgroup's rows are one contiguous run each
     if (nearest != 0) {
         if (owner) list.store(k, qi, ids, dists, counts, true);

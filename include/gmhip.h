@@ -254,6 +254,9 @@ int gm_set_variant(gm_index* idx, int variant);
  *   expansion chunk of the pigeonhole-partitioned scan are split over on the hit-buffer path (more = shorter work items and
  *   more hit lists per candidate);
  *   "pg_run" (0 = choose: 128, 32 on the register-list path): consecutive chunk-table entries of that scan executed on the same XCD;
+ *   "pg_slots" (0 = choose: slots where about one row per workgroup or more is expected short; 1 = one device-wide atomic per
+ *   workgroup; 2 = slots): how the register-list merge lists the rows it leaves incomplete (a slot per workgroup, packed by a
+ *   second kernel, instead of atomics on one cursor);
  *   "pg_group" (0 = choose: two levels from 262 144 candidates; 1 = one counting sort; 2 = two levels): how that scan's
  *   candidates are grouped by block value (gm_group.hip.h: partitions of the high key bits, then an LDS sort per partition);
  *   "pg_layout": force a layout of that scan, decimal digit pairs (bases, radius) per block, e.g. 826161 = blocks of

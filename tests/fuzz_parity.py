@@ -51,6 +51,7 @@ def run(seconds, seed, max_cases=None):
             hit = rng.choice([0, 1, 2])      # K1P's hit path: hit buffer / per level / register lists
             idx.set_param("pg_hit", hit)
             idx.set_param("pg_group", rng.choice([0, 1, 2]))      # candidate grouping: chosen / one level / two levels
+            idx.set_param("pg_slots", rng.choice([0, 1, 2]))      # the merge's list of incomplete rows: chosen / atomics / slots
         qp = _lib.pack(q, L)
         ids, dists, counts = idx.knn(qp, k)
         d1 = idx.nearest(qp)

@@ -434,6 +434,7 @@ def test_pigeonhole_layouts_match_oracle(oracle, L, variant, hit):
     idx.set_variant(variant)
     idx.set_param("pg_hit", hit)
     idx.set_param("pg_group", 1 if hit == 0 else 2)      # candidate grouping: one counting sort / two levels (partitions)
+    idx.set_param("pg_slots", 1 if (L + variant) % 2 else 2)      # the merge's list of incomplete rows: atomics / workgroup slots
     qp = _lib.pack(q, L)
     for k in (2, 5, 10, 20):
         ids, dists, counts = idx.knn(qp, k)
@@ -1342,7 +1343,7 @@ def test_speculative_follow_ups_are_exact(oracle):
     want1 = plain.nearest(foreign)
     plain.close()
     for setup in ({}, {"pg_layout": 717160, "pg_cascade": 2, "pg_layout2": 61515140}, {"pg_hit": 2},
-                  {"pg_group": 2, "pg_layout": 717160, "pg_cascade": 2, "pg_layout2": 61515140}):
+                  {"pg_group": 2, "pg_slots": 2, "pg_hit": 2, "pg_layout": 717160, "pg_cascade": 2, "pg_layout2": 61515140}):
         idx = _lib.Index(db, L, _lib.METRIC_HAMMING)
         try:
             for name, val in setup.items():

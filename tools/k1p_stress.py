@@ -113,6 +113,7 @@ def main():
             hit = int(rng.choice([0, 1, 2, 2]))      # hit buffer / chosen per level / register lists on every level
             idx.set_param("pg_hit", hit)
             idx.set_param("pg_group", int(rng.choice([0, 1, 2])))      # candidate grouping: chosen / one level / two levels
+            idx.set_param("pg_slots", int(rng.choice([0, 1, 2])))      # the merge's list of incomplete rows: chosen / atomics / slots
             if rng.random() < 0.2:      # (default: the planner scans a sample of the candidates when there are >= 32768)
                 idx.set_param("pg_sample", 0)
             casc = ""
