@@ -351,7 +351,11 @@ __global__ __launch_bounds__(1024) void k_part_scatter(const uint2* __restrict__
             cs[j] = e < n_parts ? s_cnt[e] : 0;
         }
 #pragma unroll
+#if defined(GM_PG_TIMING) && (GM_PG_TIMING & 128)      // timing build only (results WRONG): no device-wide atomics in the first pass
+        for (int j = 0; j < 4; ++j) bs[j] = cs[j];
+#else
         for (int j = 0; j < 4; ++j) bs[j] = cs[j] != 0 ? atomicAdd(&pcursor[(int)threadIdx.x + j * 1024], cs[j]) : 0;
+#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int e = (int)threadIdx.x + j * 1024;
@@ -373,8 +377,12 @@ __global__ __launch_bounds__(1024) void k_part_scatter(const uint2* __restrict__
             for (int b = 0; b < GM_PG_MAXB; ++b) {
                 if (b < K.B) {
                     const int lo = K.lo_bits[b];
+#if defined(GM_PG_TIMING) && (GM_PG_TIMING & 64)      // timing build only (results WRONG): no entry stores in the first pass
+                    if (s_cnt[K.part_base[b] + (key[t][b] >> lo)] + rank[t][b] == -12345) K.ctmp[b][0] = 0u;
+#else
                     K.ctmp[b][s_cnt[K.part_base[b] + (key[t][b] >> lo)] + rank[t][b]] =
                         ((uint32_t)i << PG_PART_LO_MAX) | (uint32_t)(key[t][b] & ((1 << lo) - 1));
+#endif
                 }
             }
         }
