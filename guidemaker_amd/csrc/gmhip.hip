@@ -901,6 +901,16 @@ static int run_pigeon_level(gm_index* idx, int level, bool nearest, int64_t n_q,
     if (timed && (rc = timing_end(idx, st, n_q * idx->n_db))) return rc;
     if ((rc = gm_pg_merge(idx, kcap, n_q, keff, ids, dists, counts, nearest, st))) return rc;
     int64_t n_inc = 0, pairs = 0;
+    int deferred = -1;      // speculative run: index of this level's "rows left by the merge" check while it has no publish yet
+    auto publish_merge_counts = [&]() -> int {      // (called with THIS level's state in the handle)
+        if (deferred < 0) return GM_OK;
+        gm_pg_pending p{};
+        const int e = gm_pg_publish_async(idx, 1, st, &p);
+        if (e) return e;
+        sp->checks[(size_t)deferred].pend = p;
+        deferred = -1;
+        return GM_OK;
+    };
     if (sp) {
         n_inc = spec_cap(idx->spec.ninc[level]);
         if (n_inc > n_q) n_inc = n_q;
@@ -909,8 +919,11 @@ static int run_pigeon_level(gm_index* idx, int level, bool nearest, int64_t n_q,
         c.level = level;
         c.kind = 0;
         c.cap = n_inc;
-        if ((rc = gm_pg_publish_async(idx, 1, st, &c.pend))) return rc;
+        // (no publish of its own yet: the level's counters as of the merge -- rows left, pairs, the histogram of the short
+        // rows -- do not change any more, so the level's NEXT publish, after the prefix / plain re-scan, carries them too;
+        // only a level that ends without one publishes here, `publish_merge_counts` below)
         sp->checks.push_back(c);
+        deferred = (int)sp->checks.size() - 1;
         idx->dev_rows = gm_pg_count_ptr(idx, 0);      // the rows the merge left: every re-scan launch below clamps to it
     } else {
         if ((rc = gm_pg_incomplete(idx, &n_inc, &pairs, st))) return rc;
@@ -978,6 +991,7 @@ static int run_pigeon_level(gm_index* idx, int level, bool nearest, int64_t n_q,
             if (rc) return rc;
             if (used2) {
                 if ((rc = gm_pg_scatter(idx, n_inc, keff, nearest, ids, dists, counts, st))) return rc;
+                if ((rc = publish_merge_counts())) return rc;
                 *used = true;
                 return GM_OK;
             }
@@ -1000,6 +1014,10 @@ static int run_pigeon_level(gm_index* idx, int level, bool nearest, int64_t n_q,
                 c.kind = 1;
                 c.cap = n_left;
                 if ((rc = gm_pg_publish_async(idx, 2, st, &c.pend))) return rc;
+                if (deferred >= 0) {
+                    sp->checks[(size_t)deferred].pend = c.pend;
+                    deferred = -1;
+                }
                 sp->checks.push_back(c);
                 idx->dev_rows = gm_pg_count_ptr(idx, 1);      // the rows the collect left (as of this publish)
             } else {
@@ -1033,6 +1051,10 @@ static int run_pigeon_level(gm_index* idx, int level, bool nearest, int64_t n_q,
             c.kind = 2;
             c.cap = n_bad;
             if ((rc = gm_pg_publish_async(idx, 3, st, &c.pend))) return rc;
+            if (deferred >= 0) {
+                sp->checks[(size_t)deferred].pend = c.pend;
+                deferred = -1;
+            }
             sp->checks.push_back(c);
             idx->dev_rows = gm_pg_count_ptr(idx, 1);
         } else {
@@ -1050,6 +1072,7 @@ static int run_pigeon_level(gm_index* idx, int level, bool nearest, int64_t n_q,
             if ((rc = gm_pg_scatter(idx, n_bad, keff, nearest, ids, dists, counts, st))) return rc;
         }
     }
+    if ((rc = publish_merge_counts())) return rc;
     *used = true;
     return GM_OK;
 }
@@ -1071,7 +1094,7 @@ int run_hamming_pigeon(gm_index* idx, bool nearest, int64_t n_q, int k, int32_t*
         bool ok = true;
         for (const SpecCheck& c : sp.checks) {
             int64_t n_inc = 0, n_bad = 0, pairs = 0;
-            if ((rc = gm_pg_pending_wait(&c.pend, c.kind == 0, st, &n_inc, &n_bad, &pairs))) {
+            if (c.pend.pg == nullptr || (rc = gm_pg_pending_wait(&c.pend, c.kind == 0, st, &n_inc, &n_bad, &pairs))) {
                 ok = false;      // (no mailbox on this platform after all: the synchronous run below decides)
                 break;
             }
