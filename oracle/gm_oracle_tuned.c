@@ -1,5 +1,5 @@
 /*
- * gm_oracle_tuned.c -- a FAST exact Hamming k-NN on the CPU.  TEST INFRASTRUCTURE ONLY (see gm_oracle.c's header: only
+ * gm_oracle_tuned.c -- FAST exact k-NN scans on the CPU (Hamming; Levenshtein at the end of the file).  TEST INFRASTRUCTURE ONLY (see gm_oracle.c's header: only
  * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load liboracle.so).
  *
  * Why it exists: gm_oracle.c restates nmslib's brute_force literally (three 32-bit one-hot words per pair, built for
@@ -70,7 +70,7 @@ static inline void tk_insert(topk_t* t, int k, int32_t nd, int32_t nid) {
     t->cnt = c + 1;
 }
 /* a pair enters when its distance is below this */
-static inline uint32_t tk_bound(const topk_t* t, int k) { return t->cnt == k ? (uint32_t)t->d[k - 1] : 0x7fffffffu; }
+static inline uint32_t tk_bound(const topk_t* t, int k) { return k > 0 && t->cnt == k ? (uint32_t)t->d[k - 1] : 0x7fffffffu; }
 
 /* ---- scalar ---- */
 static void scan_scalar(const uint32_t* lo, const uint32_t* hi, int64_t n_db, const uint32_t* qlo, const uint32_t* qhi, int nq,
@@ -230,3 +230,186 @@ int orc_knn_hamming_tuned(const char* db, int64_t n_db, const char* q, int64_t n
     free(lo); free(hi); free(qlo); free(qhi);
     return 0;
 }
+
+
+/* =====================================================================================================================
+ * Levenshtein.  gm_oracle.c's orc_leven is nmslib's `leven` restated literally (two-row O(L^2) dynamic programme per pair,
+ * /root/reference/guidemaker/core.py:461 is the call site): ~2 10^6 pairs/s per core, hours for a genome-sized pool.  Here
+ * the SAME unit-cost edit distance between two L-character strings comes from the bit-vector recurrence of Myers (J. ACM
+ * 46(3), 1999) in Hyyro's form for the global distance (the horizontal delta shifted into row 0 is +1): the candidate is
+ * the pattern (Peq[c] = positions where it has base c), the pool target streams through it one character per step, and
+ * 16 (AVX-512) / 8 (AVX2) / 1 targets advance per instruction, a target's character chosen per lane from its two bit
+ * planes.  ~20 vector operations per step and vector.  Results, order and padding exactly as orc_knn(metric = 1).
+ * Pinning: tests/test_oracle.py::test_tuned_leven_equals_the_port -- every path against orc_knn on pools with planted
+ * substitutions AND indels, every guide length, so it inherits the port's pins (reference known answer
+ * /root/reference/tests/test_core.py:346 = Levenshtein [0, 1, 2]).
+ * ===================================================================================================================== */
+static inline int lev_scalar(const uint32_t peq[4], uint32_t tlo, uint32_t thi, int L) {
+    uint32_t pv = 0xffffffffu, mv = 0;
+    int score = L;
+    const uint32_t top = 1u << (L - 1);
+    for (int j = 0; j < L; ++j) {
+        const uint32_t eq = peq[((tlo >> j) & 1u) | (((thi >> j) & 1u) << 1)];
+        const uint32_t xv = eq | mv;
+        const uint32_t xh = (((eq & pv) + pv) ^ pv) | eq;
+        uint32_t ph = mv | ~(xh | pv);
+        uint32_t mh = pv & xh;
+        score += (ph & top) ? 1 : 0;
+        score -= (mh & top) ? 1 : 0;
+        ph = (ph << 1) | 1u;
+        mh <<= 1;
+        pv = mh | ~(xv | ph);
+        mv = ph & xv;
+    }
+    return score;
+}
+
+static void lev_scan_scalar(const uint32_t* lo, const uint32_t* hi, int64_t j0, int64_t j1, const uint32_t peq[4], int L, int k,
+                            topk_t* tk) {
+    for (int64_t j = j0; j < j1; ++j) {
+        const uint32_t d = (uint32_t)lev_scalar(peq, lo[j], hi[j], L);
+        if (d < tk_bound(tk, k)) tk_insert(tk, k, (int32_t)d, (int32_t)j);
+    }
+}
+
+__attribute__((target("avx2"))) static void lev_scan_avx2(const uint32_t* lo, const uint32_t* hi, int64_t n_db, const uint32_t peq[4],
+                                                          int L, int k, topk_t* tk) {
+    const int64_t n8 = n_db & ~(int64_t)7;
+    const __m256i pA = _mm256_set1_epi32((int)peq[0]), pC = _mm256_set1_epi32((int)peq[1]), pG = _mm256_set1_epi32((int)peq[2]),
+                  pT = _mm256_set1_epi32((int)peq[3]);
+    const __m256i ones = _mm256_set1_epi32(-1), one = _mm256_set1_epi32(1), zero = _mm256_setzero_si256();
+    const __m256i top = _mm256_set1_epi32((int)(1u << (L - 1)));
+    uint32_t bound = tk_bound(tk, k);
+    for (int64_t j = 0; j < n8; j += 8) {
+        const __m256i tl = _mm256_loadu_si256((const __m256i*)(lo + j)), th = _mm256_loadu_si256((const __m256i*)(hi + j));
+        __m256i pv = ones, mv = zero, score = _mm256_set1_epi32(L);
+        for (int p = 0; p < L; ++p) {
+            const __m256i bit = _mm256_set1_epi32((int)(1u << p));
+            const __m256i ml = _mm256_cmpeq_epi32(_mm256_and_si256(tl, bit), bit), mh_ = _mm256_cmpeq_epi32(_mm256_and_si256(th, bit), bit);
+            const __m256i eq = _mm256_blendv_epi8(_mm256_blendv_epi8(pA, pC, ml), _mm256_blendv_epi8(pG, pT, ml), mh_);
+            const __m256i xv = _mm256_or_si256(eq, mv);
+            const __m256i xh = _mm256_or_si256(_mm256_xor_si256(_mm256_add_epi32(_mm256_and_si256(eq, pv), pv), pv), eq);
+            __m256i ph = _mm256_or_si256(mv, _mm256_andnot_si256(_mm256_or_si256(xh, pv), ones));
+            __m256i mh = _mm256_and_si256(pv, xh);
+            score = _mm256_sub_epi32(score, _mm256_cmpeq_epi32(_mm256_and_si256(ph, top), top));      /* - (-1) = + 1 */
+            score = _mm256_add_epi32(score, _mm256_cmpeq_epi32(_mm256_and_si256(mh, top), top));
+            ph = _mm256_or_si256(_mm256_slli_epi32(ph, 1), one);
+            mh = _mm256_slli_epi32(mh, 1);
+            pv = _mm256_or_si256(mh, _mm256_andnot_si256(_mm256_or_si256(xv, ph), ones));
+            mv = _mm256_and_si256(ph, xv);
+        }
+        int m = _mm256_movemask_ps(_mm256_castsi256_ps(_mm256_cmpgt_epi32(_mm256_set1_epi32((int)bound), score)));
+        if (m) {
+            uint32_t cc[8];
+            _mm256_storeu_si256((__m256i*)cc, score);
+            while (m) {
+                const int t = __builtin_ctz(m);
+                m &= m - 1;
+                if (cc[t] < bound) {
+                    tk_insert(tk, k, (int32_t)cc[t], (int32_t)(j + t));
+                    bound = tk_bound(tk, k);
+                }
+            }
+        }
+    }
+    lev_scan_scalar(lo, hi, n8, n_db, peq, L, k, tk);
+}
+
+__attribute__((target("avx512f"))) static void lev_scan_avx512(const uint32_t* lo, const uint32_t* hi, int64_t n_db, const uint32_t peq[4],
+                                                               int L, int k, topk_t* tk) {
+    const int64_t n16 = n_db & ~(int64_t)15;
+    const __m512i pA = _mm512_set1_epi32((int)peq[0]), pC = _mm512_set1_epi32((int)peq[1]), pG = _mm512_set1_epi32((int)peq[2]),
+                  pT = _mm512_set1_epi32((int)peq[3]);
+    const __m512i ones = _mm512_set1_epi32(-1), one = _mm512_set1_epi32(1);
+    const __m512i top = _mm512_set1_epi32((int)(1u << (L - 1)));
+    uint32_t bound = tk_bound(tk, k);
+    for (int64_t j = 0; j < n16; j += 16) {
+        const __m512i tl = _mm512_loadu_si512((const void*)(lo + j)), th = _mm512_loadu_si512((const void*)(hi + j));
+        __m512i pv = ones, mv = _mm512_setzero_si512(), score = _mm512_set1_epi32(L);
+        for (int p = 0; p < L; ++p) {
+            const __m512i bit = _mm512_set1_epi32((int)(1u << p));
+            const __mmask16 kl = _mm512_test_epi32_mask(tl, bit), kh = _mm512_test_epi32_mask(th, bit);
+            const __m512i eq = _mm512_mask_blend_epi32(kh, _mm512_mask_blend_epi32(kl, pA, pC), _mm512_mask_blend_epi32(kl, pG, pT));
+            const __m512i xv = _mm512_or_si512(eq, mv);
+            const __m512i xh = _mm512_or_si512(_mm512_xor_si512(_mm512_add_epi32(_mm512_and_si512(eq, pv), pv), pv), eq);
+            __m512i ph = _mm512_or_si512(mv, _mm512_andnot_si512(_mm512_or_si512(xh, pv), ones));
+            __m512i mh = _mm512_and_si512(pv, xh);
+            score = _mm512_mask_add_epi32(score, _mm512_test_epi32_mask(ph, top), score, one);
+            score = _mm512_mask_sub_epi32(score, _mm512_test_epi32_mask(mh, top), score, one);
+            ph = _mm512_or_si512(_mm512_slli_epi32(ph, 1), one);
+            mh = _mm512_slli_epi32(mh, 1);
+            pv = _mm512_or_si512(mh, _mm512_andnot_si512(_mm512_or_si512(xv, ph), ones));
+            mv = _mm512_and_si512(ph, xv);
+        }
+        unsigned mm = _mm512_cmplt_epu32_mask(score, _mm512_set1_epi32((int)bound));
+        if (mm) {
+            uint32_t cc[16];
+            _mm512_storeu_si512((void*)cc, score);
+            while (mm) {
+                const int t = __builtin_ctz(mm);
+                mm &= mm - 1;
+                if (cc[t] < bound) {
+                    tk_insert(tk, k, (int32_t)cc[t], (int32_t)(j + t));
+                    bound = tk_bound(tk, k);
+                }
+            }
+        }
+    }
+    lev_scan_scalar(lo, hi, n16, n_db, peq, L, k, tk);
+}
+
+/* 0 = scalar, 1 = AVX2, 2 = AVX-512F (no VPOPCNTDQ needed here) */
+static int pick_isa_lev(int force) {
+    int best = 0;
+    __builtin_cpu_init();
+    if (__builtin_cpu_supports("avx2")) best = 1;
+    if (__builtin_cpu_supports("avx512f")) best = 2;
+    return force >= 0 && force < best ? force : best;
+}
+
+/*
+ * Exact Levenshtein k-NN; same contract as orc_knn(metric = 1): db, q = rows of L chars (ACGT), ids / dists [n_q * k] padded
+ * with -1, dists = unit-cost edit distances, counts [n_q]; rows ordered by (distance, db index).  Returns 0, -1 on bad input.
+ */
+int orc_knn_leven_tuned(const char* db, int64_t n_db, const char* q, int64_t n_q, int L, int k, int32_t* ids, int32_t* dists,
+                        int32_t* counts, int threads, int force_isa) {
+    if (L < 1 || L > 32 || k < 1 || k > KMAX || n_db < 0 || n_q < 0 || n_db >= ((int64_t)1 << 31)) return -1;
+    uint32_t* lo = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(n_db + 16));
+    uint32_t* hi = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(n_db + 16));
+    uint32_t* qlo = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(n_q + 1));
+    uint32_t* qhi = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)(n_q + 1));
+    int rc = (!lo || !hi || !qlo || !qhi) ? -1 : 0;
+    if (!rc && (plane_pack(db, n_db, L, lo, hi) || plane_pack(q, n_q, L, qlo, qhi))) rc = -1;
+    if (rc) {
+        free(lo); free(hi); free(qlo); free(qhi);
+        return -1;
+    }
+    const int isa = pick_isa_lev(force_isa);
+    const uint32_t lmask = L >= 32 ? 0xffffffffu : ((1u << L) - 1u);
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#else
+    (void)threads;
+#endif
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int64_t i = 0; i < n_q; ++i) {
+        /* pattern = the candidate: positions where it has A / C / G / T */
+        const uint32_t a = qlo[i], b = qhi[i];
+        const uint32_t peq[4] = {~a & ~b & lmask, a & ~b & lmask, ~a & b & lmask, a & b & lmask};
+        topk_t tk;
+        tk.cnt = 0;
+        if (isa == 2) lev_scan_avx512(lo, hi, n_db, peq, L, k, &tk);
+        else if (isa == 1) lev_scan_avx2(lo, hi, n_db, peq, L, k, &tk);
+        else lev_scan_scalar(lo, hi, 0, n_db, peq, L, k, &tk);
+        int32_t* od = dists + i * k;
+        int32_t* oi = ids + i * k;
+        for (int j = 0; j < k; ++j) {
+            od[j] = j < tk.cnt ? tk.d[j] : -1;
+            oi[j] = j < tk.cnt ? tk.id[j] : -1;
+        }
+        counts[i] = tk.cnt;
+    }
+    free(lo); free(hi); free(qlo); free(qhi);
+    return 0;
+}
+int orc_tuned_isa_leven(void) { return pick_isa_lev(-1); }

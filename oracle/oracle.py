@@ -62,6 +62,10 @@ def lib():
                                             i32p, i32p, i32p, ctypes.c_int, ctypes.c_int]
         L.orc_knn_hamming_tuned.restype = ctypes.c_int
         L.orc_tuned_isa.restype = ctypes.c_int
+        L.orc_knn_leven_tuned.argtypes = [ctypes.c_char_p, i64, ctypes.c_char_p, i64, ctypes.c_int, ctypes.c_int,
+                                          i32p, i32p, i32p, ctypes.c_int, ctypes.c_int]
+        L.orc_knn_leven_tuned.restype = ctypes.c_int
+        L.orc_tuned_isa_leven.restype = ctypes.c_int
         _LIB = L
     return _LIB
 
@@ -141,6 +145,23 @@ def knn_tuned(db, q, L, k, threads=0, isa=-1):
     counts = np.empty((nq,), np.int32)
     p = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
     rc = lib().orc_knn_hamming_tuned(dbb, ndb, qb, nq, L, k, p(ids), p(dists), p(counts), threads, isa)
+    if rc != 0:
+        raise ValueError("oracle: bad input (non-ACGT base or bad argument)")
+    return ids, dists, counts
+
+
+def knn_leven_tuned(db, q, L, k, threads=0, isa=-1):
+    """The same answer as knn(..., 'leven', ...) -- exact, (distance, db index) order -- from gm_oracle_tuned.c (Myers /
+    Hyyro bit-vector recurrence, 16 targets per AVX-512 instruction / 8 per AVX2 / scalar; isa forces a slower path: 0
+    scalar, 1 AVX2).  Pinned against knn() by tests/test_oracle.py; used where a WHOLE genome-sized Levenshtein result is
+    checked (tests/test_gpu_fullsize.py)."""
+    dbb, ndb = _rows(db, L)
+    qb, nq = _rows(q, L)
+    ids = np.empty((nq, k), np.int32)
+    dists = np.empty((nq, k), np.int32)
+    counts = np.empty((nq,), np.int32)
+    p = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+    rc = lib().orc_knn_leven_tuned(dbb, ndb, qb, nq, L, k, p(ids), p(dists), p(counts), threads, isa)
     if rc != 0:
         raise ValueError("oracle: bad input (non-ACGT base or bad argument)")
     return ids, dists, counts

@@ -63,6 +63,23 @@ def _whole_pool_oracle(orc, pool, ids, dists, counts, stride=1):
     return checked
 
 
+def _whole_pool_oracle_leven(orc, pool, ids, dists, counts, stride=1):
+    """Every stride-th candidate row of a Levenshtein result against the fast exact CPU scan over the full pool."""
+    L, k = pool["guidelen"], pool["k"]
+    asc = np.frombuffer(b"ACGT", np.uint8)
+    shifts = (2 * np.arange(L, dtype=np.uint64))[None, :]
+    db = np.ascontiguousarray(asc[((pool["packed_db"][:, None] >> shifts) & np.uint64(3)).astype(np.uint8)])
+    rows_all = np.arange(0, pool["packed_all"].shape[0], stride)
+    checked = 0
+    for lo in range(0, rows_all.size, 50_000):
+        rows = rows_all[lo:lo + 50_000]
+        q = np.ascontiguousarray(asc[((pool["packed_all"][rows][:, None] >> shifts) & np.uint64(3)).astype(np.uint8)])
+        oi, od, oc = orc.knn_leven_tuned(db, q, L, k)
+        assert (oc == counts[rows]).all() and (od == dists[rows]).all() and (oi == ids[rows]).all(), (lo, stride)
+        checked += rows.size
+    return checked
+
+
 def _check_properties(pool, ids, dists, counts):
     k, n_db = pool["k"], pool["packed_db"].shape[0]
     assert (counts == min(k, n_db)).all()
@@ -205,6 +222,9 @@ def test_leven_workload_full_size(oracle):
         rows = np.sort(rng.choice(q.shape[0], size=ORACLE_ROWS, replace=False))
         oi, od, oc = _oracle_rows(oracle, pool, rows)
         assert (oc == counts[rows]).all() and (od == dists[rows]).all() and (oi == ids[rows]).all()
+        # ... and EVERY row (1.86 10^10 pairs) against the fast exact CPU scan (oracle/gm_oracle_tuned.c: Myers' bit-vector
+        # recurrence, pinned to the literal dynamic programme by tests/test_oracle.py::test_tuned_leven_equals_the_port)
+        assert _whole_pool_oracle_leven(oracle, pool, ids, dists, counts) == q.shape[0]
     finally:
         idx.close()
 

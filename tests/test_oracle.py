@@ -236,3 +236,48 @@ def test_tuned_oracle_equals_the_port(oracle, isa):
     got = orc.knn_tuned(tg, tg, 20, 10, isa=isa)
     assert all((a == b).all() for a, b in zip(got, want))
     assert orc.tuned_isa() in ("scalar popcnt", "AVX2", "AVX-512 VPOPCNTDQ")
+
+
+@pytest.mark.parametrize("isa", [-1, 1, 0])
+def test_tuned_leven_equals_the_port(oracle, isa):
+    """gm_oracle_tuned.c's Levenshtein scan (Myers / Hyyro bit-vector recurrence, 16 / 8 / 1 targets per instruction) is what
+    the GPU suite checks WHOLE Levenshtein results against; here it is pinned to the literal restatement of nmslib's `leven`
+    (gm_oracle.c orc_leven, the two-row dynamic programme; reference known answer tests/test_core.py:346): ids, distances,
+    counts, every guide length 4 .. 27 (+ 32), k from 1 to beyond the pool size, ragged sizes, skewed bases, pools with
+    planted substitutions, insertions and deletions (so that distances below the Hamming distance occur), duplicates."""
+    orc = oracle
+    rng = np.random.default_rng(140 + isa)
+    asc = np.frombuffer(b"ACGT", np.uint8)
+    cases = [(L, int(rng.integers(1, 700)), int(rng.integers(1, 120)), int(rng.choice([1, 2, 3, 5, 10, 20, 33, 64])))
+             for L in list(range(4, 28)) + [32]]
+    cases += [(20, 7, 30, 10), (23, 16, 8, 16), (23, 17, 9, 1), (23, 2051, 130, 5)]
+    below_hamming = 0
+    for L, n_db, n_q, k in cases:
+        p = rng.dirichlet([0.6] * 4) if rng.random() < 0.5 else [0.25] * 4
+        db = asc[rng.choice(4, size=(n_db, L), p=p)]
+        for _ in range(n_db // 2):      # planted relatives: a few edits of a pool member, indels included
+            s = list(db[int(rng.integers(0, n_db))])
+            for _ in range(int(rng.integers(1, 4))):
+                op, pos = int(rng.integers(0, 3)), int(rng.integers(0, L))
+                if op == 0:
+                    s[pos] = asc[int(rng.integers(0, 4))]
+                elif op == 1:
+                    s.insert(pos, asc[int(rng.integers(0, 4))])
+                    s.pop()
+                else:
+                    s.pop(pos)
+                    s.append(asc[int(rng.integers(0, 4))])
+            db[int(rng.integers(0, n_db))] = np.array(s, np.uint8)
+        q = np.concatenate([db[rng.integers(0, n_db, size=n_q // 2 + 1)], asc[rng.choice(4, size=(n_q // 2 + 1, L), p=p)]])
+        db, q = np.ascontiguousarray(db), np.ascontiguousarray(q)
+        want = orc.knn(db, q, L, "leven", k)
+        got = orc.knn_leven_tuned(db, q, L, k, isa=isa)
+        assert all((a == b).all() for a, b in zip(got, want)), (L, n_db, n_q, k, isa)
+        if n_db >= 50 and L >= 10:
+            hd = orc.knn(db, q, L, "hamming", min(k, 2))[1]
+            below_hamming += int(((got[1][:, :hd.shape[1]] >= 0) & (2 * got[1][:, :hd.shape[1]] < hd)).sum())
+    assert below_hamming > 0      # (the indels are felt: some neighbour is closer by edits than by substitutions)
+    # the reference's own three-row example (tests/test_core.py:332-347): distances 0, 1, 2
+    tri = ["CTAGTCACTAGCTGACAGCA", "CTAGACACTAGCTGACAGCA", "TAGTCACTAGCTGACTAGCA"]
+    ids, d, c = orc.knn_leven_tuned(tri, tri[:1], 20, 3, isa=isa)
+    assert d[0].tolist() == [0, 1, 2] and ids[0].tolist() == [0, 1, 2] and c[0] == 3

@@ -178,3 +178,31 @@ def test_pao1_levenshtein_gpu(oracle):
     q_b = np.ascontiguousarray(asc[((q[rows][:, None] >> shifts) & np.uint64(3)).astype(np.uint8)])
     oi, od, oc = oracle.knn(db_b, q_b, L, "leven", k)
     assert (oc == counts[rows]).all() and (od == dists[rows]).all() and (oi == ids[rows]).all()
+    # ... and every row against the fast exact CPU scan (Myers' bit-vector recurrence, pinned to the dynamic programme)
+    q_all = np.ascontiguousarray(asc[((q[:, None] >> shifts) & np.uint64(3)).astype(np.uint8)])
+    oi, od, oc = oracle.knn_leven_tuned(db_b, q_all, L, k)
+    assert (oc == counts).all() and (od == dists).all() and (oi == ids).all()
+
+
+@pytest.mark.gpu
+def test_pao1_l23_levenshtein_gpu(oracle):
+    """The genome's NGG targets cut at L = 23 under Levenshtein, k = 5 (bench.py's `pao1_l23`: 1 160 561 x 1 160 561, two
+    displaced-block partition levels + the plain pass): every 32nd candidate row against the fast exact CPU scan over
+    the WHOLE pool (4.2 10^10 pairs), ids, distances and counts bit for bit."""
+    pool = workloads.make_pool("pao1_l23")
+    L, k = pool["guidelen"], pool["k"]
+    q, db = pool["packed_all"], pool["packed_db"]
+    idx = _lib.Index(db, L, _lib.METRIC_LEVEN)
+    try:
+        ids, dists, counts = idx.knn(q, k)
+        assert idx.last_kernel()[0] == "k_leven_part_bs"
+    finally:
+        idx.close()
+    assert (counts == k).all() and (dists[:, 0] == 0).all() and (np.diff(dists, axis=1) >= 0).all()
+    asc = np.frombuffer(b"ACGT", np.uint8)
+    shifts = (2 * np.arange(L, dtype=np.uint64))[None, :]
+    db_b = np.ascontiguousarray(asc[((db[:, None] >> shifts) & np.uint64(3)).astype(np.uint8)])
+    rows = np.arange(0, q.shape[0], 32)
+    q_b = np.ascontiguousarray(asc[((q[rows][:, None] >> shifts) & np.uint64(3)).astype(np.uint8)])
+    oi, od, oc = oracle.knn_leven_tuned(db_b, q_b, L, k)
+    assert (oc == counts[rows]).all() and (od == dists[rows]).all() and (oi == ids[rows]).all()
